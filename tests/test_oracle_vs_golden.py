@@ -1,0 +1,166 @@
+"""The CPU oracle (oracle/mkgformer_oracle.py) against golden vectors captured from the
+unmodified reference by oracle/gen_goldens.py.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mkgformer_oracle as O
+
+TINY_V = O.VisionCfg(hidden_size=64, num_hidden_layers=12, num_attention_heads=4, intermediate_size=128,
+                     image_size=64, patch_size=32)
+
+
+def tiny_text_cfg(vocab):
+    return O.TextCfg(vocab_size=vocab, hidden_size=64, num_hidden_layers=12, num_attention_heads=4,
+                     intermediate_size=128, max_position_embeddings=64)
+
+
+def _tiny_setup(g):
+    vocab0 = int(g["vocab0"])
+    sd = O.init_params(TINY_V, tiny_text_cfg(vocab0), seed=int(g["weight_seed"]))
+    sd = O.init_relation_word(sd, g["analogy_relation_ids"].tolist())
+    batch = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in::")}
+    return sd, batch, tiny_text_cfg(vocab0 + 1)
+
+
+def test_g1_forward_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_tiny_e2e.npz"))
+    sd, b, tc = _tiny_setup(g)
+    np.testing.assert_allclose(sd["unimo.text_embeddings.word_embeddings.weight"][-1].numpy(), g["r_row"], atol=1e-7)
+    with torch.no_grad():
+        logits, trans = O.forward(sd, TINY_V, tc, b["input_ids"], b["attention_mask"], b["token_type_ids"],
+                                  b["pixel_values"], b["sep_idx"], train=False, full_logits=True)
+    np.testing.assert_allclose(trans.numpy(), g["trans"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(logits[0].numpy(), g["logits_b0"], atol=2e-5, rtol=1e-5)
+    B = logits.shape[0]
+    _, mi = (b["input_ids"] == 103).nonzero(as_tuple=True)
+    np.testing.assert_allclose(logits[torch.arange(B), mi].numpy(), g["mask_rows"], atol=2e-5, rtol=1e-5)
+    # lazy scoring == slicing the full logits
+    sc = O.score(sd, trans[torch.arange(B), mi], b["analogy_entity_ids"])
+    np.testing.assert_allclose(sc.numpy(), g["mask_rows"][:, b["analogy_entity_ids"].numpy()], atol=2e-5)
+
+
+def test_g1_loss_grads_ranks_metrics(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_tiny_e2e.npz"))
+    sd, b, tc = _tiny_setup(g)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    _, trans = O.forward(sd, TINY_V, tc, b["input_ids"], b["attention_mask"], b["token_type_ids"],
+                         b["pixel_values"], b["sep_idx"], train=False)
+    loss, mask_logits = O.finetune_loss(sd, trans, b["input_ids"], b["label"], b["rel_idx"], b["q_head_idx"],
+                                        b["a_head_idx"], b["analogy_entity_ids"], alpha=0.43)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k in g.files:
+        if k.startswith("grad::"):
+            got = sd[k[6:]].grad.numpy()
+            np.testing.assert_allclose(got, g[k], atol=3e-6, rtol=2e-4, err_msg=k)
+    # which tensors the reference leaves without a gradient (dead pooler / post layernorm)
+    none_ref = set(g["none_grad"].tolist())
+    none_got = {k for k, v in sd.items() if v.grad is None}
+    assert none_ref == none_got, (none_ref ^ none_got)
+    norms = dict(zip(g["grad_norm_names"].tolist(), g["grad_norm_vals"].tolist()))
+    for k, v in norms.items():
+        assert abs(float(sd[k].grad.norm()) - v) <= 1e-5 + 2e-4 * v, k
+    ranks = O.ranks_double_sort(mask_logits.detach(), b["label"])
+    np.testing.assert_array_equal(ranks, g["ranks"])
+    np.testing.assert_array_equal(O.ranks_count(mask_logits.detach(), b["label"]), g["ranks"])
+    m = O.rank_metrics(ranks)
+    for name, val in zip(g["metric_names"].tolist(), g["metric_vals"].tolist()):
+        assert abs(m[name] - val) < 1e-6, name
+
+
+def test_g2_real_dim_layers(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_layers_768.npz"))
+    vc, tc = O.VisionCfg(patch_size=32), O.TextCfg(vocab_size=1000)
+    sd = O.init_params(vc, tc, seed=int(g["weight_seed"]))
+    sd = {k: v.requires_grad_(True) for k, v in sd.items() if ".9." in k}
+    rng = np.random.default_rng(int(g["input_seed"]))
+    B, L, Nv = 2, 64, 1 + 2 * vc.num_patches
+    x_t = torch.from_numpy(rng.standard_normal((B, L, 768), dtype=np.float32)).requires_grad_(True)
+    x_v = torch.from_numpy(rng.standard_normal((B, Nv, 768), dtype=np.float32)).requires_grad_(True)
+    assert abs(float(x_t.detach().double().sum()) - float(g["x_t_sum"])) < 1e-6
+    am, sep = torch.from_numpy(g["attention_mask"]), torch.from_numpy(g["sep_idx"])
+    y_t, (k, v) = O.text_layer(sd, tc, 9, x_t, O.extended_mask(am), sep, x_v, train=False)
+    y_v = O.vision_layer(sd, vc, 9, x_v, (k, v))
+    w_t = torch.from_numpy(rng.standard_normal(y_t.shape, dtype=np.float32))
+    w_v = torch.from_numpy(rng.standard_normal(y_v.shape, dtype=np.float32))
+    ((y_t * w_t).sum() + (y_v * w_v).sum()).backward()
+    tol = dict(atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(y_t.detach().numpy()[:, ::4], g["y_t"], **tol)
+    np.testing.assert_allclose(y_v.detach().numpy()[:, ::8], g["y_v"], **tol)
+    np.testing.assert_allclose(k.detach().numpy()[:, ::7], g["k"], **tol)
+    np.testing.assert_allclose(v.detach().numpy()[:, ::7], g["v"], **tol)
+    np.testing.assert_allclose(x_t.grad.numpy()[:, ::4], g["gx_t"], atol=1e-4, rtol=1e-3)
+    np.testing.assert_allclose(x_v.grad.numpy()[:, ::8], g["gx_v"], atol=1e-4, rtol=1e-3)
+    p = "unimo.encoder.text_layer.9."
+    np.testing.assert_allclose(sd[p + "attention.self.adaptive_weight.0"].grad.numpy(), g["g_w0"], rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(sd[p + "attention.self.adaptive_weight.1"].grad.numpy(), g["g_w1"], rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(sd[p + "attention.self.key.weight"].grad.numpy()[:8], g["g_key_w"], rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(sd[p + "intermediate.fusion_dense.bias"].grad.numpy(), g["g_fd_b"], rtol=2e-3, atol=1e-4)
+    q = "unimo.encoder.vision_layers.9."
+    np.testing.assert_allclose(sd[q + "self_attn.q_proj.bias"].grad.numpy(), g["g_vq_b"], rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(sd[q + "mlp.fc1.weight"].grad.numpy()[:8], g["g_vfc1_w"], rtol=2e-3, atol=1e-4)
+
+
+def test_g3_loss_and_ranks(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_loss_rank.npz"))
+    lg = torch.from_numpy(g["logits"]).requires_grad_(True)
+    label = torch.from_numpy(g["label"])
+    loss = O.label_smooth_ce(lg, label, 0.1)
+    assert abs(float(loss) - float(g["lsce"])) < 1e-6
+    loss.backward()
+    np.testing.assert_allclose(lg.grad.numpy(), g["lsce_grad"], atol=1e-7)
+    np.testing.assert_array_equal(O.ranks_double_sort(lg.detach(), label), g["ranks"])
+    np.testing.assert_array_equal(O.ranks_count(lg.detach(), label), g["ranks"])
+    # tie row [1,3,3,2]: the reference's two unstable sorts give ranks {4,1|2,2|1,3}; count-based gives 1 for both 3s
+    tie_all = g["tie_ranks_all"][0]
+    assert tie_all[0] == 4 and tie_all[3] == 3 and sorted(tie_all[1:3].tolist()) == [1, 2]
+    h = torch.from_numpy(g["h"]).requires_grad_(True)
+    sim = O.relaxation_loss(h, torch.from_numpy(g["rel_idx"]), torch.from_numpy(g["q_head_idx"]), torch.from_numpy(g["a_head_idx"]))
+    assert abs(float(sim) - float(g["sim"])) < 1e-6
+    sim.backward()
+    np.testing.assert_allclose(h.grad.numpy(), g["sim_grad"], atol=1e-7)
+
+
+def test_g4_adamw_groups_schedule_and_steps(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_adamw.npz"))
+    g1 = np.load(os.path.join(golden_dir, "g1_tiny_e2e.npz"))
+    ref = dict(zip(g["group_names"].tolist(), g["group_wd"].tolist()))
+    sd, b, tc = _tiny_setup(g1)
+    assert set(ref) == set(sd)
+    for n, wd in ref.items():
+        assert O.decay_of(n) == wd, n
+    # the quirk: these ARE decayed
+    for n in ("unimo.encoder.vision_layers.0.layer_norm1.weight", "unimo.vision_pre_layrnorm.weight",
+              "unimo.encoder.text_layer.0.attention.self.adaptive_weight.0", "unimo.vision_embeddings.class_embedding"):
+        assert ref[n] == 0.01
+    T = int(g["num_training_steps"])
+    curve = [O.linear_schedule(s, 0.1 * T, T) for s in range(T + 1)]
+    np.testing.assert_allclose(curve, g["sched_curve"], atol=1e-12)
+    # three optimizer steps
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    vv = {k: torch.zeros_like(v) for k, v in sd.items()}
+    losses = []
+    for step in range(3):
+        for p in sd.values():
+            p.grad = None
+        _, trans = O.forward(sd, TINY_V, tc, b["input_ids"], b["attention_mask"], b["token_type_ids"],
+                             b["pixel_values"], b["sep_idx"], train=False)
+        loss, _ = O.finetune_loss(sd, trans, b["input_ids"], b["label"], b["rel_idx"], b["q_head_idx"],
+                                  b["a_head_idx"], b["analogy_entity_ids"], alpha=0.43)
+        loss.backward()
+        losses.append(float(loss))
+        lr = 5e-5 * O.linear_schedule(step, 0.1 * T, T)
+        assert abs(lr - float(g["lrs"][step])) < 1e-12
+        with torch.no_grad():
+            for k, p in sd.items():
+                if p.grad is None:
+                    continue
+                O.adamw_step(p, p.grad, m[k], vv[k], step + 1, lr, O.decay_of(k))
+    np.testing.assert_allclose(losses, g["losses"], atol=2e-5)
+    for k in g.files:
+        if k.startswith("after::"):
+            np.testing.assert_allclose(sd[k[7:]].detach().numpy(), g[k], atol=2e-6, rtol=1e-5, err_msg=k)
