@@ -1,0 +1,209 @@
+/* mart_hip.h -- C ABI of libmart_hip.so, the gfx950 (MI355X) kernels behind the MarT / MKGformer hot path.
+ *
+ * The reference (zjunlp/MKG_Analogy, /root/reference) is pure Python on torch ops: it has no FFI.  The drop-in
+ * boundary is its Python operator API (MarT/models/model.py:7 MKGformerKGC, MarT/models/modeling_unimo.py:848
+ * UnimoForMaskedLM.forward) and trainer surface (MarT/lit_models/transformer.py:18 TransformerLitModel).  This
+ * header is what the Python host side binds with ctypes; every entry point names the reference lines whose
+ * eager torch ops it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes; the CALLER owns every buffer (incl. workspaces); kernels never allocate or free
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no internal synchronisation
+ *   - return 0 on success, <0 on error (-1 bad argument, -2 launch failure); mart_last_error() has the text
+ *   - stateless and re-entrant; one host thread per GPU process
+ *   - bf16 tensors are raw uint16 storage; "ld*" are leading dimensions in ELEMENTS
+ */
+#ifndef MART_HIP_H
+#define MART_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MART_ACT_NONE 0
+#define MART_ACT_GELU 1   /* erf GELU   : transformers ACT2FN["gelu"],       modeling_unimo.py:454,967 */
+#define MART_ACT_QGELU 2  /* quick GELU : transformers ACT2FN["quick_gelu"], modeling_unimo.py:279     */
+
+const char* mart_last_error(void);
+int mart_abi_version(void);
+/* 0 if the current HIP device is gfx950, <0 otherwise (the product path refuses to run elsewhere) */
+int mart_check_device(void);
+
+/* ---------------------------------------------------------------- dense contractions
+ * C = epi( alpha * (A[M,K] B[N,K]^T + A2[M,K2] B2[N,K2]^T) ), bf16 operands, fp32 accumulate.
+ * epi: +bias(+bias2) -> store preact -> act -> *act'(mulz) -> +res_f32 -> +res_bf16 -> store C (bf16|f32) [+C2 bf16]
+ * Replaces nn.Linear / F.linear / conv-as-GEMM / bmm call sites: modeling_unimo.py:123-124 (patch embedding),
+ * :223-225,270 (CLIP q/k/v/out_proj), :284-286 (CLIP MLP), :327-333 (BERT q/k/v), :388,459-463,475 (BERT dense,
+ * intermediate.dense + fusion_dense as one K=2H contraction, output.dense), :405,411 (fusion bmm),
+ * :958,973 (MLM head: only the gathered [MASK] rows x the gathered entity rows of the tied embedding). */
+typedef struct {
+  const void* A; const void* B; const void* A2; const void* B2;   /* bf16; A2/B2 share lda/ldb, rows and strides */
+  int lda, ldb;
+  int M, N, K, K2;
+  const int32_t* a_rows; const int32_t* b_rows;                   /* optional row gathers (int32 indices) */
+  int batch; long long stride_a, stride_b, stride_c, stride_aux;   /* elements; aux = res/mulz */
+  const float* bias; const float* bias2; int bias_by_brow;        /* bias index = b_rows[n] when set */
+  int act; void* preact;                                          /* preact: bf16 [M,N] ld = ldc */
+  const void* mulz; int mul_act;                                  /* bf16 [M,N] ld = ldres */
+  const float* res_f32; const void* res_bf16; int ldres;          /* 0 -> ldc */
+  float alpha;
+  void* C; int ldc; int c_f32;
+  void* C2; int ldc2;                                             /* optional bf16 copy; 0 -> ldc */
+  int tile_cfg;                                                   /* 0 auto, 128, 256 */
+} mart_gemm_nt_desc;
+int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream);
+
+/* out[NX,NY] (f32, atomically accumulated) += alpha * X[M,NX]^T Y[M,NY]; optional colsum[NX] += sum_m X[m,:].
+ * Weight / bias gradients of every nn.Linear above (autograd of the same reference lines), the tied
+ * embedding gradient rows (out_rows scatter), and the fusion op's d(vis). */
+typedef struct {
+  const void* X; const void* Y; int ldx, ldy;                     /* bf16 */
+  int M, NX, NY;
+  float* out; int ldo; const int32_t* out_rows;
+  float* colsum; int colsum_by_row;                               /* colsum index = out_rows[nx] when set */
+  int batch; long long stride_x, stride_y, stride_o;
+  int splits;                                                     /* 0 auto */
+  float alpha;
+} mart_gemm_tn_desc;
+int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream);
+
+/* ---------------------------------------------------------------- layer norm family
+ * s = x_f32 (+ dropout(y_bf16, p)) ; out = LN(s) * gamma + beta.  nn.LayerNorm call sites
+ * modeling_unimo.py:509,518,711 (CLIP pre-LN, eps 1e-5), :390,477 (BERT post-LN with dropout+residual,
+ * eps 1e-12), :975 (head transform LN). */
+typedef struct {
+  const float* x_f32; const void* y_bf16;                         /* either may be NULL, not both */
+  float p_drop; uint64_t seed;                                    /* dropout on y_bf16 only */
+  const float* gamma; const float* beta; float eps;
+  int M, H;
+  float* s_out;                                                   /* optional: the pre-LN sum (saved for bwd) */
+  float* out_f32; void* out_bf16;                                 /* either may be NULL */
+  float* mean; float* rstd;                                       /* [M] */
+} mart_ln_fwd_desc;
+int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream);
+
+/* ds = LNbwd(dy_f32 + dy_bf16) + add_f32 ; dgamma/dbeta atomically accumulated.
+ * dx_bf16 = bf16(ds) * dropmask/(1-p) when p_drop>0 (gradient of the dropped-out branch y_bf16). */
+typedef struct {
+  const float* dy_f32; const void* dy_bf16;
+  const float* s; const float* mean; const float* rstd; const float* gamma;
+  const float* add_f32;
+  int M, H;
+  float* ds_f32; void* ds_bf16;
+  float p_drop; uint64_t seed;
+  float* dgamma; float* dbeta;
+} mart_ln_bwd_desc;
+int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream);
+
+/* ---------------------------------------------------------------- embeddings
+ * pixels f32 [B,2,3,S,S] -> bf16 patch matrix [B*2*P, 3*p*p] (k = c*p*p + ky*p + kx): the im2col-free
+ * operand of the bias-free patch conv, modeling_unimo.py:110-112,123-124. */
+int mart_patchify(const float* pixels, void* out_bf16, int B, int S, int p, void* stream);
+/* s[b,t,:] = [cls | patch(b,0,:) | patch(b,1,:)] + pos[0,1..P,1..P]   (modeling_unimo.py:127-130) */
+int mart_vision_assemble(const void* patch_bf16, const float* cls, const float* pos, float* s, int B, int P, int H, void* stream);
+/* backward of the assemble: dpatch (bf16) and atomically accumulated dcls, dpos */
+int mart_vision_assemble_bwd(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, void* stream);
+/* BertEmbeddings.forward (modeling_unimo.py:152-186): word[ids]+type[tt]+pos[:L] -> LN(eps) -> dropout */
+typedef struct {
+  const int64_t* ids; const int64_t* tt;
+  const float* word; const float* pos; const float* type;
+  const float* gamma; const float* beta; float eps;
+  float p_drop; uint64_t seed;
+  int B, L, H;
+  float* s_out; float* mean; float* rstd;
+  float* out_f32; void* out_bf16;
+} mart_text_embed_desc;
+int mart_text_embed_fwd(const mart_text_embed_desc* d, void* stream);
+/* dy*dropmask/(1-p) -> dyd (f32) : first half of the text-embedding backward (LN bwd follows) */
+int mart_dropout_bwd_f32(const float* dy_f32, const void* dy_bf16, float* out, long long n, float p, uint64_t seed, void* stream);
+/* scatter ds [B*L,H] into dword[ids], dpos[0..L), dtype[tt] (atomic) */
+int mart_text_embed_scatter(const float* ds, const int64_t* ids, const int64_t* tt, float* dword, float* dpos, float* dtype,
+                            int B, int L, int H, void* stream);
+
+/* ---------------------------------------------------------------- attention (head_dim 64)
+ * Flash-style multi-head attention, K/V tiles staged in LDS, wave-level online softmax.
+ *  vision: CLIPAttention.forward, modeling_unimo.py:212-272 -- no mask, keys = [text prefix (K,V) | own]
+ *  text  : BertSelfAttention.forward, :317-377 -- scores/8, adaptive analogy reweight (:342-349),
+ *          additive padding mask (:355, :55-56), softmax, attention-probs dropout (:362)
+ * q/k/v are column blocks of the fused projection output: element (row, h*64+d) at ptr[row*ld + h*64 + d],
+ * row = b*S + i.  Prefix keys j < Lp come from pk/pv (rows b*Lp + j). */
+typedef struct {
+  const void* q; const void* k; const void* v; int ldq, ldk, ldv;  /* bf16 */
+  const void* pk; const void* pv; int ldp; int Lp;                  /* optional text prefix */
+  int B, nh, Sq, Sk;                                                /* Sk = own keys (excl. prefix) */
+  float scale;
+  const int64_t* attn_mask;                                         /* [B,Sk] 1 = keep, NULL = none */
+  const int64_t* sep; int sep_stride;                               /* s = sep[b*sep_stride]; NULL = no reweight */
+  const float* w0; const float* w1;                                 /* device scalars, clamped in-kernel */
+  float p_drop; uint64_t seed;
+  void* ctx; int ldctx;                                             /* bf16 out [B*Sq, nh*64] */
+  float* lse;                                                       /* [B,nh,Sq] */
+} mart_attn_fwd_desc;
+int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream);
+
+typedef struct {
+  mart_attn_fwd_desc f;                                             /* same inputs as forward (ctx = forward output) */
+  const void* dctx; int lddctx;                                     /* bf16 */
+  float* delta;                                                     /* workspace [B,nh,Sq] */
+  void* dq; void* dk; void* dv; int lddq, lddk, lddv;               /* bf16 out */
+  void* dpk; void* dpv; int lddp;                                   /* bf16 out for prefix keys */
+  int accum_dkv;                                                    /* dk/dv += (text K/V already hold the prefix grads) */
+  float* dw;                                                        /* [2] atomically accumulated d(w0), d(w1) */
+} mart_attn_bwd_desc;
+int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream);
+
+/* ---------------------------------------------------------------- row softmax (fusion op, modeling_unimo.py:410)
+ * probs (bf16, ldp >= C, columns C..ldp zero-filled) = softmax(scores f32 [R,C]) */
+int mart_softmax_fwd(const float* scores, int lds_, void* probs_bf16, int ldp, int R, int C, void* stream);
+/* dscores (bf16, zero padded) = probs * (dprobs - sum(dprobs*probs)) */
+int mart_softmax_bwd(const void* probs_bf16, int ldp, const float* dprobs, int ldd, void* dscores_bf16, int ldo, int R, int C, void* stream);
+/* batched 2-D transpose with zero padding: out[b, c, r] = in[b, r, c], r < R else 0; out ld = Rp */
+int mart_transpose_bf16(const void* in, int ldi, long long stride_i, void* out, int Rp, long long stride_o, int R, int C, int batch, void* stream);
+
+/* ---------------------------------------------------------------- scoring head / loss / ranking
+ * LabelSmoothSoftmaxCEV1.forward (lit_models/utils.py:42-66): per-row loss and lse over C classes */
+int mart_lsce_fwd(const float* logits, int ld, const int64_t* label, float eps, float* loss_rows, float* lse, int R, int C, void* stream);
+/* dlogits = gscale[0] * rowscale * (softmax * sum(target) - target), bf16 (zero padded to ldo) and/or f32 */
+int mart_lsce_bwd(const float* logits, int ld, const int64_t* label, const float* lse, float eps, const float* gscale, float rowscale,
+                  void* dlogits_bf16, int ldo, float* dlogits_f32, int R, int C, void* stream);
+/* rank = 1 + #(logit > logit[label])  == argsort(argsort(-logits))[label]+1 without ties (lit_models/transformer.py:162-164) */
+int mart_rank(const float* logits, int ld, const int64_t* label, int64_t* rank, int R, int C, void* stream);
+/* relaxation loss rows (lit_models/transformer.py:103-108): relu(cos(q,a)) + 1 - cos(r0,r1) on rows of trans [B,L,H] */
+int mart_simloss_fwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, float* loss_rows,
+                     int B, int L, int H, void* stream);
+/* dtrans (atomic +=) for the four gathered rows; g = gscale[0]*rowscale */
+int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, const float* gscale,
+                     float rowscale, float* dtrans, int B, int L, int H, void* stream);
+
+/* ---------------------------------------------------------------- small utilities
+ * [MASK] position per row: (input_ids == mask_id).nonzero() without the host sync of lit_models/transformer.py:94 */
+int mart_find_token(const int64_t* ids, int B, int L, int64_t token, int32_t* pos_out, int32_t* row_out, void* stream);
+int mart_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
+int mart_cast_bf16_f32(const void* src, float* dst, long long n, void* stream);
+/* dst[r,:] = src[rows[r],:] for 2-byte (bf16) elements; H multiple of 8 */
+int mart_gather_rows_bf16(const void* src, int ld, const int32_t* rows, void* dst, int R, int H, void* stream);
+/* out = dy * act'(z), all bf16 (backward of the head transform activation, modeling_unimo.py:974) */
+int mart_act_bwd(const void* dy_bf16, const void* z_bf16, int act, void* out_bf16, long long n, void* stream);
+int mart_gather_rows_f32(const float* src, int ld, const int32_t* rows, float* dst, int R, int H, void* stream);
+int mart_scatter_add_rows_f32(const float* src, const int32_t* rows, float* dst, int ld, int R, int H, void* stream);
+/* out = a (+ b) with mixed dtypes; used to merge gradient contributions */
+int mart_add_f32_bf16(const float* a, const void* b_bf16, float* out_f32, void* out_bf16, long long n, void* stream);
+/* debug/test hook: the dropout keep-mask the kernels derive from (seed, index) */
+int mart_dropout_mask(uint8_t* out, long long n, float p, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------- optimizer (lit_models/transformer.py:224-241)
+ * Multi-tensor AdamW over the flat parameter buffer; also refreshes the bf16 shadow the GEMMs read.
+ * chunks: int32 triples (start, length, decay_flag), start/length in elements. */
+typedef struct {
+  float* master; const float* grad; float* m; float* v; void* shadow_bf16;
+  const int32_t* chunks; int n_chunks;
+  float lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale;
+} mart_adamw_desc;
+int mart_adamw(const mart_adamw_desc* d, void* stream);
+/* batched bf16 transposes described by int64 quadruples (src_off, dst_off, rows, cols) into the W^T shadow */
+int mart_transpose_table(const void* src_bf16, void* dst_bf16, const int64_t* table, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

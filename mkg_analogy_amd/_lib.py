@@ -1,0 +1,133 @@
+"""ctypes binding of libmart_hip.so (the C ABI declared in include/mart_hip.h).
+
+The library is built in-tree by ``mkg_analogy_amd._build`` / ``__graft_entry__.build()``.  There is NO fallback:
+if the shared object is missing or a call fails, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmart_hip.so")
+
+vp, i32, i64, f32, u64, u8 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint64, C.c_uint8
+
+
+class MartError(RuntimeError):
+    pass
+
+
+class GemmNT(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("A2", vp), ("B2", vp), ("lda", i32), ("ldb", i32),
+                ("M", i32), ("N", i32), ("K", i32), ("K2", i32), ("a_rows", vp), ("b_rows", vp),
+                ("batch", i32), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64), ("stride_aux", i64),
+                ("bias", vp), ("bias2", vp), ("bias_by_brow", i32), ("act", i32), ("preact", vp),
+                ("mulz", vp), ("mul_act", i32), ("res_f32", vp), ("res_bf16", vp), ("ldres", i32),
+                ("alpha", f32), ("C", vp), ("ldc", i32), ("c_f32", i32), ("C2", vp), ("ldc2", i32), ("tile_cfg", i32)]
+
+
+class GemmTN(C.Structure):
+    _fields_ = [("X", vp), ("Y", vp), ("ldx", i32), ("ldy", i32), ("M", i32), ("NX", i32), ("NY", i32),
+                ("out", vp), ("ldo", i32), ("out_rows", vp), ("colsum", vp), ("colsum_by_row", i32),
+                ("batch", i32), ("stride_x", i64), ("stride_y", i64), ("stride_o", i64), ("splits", i32), ("alpha", f32)]
+
+
+class LnFwd(C.Structure):
+    _fields_ = [("x_f32", vp), ("y_bf16", vp), ("p_drop", f32), ("seed", u64), ("gamma", vp), ("beta", vp), ("eps", f32),
+                ("M", i32), ("H", i32), ("s_out", vp), ("out_f32", vp), ("out_bf16", vp), ("mean", vp), ("rstd", vp)]
+
+
+class LnBwd(C.Structure):
+    _fields_ = [("dy_f32", vp), ("dy_bf16", vp), ("s", vp), ("mean", vp), ("rstd", vp), ("gamma", vp), ("add_f32", vp),
+                ("M", i32), ("H", i32), ("ds_f32", vp), ("ds_bf16", vp), ("p_drop", f32), ("seed", u64),
+                ("dgamma", vp), ("dbeta", vp)]
+
+
+class TextEmbed(C.Structure):
+    _fields_ = [("ids", vp), ("tt", vp), ("word", vp), ("pos", vp), ("type", vp), ("gamma", vp), ("beta", vp), ("eps", f32),
+                ("p_drop", f32), ("seed", u64), ("B", i32), ("L", i32), ("H", i32), ("s_out", vp), ("mean", vp), ("rstd", vp),
+                ("out_f32", vp), ("out_bf16", vp)]
+
+
+class AttnFwd(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("ldq", i32), ("ldk", i32), ("ldv", i32),
+                ("pk", vp), ("pv", vp), ("ldp", i32), ("Lp", i32),
+                ("B", i32), ("nh", i32), ("Sq", i32), ("Sk", i32), ("scale", f32),
+                ("attn_mask", vp), ("sep", vp), ("sep_stride", i32), ("w0", vp), ("w1", vp),
+                ("p_drop", f32), ("seed", u64), ("ctx", vp), ("ldctx", i32), ("lse", vp)]
+
+
+class AttnBwd(C.Structure):
+    _fields_ = [("f", AttnFwd), ("dctx", vp), ("lddctx", i32), ("delta", vp),
+                ("dq", vp), ("dk", vp), ("dv", vp), ("lddq", i32), ("lddk", i32), ("lddv", i32),
+                ("dpk", vp), ("dpv", vp), ("lddp", i32), ("accum_dkv", i32), ("dw", vp)]
+
+
+class AdamW(C.Structure):
+    _fields_ = [("master", vp), ("grad", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("chunks", vp), ("n_chunks", i32),
+                ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bc1", f32), ("bc2", f32),
+                ("grad_scale", f32)]
+
+
+_SIGS = {
+    "mart_last_error": (C.c_char_p, []),
+    "mart_abi_version": (i32, []),
+    "mart_check_device": (i32, []),
+    "mart_gemm_nt": (i32, [C.POINTER(GemmNT), vp]),
+    "mart_gemm_tn": (i32, [C.POINTER(GemmTN), vp]),
+    "mart_ln_fwd": (i32, [C.POINTER(LnFwd), vp]),
+    "mart_ln_bwd": (i32, [C.POINTER(LnBwd), vp]),
+    "mart_patchify": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mart_vision_assemble": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mart_vision_assemble_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mart_text_embed_fwd": (i32, [C.POINTER(TextEmbed), vp]),
+    "mart_dropout_bwd_f32": (i32, [vp, vp, vp, i64, f32, u64, vp]),
+    "mart_text_embed_scatter": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mart_attn_fwd": (i32, [C.POINTER(AttnFwd), vp]),
+    "mart_attn_bwd": (i32, [C.POINTER(AttnBwd), vp]),
+    "mart_softmax_fwd": (i32, [vp, i32, vp, i32, i32, i32, vp]),
+    "mart_softmax_bwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "mart_transpose_bf16": (i32, [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp]),
+    "mart_lsce_fwd": (i32, [vp, i32, vp, f32, vp, vp, i32, i32, vp]),
+    "mart_lsce_bwd": (i32, [vp, i32, vp, vp, f32, vp, f32, vp, i32, vp, i32, i32, vp]),
+    "mart_rank": (i32, [vp, i32, vp, vp, i32, i32, vp]),
+    "mart_simloss_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mart_simloss_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
+    "mart_find_token": (i32, [vp, i32, i32, i64, vp, vp, vp]),
+    "mart_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
+    "mart_cast_bf16_f32": (i32, [vp, vp, i64, vp]),
+    "mart_gather_rows_bf16": (i32, [vp, i32, vp, vp, i32, i32, vp]),
+    "mart_act_bwd": (i32, [vp, vp, i32, vp, i64, vp]),
+    "mart_gather_rows_f32": (i32, [vp, i32, vp, vp, i32, i32, vp]),
+    "mart_scatter_add_rows_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "mart_add_f32_bf16": (i32, [vp, vp, vp, vp, i64, vp]),
+    "mart_dropout_mask": (i32, [vp, i64, f32, u64, vp]),
+    "mart_adamw": (i32, [C.POINTER(AdamW), vp]),
+    "mart_transpose_table": (i32, [vp, vp, vp, i32, vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library.  Raises MartError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MartError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(the MKGformer path has no non-HIP fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().mart_last_error()
+        raise MartError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,497 @@
+// Flash-style multi-head attention for head_dim 64 on gfx950 (forward, dQ pass, dK/dV pass).
+//
+// One skeleton, three kernels.  A wave OWNS 32 rows (queries in fwd/dQ, keys in dK/dV) whose fragments stay in
+// registers as MFMA B operands, so every MFMA result has "lane = owner row": online-softmax state, rescaling and
+// the final stores are lane-local.  The other side is STREAMED in 64-row tiles through a double-buffered LDS
+// ring filled by LDS-DMA (global_load_lds); first-GEMM fragments are plain ds_read_b128 on an XOR-swizzled
+// image, second-GEMM fragments (contraction over the streamed rows) use the LDS transpose read.
+//
+//  vision (CLIPAttention, modeling_unimo.py:212-272): softmax(q k^T * dh^-0.5), no mask, keys = [text prefix | own]
+//  text   (BertSelfAttention, :317-377): scores/8 -> adaptive analogy reweight (:342-349) -> + (1-mask)*-1e4
+//          (:355,:55-56) -> softmax -> dropout(p) on the probabilities (:362)
+#include "common.h"
+#include "mart_hip.h"
+
+namespace {
+
+constexpr int NTH = 256;                 // 4 waves
+constexpr int TILE_BYTES = 64 * 128;     // 64 rows x 64 bf16
+constexpr int STAGE_BYTES = 2 * TILE_BYTES + 512;   // two tiles + 2x64 floats (lse, delta)
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+
+struct Side {                            // a [rows, nh*64] bf16 view with an optional prefix block in front
+  const bf16* own; int ld_own; int n_own;          // rows of this batch element: own[(b*n_own + j)*ld_own + h*64 + d]
+  const bf16* pre; int ld_pre; int n_pre;
+};
+__device__ __forceinline__ const bf16* side_row(const Side& s, int b, int h, int j) {
+  // j in [0, n_pre + n_own); clamps to the last valid row
+  j = min(j, s.n_pre + s.n_own - 1);
+  if (j < s.n_pre) return s.pre + ((long long)b * s.n_pre + j) * s.ld_pre + h * 64;
+  return s.own + ((long long)b * s.n_own + (j - s.n_pre)) * s.ld_own + h * 64;
+}
+
+// stage one 64x64 tile (rows r0..r0+63 of `s`) into LDS with the chunk swizzle c' = c ^ ((row>>1)&7)
+__device__ __forceinline__ void stage_tile(const Side& s, int b, int h, int r0, char* lds, int tid, int wave) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int c = r * NTH + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
+    glds16(side_row(s, b, h, r0 + row) + lc * 8, lds + (r * NTH + wave * 64) * 16);
+  }
+}
+// plain fragment: rows t*32 + l31, k-step ks (16 of the 64 head dims)
+__device__ __forceinline__ bf16x8 tile_frag(const char* lds, int t, int ks, int l31, int hh) {
+  const int row = t * 32 + l31, lc = ks * 2 + hh;
+  return *(const bf16x8*)(lds + row * 128 + ((lc ^ ((row >> 1) & 7)) << 4));
+}
+// transposed fragment for the second GEMM: A[i = dim dt*32 + l31][k = 8 streamed rows]; k order matches the
+// register order of an MFMA result tile: e<4 -> row base+4hh+e, e>=4 -> row base+8+4hh+(e-4)
+__device__ __forceinline__ bf16x8 tile_frag_tr(const char* lds, int base, int dt, int lane) {
+  const int pp = lane & 15, g1 = (lane >> 4) & 1, hh = lane >> 5;
+  const int col = dt * 32 + g1 * 16 + (pp & 3) * 4;
+  const int r1 = base + 4 * hh + (pp >> 2), r2 = r1 + 8;
+  const int lc = col >> 3, bo = (col & 7) * 2;
+  s16x4 lo = lds_tr_read(lds + r1 * 128 + ((lc ^ ((r1 >> 1) & 7)) << 4) + bo);
+  s16x4 hi = lds_tr_read(lds + r2 * 128 + ((lc ^ ((r2 >> 1) & 7)) << 4) + bo);
+  return join_tr(lo, hi);
+}
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+  return o;
+}
+
+struct TextCtl {                          // per-(b) text controls, all optional
+  const int64_t* mask_row;                // attention_mask row of this batch element or NULL
+  int sep;                                // reweight split, <0 = off
+  float c0, c1;
+  float p_drop, inv_keep; uint64_t seed;
+};
+__device__ __forceinline__ TextCtl make_ctl(const mart_attn_fwd_desc& p, int b, int Sk) {
+  TextCtl c;
+  c.mask_row = p.attn_mask ? p.attn_mask + (long long)b * Sk : nullptr;
+  c.sep = p.sep ? (int)p.sep[(long long)b * p.sep_stride] : -1;
+  c.c0 = p.w0 ? fminf(fmaxf(p.w0[0], 0.f), 0.5f) : 1.f;
+  c.c1 = p.w1 ? fminf(fmaxf(p.w1[0], 0.5f), 1.f) : 1.f;
+  c.p_drop = p.p_drop; c.inv_keep = 1.f / (1.f - p.p_drop); c.seed = p.seed;
+  return c;
+}
+__device__ __forceinline__ float reweight(const TextCtl& c, int qi, int kj) {
+  if (c.sep < 0 || kj < c.sep) return 1.f;
+  return qi < c.sep ? c.c0 : c.c1;
+}
+
+// =========================================================================== forward
+__global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int Stot = p.Lp + p.Sk;
+  const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
+  const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
+  const TextCtl ctl = make_ctl(p, b, p.Sk);
+  const bool text = ctl.mask_row || ctl.sep >= 0 || ctl.p_drop > 0.f;
+
+  const int qi = q0 + l31;
+  const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + min(qi, p.Sq - 1)) * p.ldq + h * 64;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  const int ntiles = (Stot + 63) / 64;
+  stage_tile(K, b, h, 0, smem, tid, wave);
+  stage_tile(V, b, h, 0, smem + TILE_BYTES, tid, wave);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+    if (kt + 1 < ntiles) {
+      char* nb = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      stage_tile(K, b, h, (kt + 1) * 64, nb, tid, wave);
+      stage_tile(V, b, h, (kt + 1) * 64, nb + TILE_BYTES, tid, wave);
+    }
+    const char* sK = smem + (kt & 1) * STAGE_BYTES;
+    const char* sV = sK + TILE_BYTES;
+    // S^T[key][q] = K q^T
+    f32x16 st[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st[t] = mfma32(tile_frag(sK, t, ks, l31, hh), qf[ks], st[t]);
+    }
+    float pv[2][16];
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
+        float s = st[t][r] * p.scale;
+        if (text) {
+          s *= reweight(ctl, qi, kj);
+          if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+        }
+        if (kj >= Stot) s = -1.0e30f;
+        pv[t][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(pv[t][r] - m_new);
+        rs += e;
+        float used = e;
+        if (ctl.p_drop > 0.f) {
+          const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
+          const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
+          used = dropout_keep(ctl.seed, idx, ctl.p_drop) ? e * ctl.inv_keep : 0.f;
+        }
+        pv[t][r] = used;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+    // O^T[d][q] += V^T P^T
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bf16x8 pf = pack8(&pv[t][8 * a]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) ot[dt] = mfma32(tile_frag_tr(sV, t * 32 + 16 * a, dt, lane), pf, ot[dt]);
+      }
+  }
+  if (qi < p.Sq) {
+    const float inv = 1.f / l_run;
+    bf16* op = (bf16*)p.ctx + ((long long)b * p.Sq + qi) * p.ldctx + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v = {ot[dt][4 * qd] * inv, ot[dt][4 * qd + 1] * inv, ot[dt][4 * qd + 2] * inv, ot[dt][4 * qd + 3] * inv};
+        *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
+      }
+    if (hh == 0 && p.lse) p.lse[((long long)b * p.nh + h) * p.Sq + qi] = m_run + __logf(l_run);
+  }
+}
+
+// =========================================================================== delta = rowsum(dO * O)
+__global__ void attn_delta_k(const bf16* __restrict__ o, int ldo, const bf16* __restrict__ dout, int lddo, float* __restrict__ delta,
+                             int B, int nh, int Sq) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, q, h) with h fastest
+  const long long n = (long long)B * Sq * nh;
+  if (i >= n) return;
+  const int h = (int)(i % nh);
+  const long long row = i / nh;                                             // b*Sq + q
+  const bf16* a = o + row * ldo + h * 64;
+  const bf16* g = dout + row * lddo + h * 64;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    bf16x8 x = *(const bf16x8*)(a + c * 8), y = *(const bf16x8*)(g + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += (float)x[e] * (float)y[e];
+  }
+  const long long bq = row;
+  const int bb = (int)(bq / Sq), q = (int)(bq % Sq);
+  delta[((long long)bb * nh + h) * Sq + q] = acc;
+}
+
+// =========================================================================== backward, dQ pass (owner = queries)
+__global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const mart_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int Stot = p.Lp + p.Sk;
+  const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
+  const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
+  const TextCtl ctl = make_ctl(p, b, p.Sk);
+  const bool text = ctl.mask_row || ctl.sep >= 0 || ctl.p_drop > 0.f;
+
+  const int qi = q0 + l31, qc = min(qi, p.Sq - 1);
+  const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + qc) * p.ldq + h * 64;
+  const bf16* gp = (const bf16*)pb.dctx + ((long long)b * p.Sq + qc) * pb.lddctx + h * 64;
+  bf16x8 qf[4], gf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
+    gf[ks] = *(const bf16x8*)(gp + ks * 16 + hh * 8);
+  }
+  const long long li = ((long long)b * p.nh + h) * p.Sq + qc;
+  const float lse = p.lse[li], delta = pb.delta[li];
+  const bool qvalid = qi < p.Sq;
+
+  f32x16 dq[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+  float dc0 = 0.f, dc1 = 0.f;
+
+  const int ntiles = (Stot + 63) / 64;
+  stage_tile(K, b, h, 0, smem, tid, wave);
+  stage_tile(V, b, h, 0, smem + TILE_BYTES, tid, wave);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();
+    if (kt + 1 < ntiles) {
+      char* nb = smem + ((kt + 1) & 1) * STAGE_BYTES;
+      stage_tile(K, b, h, (kt + 1) * 64, nb, tid, wave);
+      stage_tile(V, b, h, (kt + 1) * 64, nb + TILE_BYTES, tid, wave);
+    }
+    const char* sK = smem + (kt & 1) * STAGE_BYTES;
+    const char* sV = sK + TILE_BYTES;
+    f32x16 st[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[t][r] = 0.f; dp[t][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        st[t] = mfma32(tile_frag(sK, t, ks, l31, hh), qf[ks], st[t]);
+        dp[t] = mfma32(tile_frag(sV, t, ks, l31, hh), gf[ks], dp[t]);
+      }
+    }
+    float dsv[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
+        const float spre = st[t][r] * p.scale;
+        float f = 1.f, s = spre;
+        if (text) {
+          f = reweight(ctl, qi, kj);
+          s *= f;
+          if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+        }
+        float pr = (kj < Stot && qvalid) ? __expf(s - lse) : 0.f;
+        float dpd = dp[t][r];
+        if (ctl.p_drop > 0.f) {
+          const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
+          dpd = dropout_keep(ctl.seed, idx, ctl.p_drop) ? dpd * ctl.inv_keep : 0.f;
+        }
+        const float ds = pr * (dpd - delta);           // d/d(post-reweight, pre-mask score)
+        if (ctl.sep >= 0 && kj >= ctl.sep) { if (qi < ctl.sep) dc0 += ds * spre; else dc1 += ds * spre; }
+        dsv[t][r] = ds * f * p.scale;                  // d/d(raw q.k)
+      }
+    // dQ^T[d][q] += K^T dS^T
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bf16x8 df = pack8(&dsv[t][8 * a]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tile_frag_tr(sK, t * 32 + 16 * a, dt, lane), df, dq[dt]);
+      }
+  }
+  if (qvalid) {
+    bf16* op = (bf16*)pb.dq + ((long long)b * p.Sq + qi) * pb.lddq + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f32x4 v = {dq[dt][4 * qd], dq[dt][4 * qd + 1], dq[dt][4 * qd + 2], dq[dt][4 * qd + 3]};
+        *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
+      }
+  }
+  if (pb.dw && ctl.sep >= 0) {
+    dc0 = wave_sum(dc0); dc1 = wave_sum(dc1);
+    if (lane == 0) {
+      const float w0 = p.w0[0], w1 = p.w1[0];
+      if (w0 >= 0.f && w0 <= 0.5f) atomicAdd(pb.dw + 0, dc0);     // clamp sub-gradient: passes inside and AT the bounds
+      if (w1 >= 0.5f && w1 <= 1.f) atomicAdd(pb.dw + 1, dc1);
+    }
+  }
+}
+
+// =========================================================================== backward, dK/dV pass (owner = keys)
+__global__ __launch_bounds__(NTH) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const mart_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int Stot = p.Lp + p.Sk;
+  const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
+  const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
+  const Side Q{(const bf16*)p.q, p.ldq, p.Sq, nullptr, 0, 0};
+  const Side G{(const bf16*)pb.dctx, pb.lddctx, p.Sq, nullptr, 0, 0};
+  const TextCtl ctl = make_ctl(p, b, p.Sk);
+  const bool text = ctl.mask_row || ctl.sep >= 0 || ctl.p_drop > 0.f;
+
+  const int kj = k0 + l31;
+  const bool kvalid = kj < Stot;
+  const bf16* kp = side_row(K, b, h, kj);
+  const bf16* vp = side_row(V, b, h, kj);
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = *(const bf16x8*)(kp + ks * 16 + hh * 8);
+    vf[ks] = *(const bf16x8*)(vp + ks * 16 + hh * 8);
+  }
+  const float maskadd = (ctl.mask_row && kvalid) ? (1.0f - (float)ctl.mask_row[kj]) * -10000.0f : 0.f;
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+
+  const float* lse_b = p.lse + ((long long)b * p.nh + h) * p.Sq;
+  const float* del_b = pb.delta + ((long long)b * p.nh + h) * p.Sq;
+  auto stage_stats = [&](int q0, char* base) {       // 64 lse + 64 delta floats via 4-byte LDS-DMA (waves 0,1)
+    if (wave < 2) {
+      const float* src = (wave == 0 ? lse_b : del_b) + min(q0 + lane, p.Sq - 1);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + 2 * TILE_BYTES + wave * 256), 4, 0, 0);
+    }
+  };
+
+  const int ntiles = (p.Sq + 63) / 64;
+  stage_tile(Q, b, h, 0, smem, tid, wave);
+  stage_tile(G, b, h, 0, smem + TILE_BYTES, tid, wave);
+  stage_stats(0, smem);
+  for (int qt = 0; qt < ntiles; ++qt) {
+    __syncthreads();
+    if (qt + 1 < ntiles) {
+      char* nb = smem + ((qt + 1) & 1) * STAGE_BYTES;
+      stage_tile(Q, b, h, (qt + 1) * 64, nb, tid, wave);
+      stage_tile(G, b, h, (qt + 1) * 64, nb + TILE_BYTES, tid, wave);
+      stage_stats((qt + 1) * 64, nb);
+    }
+    const char* sQ = smem + (qt & 1) * STAGE_BYTES;
+    const char* sG = sQ + TILE_BYTES;
+    const float* sLse = (const float*)(sQ + 2 * TILE_BYTES);
+    const float* sDel = sLse + 64;
+    // S[q][key] = Q k^T ; dP[q][key] = dO v^T      (lane = key)
+    f32x16 st[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[t][r] = 0.f; dp[t][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        st[t] = mfma32(tile_frag(sQ, t, ks, l31, hh), kf[ks], st[t]);
+        dp[t] = mfma32(tile_frag(sG, t, ks, l31, hh), vf[ks], dp[t]);
+      }
+    }
+    float pd[2][16], dsv[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = t * 32 + mfma_row(r, hh);
+        const int qi = qt * 64 + ql;
+        float f = 1.f, s = st[t][r] * p.scale;
+        if (text) { f = reweight(ctl, qi, kj); s = s * f + maskadd; }
+        const float pr = (kvalid && qi < p.Sq) ? __expf(s - sLse[ql]) : 0.f;
+        float keep = 1.f;
+        if (ctl.p_drop > 0.f) {
+          const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
+          keep = dropout_keep(ctl.seed, idx, ctl.p_drop) ? ctl.inv_keep : 0.f;
+        }
+        pd[t][r] = pr * keep;
+        dsv[t][r] = pr * (dp[t][r] * keep - sDel[ql]) * f * p.scale;
+      }
+    // dV^T[d][key] += dO^T Pd ; dK^T[d][key] += Q^T dS
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const bf16x8 pf = pack8(&pd[t][8 * a]);
+        const bf16x8 df = pack8(&dsv[t][8 * a]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = mfma32(tile_frag_tr(sG, t * 32 + 16 * a, dt, lane), pf, dv[dt]);
+          dk[dt] = mfma32(tile_frag_tr(sQ, t * 32 + 16 * a, dt, lane), df, dk[dt]);
+        }
+      }
+  }
+  if (!kvalid) return;
+  bf16* okp; bf16* ovp; bool acc = false;
+  if (kj < p.Lp) {
+    okp = (bf16*)pb.dpk + ((long long)b * p.Lp + kj) * pb.lddp + h * 64;
+    ovp = (bf16*)pb.dpv + ((long long)b * p.Lp + kj) * pb.lddp + h * 64;
+  } else {
+    okp = (bf16*)pb.dk + ((long long)b * p.Sk + (kj - p.Lp)) * pb.lddk + h * 64;
+    ovp = (bf16*)pb.dv + ((long long)b * p.Sk + (kj - p.Lp)) * pb.lddv + h * 64;
+    acc = pb.accum_dkv != 0;
+  }
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int off = dt * 32 + 8 * qd + 4 * hh;
+      f32x4 a = {dk[dt][4 * qd], dk[dt][4 * qd + 1], dk[dt][4 * qd + 2], dk[dt][4 * qd + 3]};
+      f32x4 c = {dv[dt][4 * qd], dv[dt][4 * qd + 1], dv[dt][4 * qd + 2], dv[dt][4 * qd + 3]};
+      if (acc) { a += bf4_to_f4(*(const bf16x4*)(okp + off)); c += bf4_to_f4(*(const bf16x4*)(ovp + off)); }
+      *(bf16x4*)(okp + off) = f4_to_bf4(a);
+      *(bf16x4*)(ovp + off) = f4_to_bf4(c);
+    }
+}
+
+int check_fwd(const mart_attn_fwd_desc* d) {
+  MART_CHECK(d && d->q && d->k && d->v && d->ctx, "attn: null pointer");
+  MART_CHECK(d->B > 0 && d->nh > 0 && d->Sq > 0 && d->Sk > 0 && d->Lp >= 0, "attn: bad shape");
+  MART_CHECK(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldctx % 4 == 0, "attn: leading dims must keep 16-byte rows");
+  MART_CHECK(d->Lp == 0 || (d->pk && d->pv && d->ldp % 8 == 0), "attn: prefix needs pk/pv/ldp");
+  MART_CHECK((d->w0 == nullptr) == (d->w1 == nullptr), "attn: w0/w1 must come together");
+  MART_CHECK(!d->sep || (d->w0 && d->Lp == 0), "attn: reweight needs w0/w1 and no prefix");
+  MART_CHECK(!d->attn_mask || d->Lp == 0, "attn: mask with prefix unsupported");
+  MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "attn: bad dropout p");
+  return 0;
+}
+bool g_attr_set = false;
+int set_attrs() {
+  if (g_attr_set) return 0;
+  if (hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+      hipFuncSetAttribute((const void*)attn_bwd_dq_k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+      hipFuncSetAttribute((const void*)attn_bwd_dkv_k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    mart_set_error("attn: hipFuncSetAttribute failed");
+    return -2;
+  }
+  g_attr_set = true;
+  return 0;
+}
+}  // namespace
+
+extern "C" int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream) {
+  if (int rc = check_fwd(d)) return rc;
+  if (int rc = set_attrs()) return rc;
+  hipLaunchKernelGGL(attn_fwd_k, dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream) {
+  MART_CHECK(d != nullptr, "attn_bwd: null descriptor");
+  if (int rc = check_fwd(&d->f)) return rc;
+  MART_CHECK(d->f.lse && d->dctx && d->delta && d->dq && d->dk && d->dv, "attn_bwd: null pointer");
+  MART_CHECK(d->lddctx % 8 == 0 && d->lddq % 4 == 0 && d->lddk % 4 == 0 && d->lddv % 4 == 0, "attn_bwd: bad leading dims");
+  MART_CHECK(d->f.Lp == 0 || (d->dpk && d->dpv && d->lddp % 4 == 0), "attn_bwd: prefix grads need dpk/dpv");
+  if (int rc = set_attrs()) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const mart_attn_fwd_desc& f = d->f;
+  const long long n = (long long)f.B * f.Sq * f.nh;
+  hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16*)f.ctx, f.ldctx, (const bf16*)d->dctx,
+                     d->lddctx, d->delta, f.B, f.nh, f.Sq);
+  MART_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dq_k, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
+  MART_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dkv_k, dim3((f.Lp + f.Sk + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
+  MART_LAUNCH_CHECK();
+  return 0;
+}

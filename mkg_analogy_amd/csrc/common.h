@@ -1,0 +1,133 @@
+// Shared device helpers for the MarT/MKGformer gfx950 kernels.
+// gfx950 (CDNA4) only: wave64, MFMA 32x32x16 bf16, LDS-DMA (global_load_lds), ds_read_b64_tr_b16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---- error plumbing shared by every translation unit (defined in util.hip)
+extern "C" void mart_set_error(const char* msg);
+#define MART_CHECK(cond, msg)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      mart_set_error(msg);               \
+      return -1;                         \
+    }                                    \
+  } while (0)
+#define MART_LAUNCH_CHECK()                               \
+  do {                                                    \
+    hipError_t e_ = hipGetLastError();                    \
+    if (e_ != hipSuccess) {                               \
+      mart_set_error(hipGetErrorString(e_));              \
+      return -2;                                          \
+    }                                                     \
+  } while (0)
+
+// ---- MFMA 32x32x16 bf16.  D[i][j] += sum_k A[i][k] B[k][j].
+// Operand layout (wave64): lane l holds A[i = l&31][k = 8*(l>>5) + 0..7] and B[k = 8*(l>>5)+0..7][j = l&31].
+// Result layout: lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// row index inside a 32x32 MFMA result tile held by (lane-half h, reg r)
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- LDS transpose read: within each 16-lane group, lane p supplies the address of 4 contiguous bf16
+// (row p>>2, 4-column chunk p&3 of a 4x16 block) and receives column p, rows 0..3 of that block.
+__device__ __forceinline__ s16x4 lds_tr_read(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_addr));
+}
+__device__ __forceinline__ bf16x8 join_tr(s16x4 lo, s16x4 hi) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// ---- async 16-byte global -> LDS copy.  LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc_lane), LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+// ---- bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
+__device__ __forceinline__ bf16x4 f4_to_bf4(f32x4 v) {
+  bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  return o;
+}
+__device__ __forceinline__ f32x4 bf4_to_f4(bf16x4 v) {
+  f32x4 o = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return o;
+}
+
+// ---- activations (reference: transformers ACT2FN 'gelu' = erf GELU, 'quick_gelu' = x*sigmoid(1.702x))
+#define ACT_NONE 0
+#define ACT_GELU 1
+#define ACT_QGELU 2
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == ACT_GELU) return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f));
+  if (act == ACT_QGELU) return z / (1.0f + __expf(-1.702f * z));
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == ACT_GELU) {
+    float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+    return cdf + z * pdf;
+  }
+  if (act == ACT_QGELU) {
+    float s = 1.0f / (1.0f + __expf(-1.702f * z));
+    return s * (1.0f + 1.702f * z * (1.0f - s));
+  }
+  return 1.0f;
+}
+
+// ---- wave / block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based RNG for dropout: one 32-bit hash per element index (stateless, so the backward
+// pass regenerates the forward mask from (seed, index)).  keep <=> u >= p.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
+  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t h = mix32(lo ^ (uint32_t)seed);
+  h = mix32(h + hi * 0x9e3779b9U + (uint32_t)(seed >> 32));
+  h = mix32(h ^ 0x85ebca6bU);
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
+  return rng_uniform(seed, idx) >= p;
+}
+
+// ---- XCD-aware, bijective remap of a linear workgroup id (8 XCDs; block b runs on XCD b%8):
+// consecutive logical ids land on the same XCD so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int NX = 8;
+  int xcd = bid % NX, idx = bid / NX;
+  int q = nwg / NX, r = nwg % NX;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

@@ -1,0 +1,262 @@
+// NT GEMM on gfx950 MFMA:  C[M,N] = epilogue( A[M,K] * B[N,K]^T (+ A2[M,K2] * B2[N,K2]^T) )
+//
+// Every dense contraction of the MKGformer step is an instance (SURVEY 2.2 K1,K3,K5-K7,K10-K12 and
+// their data-gradients, which use the transposed bf16 weight shadows so they are NT as well).
+//   * bf16 operands, fp32 accumulate, v_mfma_f32_32x32x16_bf16
+//   * tiles BMxBNx64, LDS double buffer filled by LDS-DMA (global_load_lds, 16 B/lane); the LDS image is
+//     lane-linear, the 16-byte-chunk XOR swizzle is applied on the per-lane SOURCE address and on the
+//     ds_read_b128 address (conflict-free for the 4x16-lane b128 service groups)
+//   * operands swapped into the MFMA so each lane owns one output row and 4 consecutive columns per
+//     register quad: bias / activation / residual / dual-dtype stores are 8-16 B vector accesses
+//   * optional row gathers on A and B (scoring head: mask rows x word_emb[entity ids]) folded into the
+//     per-lane source address -- the gather costs nothing extra
+//   * workgroup ids remapped so that neighbouring tiles (same A panel) share an XCD's L2
+#include "common.h"
+#include "mart_hip.h"
+
+namespace {
+
+struct Args {
+  const bf16* A; const bf16* B; const bf16* A2; const bf16* B2;
+  int lda, ldb;
+  int M, N, K, K2;
+  const int* a_rows; const int* b_rows;
+  long long sA, sB, sC, sAux;       // batch strides in elements (A/A2, B/B2, C/C2/preact, residual/mulz)
+  const float* bias; const float* bias2; int bias_by_brow;
+  int act;
+  bf16* preact;
+  const bf16* mulz; int mul_act;
+  const float* res_f32; const bf16* res_bf16; int ldres;
+  float alpha;
+  void* C; int ldc; int c_f32;
+  bf16* C2; int ldc2;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int BK = 64;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int RA = (BM * 8) / NT, RB = (BN * 8) / NT;   // 16-byte chunks per thread per stage
+  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/threads mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+  const long long bz = blockIdx.y;
+
+  const bf16* A = p.A + bz * p.sA;
+  const bf16* B = p.B + bz * p.sB;
+  const bf16* A2 = p.A2 ? p.A2 + bz * p.sA : nullptr;
+  const bf16* B2 = p.B2 ? p.B2 + bz * p.sB : nullptr;
+
+  // per-thread source offsets (elements) of the chunks this thread stages; constant over the K loop
+  unsigned offA[RA], offB[RB];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
+    int gm = min(m0 + row, p.M - 1);
+    if (p.a_rows) gm = p.a_rows[gm];
+    offA[r] = (unsigned)gm * (unsigned)p.lda + lc * 8;
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
+    int gn = min(n0 + row, p.N - 1);
+    if (p.b_rows) gn = p.b_rows[gn];
+    offB[r] = (unsigned)gn * (unsigned)p.ldb + lc * 8;
+  }
+
+  const int nk1 = p.K / BK, nk = nk1 + p.K2 / BK;
+
+  auto stage = [&](int t, int buf) {
+    const bf16* Ap = A; const bf16* Bp = B; int k0 = t * BK;
+    if (t >= nk1) { Ap = A2; Bp = B2; k0 = (t - nk1) * BK; }
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) glds16(Ap + offA[r] + k0, sA + (r * NT + wave * 64) * 16);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) glds16(Bp + offB[r] + k0, sB + (r * NT + wave * 64) * 16);
+  };
+
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // LDS read addressing: row -> byte base and swizzle key
+  int rowA[TM], rowB[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rowA[i] = wm0 + i * 32 + l31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) rowB[j] = wn0 + j * 32 + l31;
+
+  stage(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    __syncthreads();                    // tile t landed (vmcnt(0) per wave, then barrier); buffer (t+1)&1 is free
+    if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
+    const char* sA = smem + (t & 1) * STAGE;
+    const char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[TM], bfr[TN];
+      const int lc = ks * 2 + h;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *(const bf16x8*)(sA + rowA[i] * 128 + ((lc ^ ((rowA[i] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[j] = *(const bf16x8*)(sB + rowB[j] * 128 + ((lc ^ ((rowB[j] >> 1) & 7)) << 4));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[j], af[i], acc[i][j]);   // D[n][m]: lane = row m
+    }
+  }
+
+  // ---------------- epilogue: lane owns row m, 4 consecutive n per register quad
+  const bool vec = ((p.ldc & 3) == 0) && (!p.res_f32 && !p.res_bf16 && !p.mulz || (p.ldres & 3) == 0) &&
+                   (!p.C2 || (p.ldc2 & 3) == 0);
+  float* Cf = p.c_f32 ? (float*)p.C + bz * p.sC : nullptr;
+  bf16* Cb = p.c_f32 ? nullptr : (bf16*)p.C + bz * p.sC;
+  bf16* C2 = p.C2 ? p.C2 + bz * p.sC : nullptr;
+  bf16* PA = p.preact ? p.preact + bz * p.sC : nullptr;
+  const float* Rf = p.res_f32 ? p.res_f32 + bz * p.sAux : nullptr;
+  const bf16* Rb = p.res_bf16 ? p.res_bf16 + bz * p.sAux : nullptr;
+  const bf16* MZ = p.mulz ? p.mulz + bz * p.sAux : nullptr;
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm0 + i * 32 + l31;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn0 + j * 32 + 8 * q + 4 * h;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+        const int nv = min(4, p.N - n);
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nv) {
+              int bi = p.bias_by_brow ? p.b_rows[n + e] : n + e;
+              v[e] += p.bias[bi];
+              if (p.bias2) v[e] += p.bias2[bi];
+            }
+        }
+        const long long oc = (long long)m * p.ldc + n;
+        if (PA) {
+          if (vec && nv == 4) *(bf16x4*)(PA + oc) = f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
+          else for (int e = 0; e < nv; ++e) PA[oc + e] = f2bf(v[e]);
+        }
+        if (p.act != ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
+        }
+        const long long orr = (long long)m * p.ldres + n;
+        if (MZ) {
+          if (vec && nv == 4) {
+            f32x4 z = bf4_to_f4(*(const bf16x4*)(MZ + orr));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad(z[e], p.mul_act);
+          } else for (int e = 0; e < nv; ++e) v[e] *= act_grad(bf2f(MZ[orr + e]), p.mul_act);
+        }
+        if (Rf) {
+          if (vec && nv == 4) {
+            f32x4 r = *(const f32x4*)(Rf + orr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+          } else for (int e = 0; e < nv; ++e) v[e] += Rf[orr + e];
+        }
+        if (Rb) {
+          if (vec && nv == 4) {
+            f32x4 r = bf4_to_f4(*(const bf16x4*)(Rb + orr));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+          } else for (int e = 0; e < nv; ++e) v[e] += bf2f(Rb[orr + e]);
+        }
+        if (Cf) {
+          if (vec && nv == 4) *(f32x4*)(Cf + oc) = f32x4{v[0], v[1], v[2], v[3]};
+          else for (int e = 0; e < nv; ++e) Cf[oc + e] = v[e];
+        } else {
+          if (vec && nv == 4) *(bf16x4*)(Cb + oc) = f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
+          else for (int e = 0; e < nv; ++e) Cb[oc + e] = f2bf(v[e]);
+        }
+        if (C2) {
+          const long long o2 = (long long)m * p.ldc2 + n;
+          if (vec && nv == 4) *(bf16x4*)(C2 + o2) = f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
+          else for (int e = 0; e < nv; ++e) C2[o2 + e] = f2bf(v[e]);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(const Args& a, int batch, hipStream_t st) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int LDS = 2 * (BM + BN) * 64 * 2;
+  static bool attr_set = false;
+  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      mart_set_error("gemm_nt: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      return -2;
+    }
+    attr_set = true;
+  }
+  int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(NT), LDS, st, a);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
+  MART_CHECK(d != nullptr, "gemm_nt: null descriptor");
+  MART_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: M,N,K must be positive");
+  MART_CHECK(d->K % 64 == 0 && d->K2 % 64 == 0, "gemm_nt: K and K2 must be multiples of 64");
+  MART_CHECK(d->lda % 8 == 0 && d->ldb % 8 == 0, "gemm_nt: lda/ldb must be multiples of 8 (16-byte rows)");
+  MART_CHECK(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0, "gemm_nt: A/B must be 16-byte aligned");
+  MART_CHECK((d->K2 == 0) == (d->A2 == nullptr) && (d->K2 == 0) == (d->B2 == nullptr), "gemm_nt: A2/B2/K2 inconsistent");
+  MART_CHECK(d->C != nullptr && d->ldc >= d->N, "gemm_nt: bad C/ldc");
+  MART_CHECK(!d->bias_by_brow || d->b_rows, "gemm_nt: bias_by_brow needs b_rows");
+  MART_CHECK((long long)d->M * d->lda < (1LL << 32) && (long long)d->N * d->ldb < (1LL << 32) || d->a_rows || d->b_rows,
+             "gemm_nt: operand too large for 32-bit element offsets");
+  Args a;
+  a.A = (const bf16*)d->A; a.B = (const bf16*)d->B; a.A2 = (const bf16*)d->A2; a.B2 = (const bf16*)d->B2;
+  a.lda = d->lda; a.ldb = d->ldb; a.M = d->M; a.N = d->N; a.K = d->K; a.K2 = d->K2;
+  a.a_rows = d->a_rows; a.b_rows = d->b_rows;
+  a.sA = d->stride_a; a.sB = d->stride_b; a.sC = d->stride_c; a.sAux = d->stride_aux;
+  a.bias = d->bias; a.bias2 = d->bias2; a.bias_by_brow = d->bias_by_brow;
+  a.act = d->act; a.preact = (bf16*)d->preact; a.mulz = (const bf16*)d->mulz; a.mul_act = d->mul_act;
+  a.res_f32 = d->res_f32; a.res_bf16 = (const bf16*)d->res_bf16; a.ldres = d->ldres ? d->ldres : d->ldc;
+  a.alpha = d->alpha; a.C = d->C; a.ldc = d->ldc; a.c_f32 = d->c_f32; a.C2 = (bf16*)d->C2;
+  a.ldc2 = d->ldc2 ? d->ldc2 : d->ldc;
+  const int batch = d->batch > 0 ? d->batch : 1;
+  hipStream_t st = (hipStream_t)stream;
+  long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
+  int cfg = d->tile_cfg;
+  if (cfg == 0) cfg = (t256 >= 224) ? 256 : 128;
+  if (cfg == 256) return launch<256, 256, 2, 4>(a, batch, st);
+  return launch<128, 128, 2, 2>(a, batch, st);
+}

@@ -1,0 +1,207 @@
+// Scoring-head losses, ranking and the fused multi-tensor AdamW.
+#include "common.h"
+#include "mart_hip.h"
+
+namespace {
+constexpr int TPB = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float t = -3.0e38f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t = fmaxf(t, sh[i]);
+  return t;
+}
+
+// LabelSmoothSoftmaxCEV1 (lit_models/utils.py:49-62): target = eps/C everywhere, 1-eps at the label.
+// loss_row = -(sum_c t_c * logp_c) = lse*T - (eps/C)*sum_c x_c - (1-eps-eps/C)*x_label ,  T = 1-eps + eps*(C-1)/C
+__global__ void lsce_fwd_k(const float* __restrict__ lg, int ld, const int64_t* __restrict__ label, float eps, float* loss_rows,
+                           float* lse_out, int R, int C) {
+  __shared__ float sh[8];
+  const int r = blockIdx.x;
+  const float* x = lg + (long long)r * ld;
+  float mx = -3.0e38f;
+  for (int c = threadIdx.x; c < C; c += TPB) mx = fmaxf(mx, x[c]);
+  mx = block_max(mx, sh);
+  float se = 0.f, sx = 0.f;
+  for (int c = threadIdx.x; c < C; c += TPB) { se += __expf(x[c] - mx); sx += x[c]; }
+  se = block_sum(se, sh);
+  sx = block_sum(sx, sh);
+  if (threadIdx.x == 0) {
+    const float lse = mx + __logf(se);
+    const float neg = eps / (float)C, pos = 1.f - eps;
+    const float T = pos + neg * (float)(C - 1);
+    const float xl = x[label[r]];
+    loss_rows[r] = lse * T - neg * (sx - xl) - pos * xl;
+    lse_out[r] = lse;
+  }
+}
+__global__ void lsce_bwd_k(const float* __restrict__ lg, int ld, const int64_t* __restrict__ label, const float* __restrict__ lse, float eps,
+                           const float* __restrict__ gscale, float rowscale, bf16* ob, int ldo, float* of, int R, int C) {
+  const int r = blockIdx.x;
+  const float* x = lg + (long long)r * ld;
+  const float g = (gscale ? gscale[0] : 1.f) * rowscale;
+  const float neg = eps / (float)C, pos = 1.f - eps;
+  const float T = pos + neg * (float)(C - 1);
+  const float l = lse[r];
+  const int lab = (int)label[r];
+  for (int c = threadIdx.x; c < ldo; c += TPB) {
+    float v = 0.f;
+    if (c < C) v = g * (__expf(x[c] - l) * T - (c == lab ? pos : neg));
+    if (ob) ob[(long long)r * ldo + c] = f2bf(v);
+    if (of && c < C) of[(long long)r * C + c] = v;
+  }
+}
+__global__ void rank_k(const float* __restrict__ lg, int ld, const int64_t* __restrict__ label, int64_t* rank, int R, int C) {
+  __shared__ float sh[8];
+  const int r = blockIdx.x;
+  const float* x = lg + (long long)r * ld;
+  const float xl = x[label[r]];
+  float cnt = 0.f;
+  for (int c = threadIdx.x; c < C; c += TPB) cnt += (x[c] > xl) ? 1.f : 0.f;
+  cnt = block_sum(cnt, sh);
+  if (threadIdx.x == 0) rank[r] = (int64_t)(cnt + 0.5f) + 1;
+}
+
+// cosine similarity pieces (F.cosine_similarity eps = 1e-8 clamps each norm)
+struct Cos { float dot, na, nb; };
+__device__ __forceinline__ Cos cos_parts(const float* a, const float* b, int H, float* sh) {
+  float d = 0.f, x = 0.f, y = 0.f;
+  for (int c = threadIdx.x; c < H; c += TPB) { d += a[c] * b[c]; x += a[c] * a[c]; y += b[c] * b[c]; }
+  Cos o;
+  o.dot = block_sum(d, sh); o.na = sqrtf(block_sum(x, sh)); o.nb = sqrtf(block_sum(y, sh));
+  return o;
+}
+__global__ void simloss_fwd_k(const float* __restrict__ tr, const int64_t* rel, const int64_t* qh, const int64_t* ah, float* loss_rows,
+                              int B, int L, int H) {
+  __shared__ float sh[8];
+  const int b = blockIdx.x;
+  const float* base = tr + (long long)b * L * H;
+  Cos e = cos_parts(base + qh[b] * H, base + ah[b] * H, H, sh);
+  Cos r = cos_parts(base + rel[2 * b] * H, base + rel[2 * b + 1] * H, H, sh);
+  if (threadIdx.x == 0) {
+    const float ce = e.dot / (fmaxf(e.na, 1e-8f) * fmaxf(e.nb, 1e-8f));
+    const float cr = r.dot / (fmaxf(r.na, 1e-8f) * fmaxf(r.nb, 1e-8f));
+    loss_rows[b] = fmaxf(ce, 0.f) + 1.f - cr;
+  }
+}
+// d cos(a,b)/da = b/(|a||b|) - cos * a/|a|^2
+__global__ void simloss_bwd_k(const float* __restrict__ tr, const int64_t* rel, const int64_t* qh, const int64_t* ah,
+                              const float* __restrict__ gscale, float rowscale, float* dtr, int B, int L, int H) {
+  __shared__ float sh[8];
+  const int b = blockIdx.x;
+  const float g = (gscale ? gscale[0] : 1.f) * rowscale;
+  const float* base = tr + (long long)b * L * H;
+  float* dbase = dtr + (long long)b * L * H;
+  for (int pair = 0; pair < 2; ++pair) {
+    const long long ia = pair == 0 ? qh[b] : rel[2 * b], ib = pair == 0 ? ah[b] : rel[2 * b + 1];
+    const float* a = base + ia * H;
+    const float* bb = base + ib * H;
+    Cos c = cos_parts(a, bb, H, sh);
+    const float na = fmaxf(c.na, 1e-8f), nb = fmaxf(c.nb, 1e-8f);
+    const float cs = c.dot / (na * nb);
+    float coef = pair == 0 ? (cs > 0.f ? g : 0.f) : -g;          // relu(cos(q,a)) and -(cos(r0,r1))
+    if (coef == 0.f) continue;
+    for (int k = threadIdx.x; k < H; k += TPB) {
+      const float da = coef * (bb[k] / (na * nb) - cs * a[k] / (na * na));
+      const float db = coef * (a[k] / (na * nb) - cs * bb[k] / (nb * nb));
+      atomicAdd(dbase + ia * H + k, da);
+      atomicAdd(dbase + ib * H + k, db);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ fused AdamW (torch.optim.AdamW semantics)
+__global__ __launch_bounds__(TPB) void adamw_k(mart_adamw_desc p) {
+  for (int ci = blockIdx.x; ci < p.n_chunks; ci += gridDim.x) {
+    const int start = p.chunks[3 * ci], len = p.chunks[3 * ci + 1];
+    const float wd = p.chunks[3 * ci + 2] ? p.weight_decay : 0.f;
+    const float decay = 1.f - p.lr * wd;
+    const float step_size = p.lr / p.bc1;
+    const float inv_sqrt_bc2 = rsqrtf(p.bc2);
+    bf16* sh = (bf16*)p.shadow_bf16;
+    for (int i = threadIdx.x * 4; i < len; i += TPB * 4) {
+      const long long o = (long long)start + i;
+      if (i + 3 < len) {
+        f32x4 w = *(f32x4*)(p.master + o), g = *(const f32x4*)(p.grad + o), m = *(f32x4*)(p.m + o), v = *(f32x4*)(p.v + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ge = g[e] * p.grad_scale;
+          w[e] *= decay;
+          m[e] = p.beta1 * m[e] + (1.f - p.beta1) * ge;
+          v[e] = p.beta2 * v[e] + (1.f - p.beta2) * ge * ge;
+          w[e] -= step_size * m[e] / (sqrtf(v[e]) * inv_sqrt_bc2 + p.eps);
+        }
+        *(f32x4*)(p.master + o) = w; *(f32x4*)(p.m + o) = m; *(f32x4*)(p.v + o) = v;
+        if (sh) *(bf16x4*)(sh + o) = f4_to_bf4(w);
+      } else {
+        for (int e = 0; e < len - i; ++e) {
+          const float ge = p.grad[o + e] * p.grad_scale;
+          float w = p.master[o + e] * decay;
+          const float m = p.beta1 * p.m[o + e] + (1.f - p.beta1) * ge;
+          const float v = p.beta2 * p.v[o + e] + (1.f - p.beta2) * ge * ge;
+          w -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + p.eps);
+          p.master[o + e] = w; p.m[o + e] = m; p.v[o + e] = v;
+          if (sh) sh[o + e] = f2bf(w);
+        }
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int mart_lsce_fwd(const float* logits, int ld, const int64_t* label, float eps, float* loss_rows, float* lse, int R, int C, void* stream) {
+  MART_CHECK(logits && label && loss_rows && lse && R > 0 && C > 0 && ld >= C, "lsce_fwd: bad args");
+  hipLaunchKernelGGL(lsce_fwd_k, dim3(R), dim3(TPB), 0, (hipStream_t)stream, logits, ld, label, eps, loss_rows, lse, R, C);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_lsce_bwd(const float* logits, int ld, const int64_t* label, const float* lse, float eps, const float* gscale, float rowscale,
+                             void* dlogits_bf16, int ldo, float* dlogits_f32, int R, int C, void* stream) {
+  MART_CHECK(logits && label && lse && (dlogits_bf16 || dlogits_f32) && R > 0 && C > 0 && ld >= C && ldo >= C, "lsce_bwd: bad args");
+  hipLaunchKernelGGL(lsce_bwd_k, dim3(R), dim3(TPB), 0, (hipStream_t)stream, logits, ld, label, lse, eps, gscale, rowscale, (bf16*)dlogits_bf16, ldo,
+                     dlogits_f32, R, C);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_rank(const float* logits, int ld, const int64_t* label, int64_t* rank, int R, int C, void* stream) {
+  MART_CHECK(logits && label && rank && R > 0 && C > 0 && ld >= C, "rank: bad args");
+  hipLaunchKernelGGL(rank_k, dim3(R), dim3(TPB), 0, (hipStream_t)stream, logits, ld, label, rank, R, C);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_simloss_fwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, float* loss_rows, int B, int L,
+                                int H, void* stream) {
+  MART_CHECK(trans && rel_idx && q_idx && a_idx && loss_rows && B > 0 && L > 0 && H > 0, "simloss_fwd: bad args");
+  hipLaunchKernelGGL(simloss_fwd_k, dim3(B), dim3(TPB), 0, (hipStream_t)stream, trans, rel_idx, q_idx, a_idx, loss_rows, B, L, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, const float* gscale,
+                                float rowscale, float* dtrans, int B, int L, int H, void* stream) {
+  MART_CHECK(trans && rel_idx && q_idx && a_idx && dtrans && B > 0 && L > 0 && H > 0, "simloss_bwd: bad args");
+  hipLaunchKernelGGL(simloss_bwd_k, dim3(B), dim3(TPB), 0, (hipStream_t)stream, trans, rel_idx, q_idx, a_idx, gscale, rowscale, dtrans, B, L, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_adamw(const mart_adamw_desc* d, void* stream) {
+  MART_CHECK(d && d->master && d->grad && d->m && d->v && d->chunks && d->n_chunks > 0, "adamw: bad args");
+  MART_CHECK(d->bc1 > 0.f && d->bc2 > 0.f, "adamw: bias corrections must be positive");
+  int g = d->n_chunks < 4096 ? d->n_chunks : 4096;
+  hipLaunchKernelGGL(adamw_k, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
+  MART_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,414 @@
+// HBM-bound row kernels: LayerNorm family, embeddings, row softmax, transposes.
+// One wave64 per row, 16-byte vector accesses, fp32 statistics (two-pass in registers).
+#include "common.h"
+#include "mart_hip.h"
+
+namespace {
+constexpr int WPB = 4;            // waves (rows in flight) per workgroup
+constexpr int TPB = 64 * WPB;
+constexpr int VMAX = 4;           // float4 per lane cached in registers -> H <= 1024
+
+inline int row_grid(int M) {
+  int g = (M + WPB - 1) / WPB;
+  return g > 4096 ? 4096 : (g < 1 ? 1 : g);
+}
+
+// ------------------------------------------------------------------ LayerNorm forward
+__global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * WPB;
+  const int nv = p.H / 256;                       // float4 per lane (H multiple of 256)
+  const float inv_keep = 1.f / (1.f - p.p_drop);
+  const bf16* yb = (const bf16*)p.y_bf16;
+  for (int m = wave_g; m < p.M; m += nwaves) {
+    f32x4 x[VMAX];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) {
+      if (v < nv) {
+        const int c = (v * 64 + lane) * 4;
+        const long long o = (long long)m * p.H + c;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (p.x_f32) t = *(const f32x4*)(p.x_f32 + o);
+        if (yb) {
+          f32x4 y = bf4_to_f4(*(const bf16x4*)(yb + o));
+          if (p.p_drop > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? y[e] * inv_keep : 0.f;
+          }
+          t += y;
+        }
+        x[v] = t;
+        sum += t[0] + t[1] + t[2] + t[3];
+        if (p.s_out) *(f32x4*)(p.s_out + o) = t;
+      }
+    }
+    const float mean = wave_sum(sum) / (float)p.H;
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+      if (v < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float dlt = x[v][e] - mean; sq += dlt * dlt; }
+      }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.H + p.eps);
+    if (lane == 0) { p.mean[m] = mean; p.rstd[m] = rstd; }
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+      if (v < nv) {
+        const int c = (v * 64 + lane) * 4;
+        const long long o = (long long)m * p.H + c;
+        f32x4 g = *(const f32x4*)(p.gamma + c), b = *(const f32x4*)(p.beta + c), y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (x[v][e] - mean) * rstd * g[e] + b[e];
+        if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
+        if (p.out_bf16) *(bf16x4*)((bf16*)p.out_bf16 + o) = f4_to_bf4(y);
+      }
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+__global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
+  __shared__ float red[WPB][2][VMAX * 256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave_g = blockIdx.x * WPB + w;
+  const int nwaves = gridDim.x * WPB;
+  const int nv = p.H / 256;
+  const float inv_keep = 1.f / (1.f - p.p_drop);
+  const bf16* dyb = (const bf16*)p.dy_bf16;
+  f32x4 dg[VMAX], db[VMAX], gam[VMAX];
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) {
+    dg[v] = f32x4{0.f, 0.f, 0.f, 0.f}; db[v] = dg[v]; gam[v] = dg[v];
+    if (v < nv) gam[v] = *(const f32x4*)(p.gamma + (v * 64 + lane) * 4);
+  }
+  for (int m = wave_g; m < p.M; m += nwaves) {
+    const float mean = p.mean[m], rstd = p.rstd[m];
+    f32x4 dy[VMAX], xh[VMAX];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+      if (v < nv) {
+        const long long o = (long long)m * p.H + (v * 64 + lane) * 4;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (p.dy_f32) d = *(const f32x4*)(p.dy_f32 + o);
+        if (dyb) d += bf4_to_f4(*(const bf16x4*)(dyb + o));
+        f32x4 s = *(const f32x4*)(p.s + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float xhat = (s[e] - mean) * rstd;
+          xh[v][e] = xhat;
+          float g = d[e] * gam[v][e];
+          s1 += g; s2 += g * xhat;
+          dg[v][e] += d[e] * xhat; db[v][e] += d[e];
+        }
+        dy[v] = d;
+      }
+    const float c1 = wave_sum(s1) / (float)p.H, c2 = wave_sum(s2) / (float)p.H;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+      if (v < nv) {
+        const long long o = (long long)m * p.H + (v * 64 + lane) * 4;
+        f32x4 ds;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ds[e] = rstd * (dy[v][e] * gam[v][e] - c1 - xh[v][e] * c2);
+        if (p.ds_bf16) {
+          f32x4 dd = ds;
+          if (p.p_drop > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dd[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? dd[e] * inv_keep : 0.f;
+          }
+          *(bf16x4*)((bf16*)p.ds_bf16 + o) = f4_to_bf4(dd);
+        }
+        if (p.add_f32) ds += *(const f32x4*)(p.add_f32 + o);
+        if (p.ds_f32) *(f32x4*)(p.ds_f32 + o) = ds;
+      }
+  }
+  if (!p.dgamma && !p.dbeta) return;
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v)
+    if (v < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[w][0][(v * 64 + lane) * 4 + e] = dg[v][e];
+        red[w][1][(v * 64 + lane) * 4 + e] = db[v][e];
+      }
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.H; c += TPB) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < WPB; ++ww) { a += red[ww][0][c]; b += red[ww][1][c]; }
+    if (p.dgamma) atomicAdd(p.dgamma + c, a);
+    if (p.dbeta) atomicAdd(p.dbeta + c, b);
+  }
+}
+
+// ------------------------------------------------------------------ text embeddings (gather + LN + dropout)
+__global__ __launch_bounds__(TPB) void text_embed_k(mart_text_embed_desc p) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * WPB;
+  const int nv = p.H / 256, M = p.B * p.L;
+  const float inv_keep = 1.f / (1.f - p.p_drop);
+  for (int m = wave_g; m < M; m += nwaves) {
+    const long long id = p.ids[m], tt = p.tt[m];
+    const int pos = m % p.L;
+    f32x4 x[VMAX];
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+      if (v < nv) {
+        const int c = (v * 64 + lane) * 4;
+        f32x4 t = *(const f32x4*)(p.word + id * p.H + c);
+        t += *(const f32x4*)(p.type + tt * p.H + c);
+        t += *(const f32x4*)(p.pos + (long long)pos * p.H + c);
+        x[v] = t;
+        sum += t[0] + t[1] + t[2] + t[3];
+        if (p.s_out) *(f32x4*)(p.s_out + (long long)m * p.H + c) = t;
+      }
+    const float mean = wave_sum(sum) / (float)p.H;
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+      if (v < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { float dlt = x[v][e] - mean; sq += dlt * dlt; }
+      }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.H + p.eps);
+    if (lane == 0) { p.mean[m] = mean; p.rstd[m] = rstd; }
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+      if (v < nv) {
+        const int c = (v * 64 + lane) * 4;
+        const long long o = (long long)m * p.H + c;
+        f32x4 g = *(const f32x4*)(p.gamma + c), b = *(const f32x4*)(p.beta + c), y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          y[e] = (x[v][e] - mean) * rstd * g[e] + b[e];
+          if (p.p_drop > 0.f) y[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? y[e] * inv_keep : 0.f;
+        }
+        if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
+        if (p.out_bf16) *(bf16x4*)((bf16*)p.out_bf16 + o) = f4_to_bf4(y);
+      }
+  }
+}
+
+__global__ void text_embed_scatter_k(const float* __restrict__ ds, const int64_t* __restrict__ ids, const int64_t* __restrict__ tt,
+                                     float* dword, float* dpos, float* dtype, int B, int L, int H) {
+  const int m = blockIdx.x;
+  const long long id = ids[m], t = tt[m];
+  const int pos = m % L;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    const float g = ds[(long long)m * H + c];
+    atomicAdd(dword + id * H + c, g);
+    atomicAdd(dpos + (long long)pos * H + c, g);
+    atomicAdd(dtype + t * H + c, g);
+  }
+}
+
+// ------------------------------------------------------------------ vision embeddings
+// pixels [B,2,3,S,S] f32 -> patch matrix [(b,img,py,px), (c,ky,kx)] bf16
+__global__ void patchify_k(const float* __restrict__ pix, bf16* __restrict__ out, int B, int S, int p) {
+  const int g = S / p, P = g * g, K = 3 * p * p;
+  const long long row = blockIdx.x;                  // (b*2+img)*P + py*g + px
+  const int patch = (int)(row % P);
+  const long long bi = row / P;
+  const int py = patch / g, px = patch % g;
+  const float* src = pix + bi * 3LL * S * S;
+  for (int k4 = threadIdx.x * 4; k4 < K; k4 += blockDim.x * 4) {
+    const int c = k4 / (p * p), rem = k4 % (p * p), ky = rem / p, kx = rem % p;   // p multiple of 4 -> 4 kx contiguous
+    f32x4 v = *(const f32x4*)(src + ((long long)c * S + py * p + ky) * S + px * p + kx);
+    *(bf16x4*)(out + row * K + k4) = f4_to_bf4(v);
+  }
+}
+
+__global__ void vision_assemble_k(const bf16* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
+                                  float* __restrict__ s, int B, int P, int H) {
+  const int Nv = 1 + 2 * P;
+  const long long row = blockIdx.x;                  // b*Nv + t
+  const int t = (int)(row % Nv);
+  const long long b = row / Nv;
+  const int pidx = t == 0 ? 0 : (t <= P ? t : t - P);
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+    f32x4 v;
+    if (t == 0) v = *(const f32x4*)(cls + c);
+    else v = bf4_to_f4(*(const bf16x4*)(patch + ((b * 2 * P) + (t - 1)) * H + c));     // (b,0,t-1) or (b,1,t-1-P): contiguous
+    v += *(const f32x4*)(pos + (long long)pidx * H + c);
+    *(f32x4*)(s + row * H + c) = v;
+  }
+}
+
+// dpatch = bf16(ds rows 1..2P); dcls += sum_b ds[b,0]; dpos[t] += sum_b (ds[b,t] + ds[b,t+P])
+__global__ void vision_assemble_bwd_k(const float* __restrict__ ds, bf16* __restrict__ dpatch, float* dcls, float* dpos, int B, int P, int H) {
+  const int Nv = 1 + 2 * P;
+  const int t = blockIdx.x;                          // 0..P : position row
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float acc = 0.f, acc_cls = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float* base = ds + (long long)b * Nv * H;
+      if (t == 0) { float g = base[c]; acc += g; acc_cls += g; }
+      else {
+        float g0 = base[(long long)t * H + c], g1 = base[(long long)(t + P) * H + c];
+        acc += g0 + g1;
+        dpatch[((long long)b * 2 * P + (t - 1)) * H + c] = f2bf(g0);
+        dpatch[((long long)b * 2 * P + (t - 1 + P)) * H + c] = f2bf(g1);
+      }
+    }
+    atomicAdd(dpos + (long long)t * H + c, acc);
+    if (t == 0) atomicAdd(dcls + c, acc_cls);
+  }
+}
+
+// ------------------------------------------------------------------ row softmax (one wave per row)
+__global__ __launch_bounds__(TPB) void softmax_fwd_k(const float* __restrict__ sc, int ld, bf16* __restrict__ pr, int ldp, int R, int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* s = sc + (long long)r * ld;
+  float mx = -3.0e38f;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, s[c]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) sum += __expf(s[c] - mx);
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  bf16* o = pr + (long long)r * ldp;
+  for (int c = lane; c < ldp; c += 64) o[c] = c < C ? f2bf(__expf(s[c] - mx) * inv) : (bf16)0.f;
+}
+__global__ __launch_bounds__(TPB) void softmax_bwd_k(const bf16* __restrict__ pr, int ldp, const float* __restrict__ dp, int ldd,
+                                                     bf16* __restrict__ dsout, int ldo, int R, int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const bf16* p = pr + (long long)r * ldp;
+  const float* d = dp + (long long)r * ldd;
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot += bf2f(p[c]) * d[c];
+  dot = wave_sum(dot);
+  bf16* o = dsout + (long long)r * ldo;
+  for (int c = lane; c < ldo; c += 64) o[c] = c < C ? f2bf(bf2f(p[c]) * (d[c] - dot)) : (bf16)0.f;
+}
+
+// ------------------------------------------------------------------ tiled 2-D transposes (32x32 through LDS)
+__global__ void transpose_k(const bf16* __restrict__ in, int ldi, long long si, bf16* __restrict__ out, int Rp, long long so, int R, int C) {
+  __shared__ bf16 tile[32][33];
+  const bf16* src = in + (long long)blockIdx.z * si;
+  bf16* dst = out + (long long)blockIdx.z * so;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? src[(long long)r * ldi + c] : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < Rp) dst[(long long)c * Rp + r] = tile[tx][i];
+  }
+}
+__global__ void transpose_table_k(const bf16* __restrict__ src, bf16* __restrict__ dst, const int64_t* __restrict__ table, int n) {
+  __shared__ bf16 tile[32][33];
+  // blockIdx.y = matrix; blockIdx.x = linear tile id (grid-stride over that matrix's tiles)
+  const int64_t* e = table + 4LL * blockIdx.y;
+  const bf16* s = src + e[0];
+  bf16* d = dst + e[1];
+  const int R = (int)e[2], C = (int)e[3];
+  const int tr = (R + 31) / 32, tc = (C + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      tile[i][tx] = (r < R && c < C) ? s[(long long)r * C + c] : (bf16)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < C && r < R) d[(long long)c * R + r] = tile[tx][i];
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
+extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
+  MART_CHECK(d && (d->x_f32 || d->y_bf16), "ln_fwd: need x_f32 or y_bf16");
+  MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX, "ln_fwd: H must be a multiple of 256 and <= 1024");
+  MART_CHECK(d->gamma && d->beta && d->mean && d->rstd && (d->out_f32 || d->out_bf16), "ln_fwd: null pointer");
+  MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "ln_fwd: bad dropout p");
+  hipLaunchKernelGGL(ln_fwd_k, dim3(row_grid(d->M)), dim3(TPB), 0, (hipStream_t)stream, *d);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
+  MART_CHECK(d && (d->dy_f32 || d->dy_bf16), "ln_bwd: need dy_f32 or dy_bf16");
+  MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX, "ln_bwd: H must be a multiple of 256 and <= 1024");
+  MART_CHECK(d->s && d->mean && d->rstd && d->gamma && (d->ds_f32 || d->ds_bf16), "ln_bwd: null pointer");
+  int g = row_grid(d->M);
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(ln_bwd_k, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_text_embed_fwd(const mart_text_embed_desc* d, void* stream) {
+  MART_CHECK(d && d->ids && d->tt && d->word && d->pos && d->type && d->gamma && d->beta, "text_embed: null pointer");
+  MART_CHECK(d->B > 0 && d->L > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX, "text_embed: bad shape");
+  MART_CHECK(d->mean && d->rstd && (d->out_f32 || d->out_bf16), "text_embed: null output");
+  hipLaunchKernelGGL(text_embed_k, dim3(row_grid(d->B * d->L)), dim3(TPB), 0, (hipStream_t)stream, *d);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_text_embed_scatter(const float* ds, const int64_t* ids, const int64_t* tt, float* dword, float* dpos, float* dtype,
+                                       int B, int L, int H, void* stream) {
+  MART_CHECK(ds && ids && tt && dword && dpos && dtype && B > 0 && L > 0 && H > 0, "text_embed_scatter: bad args");
+  hipLaunchKernelGGL(text_embed_scatter_k, dim3(B * L), dim3(256), 0, (hipStream_t)stream, ds, ids, tt, dword, dpos, dtype, B, L, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_patchify(const float* pixels, void* out_bf16, int B, int S, int p, void* stream) {
+  MART_CHECK(pixels && out_bf16 && B > 0 && S > 0 && p > 0 && S % p == 0 && p % 4 == 0, "patchify: bad args");
+  const int g = S / p;
+  hipLaunchKernelGGL(patchify_k, dim3(B * 2 * g * g), dim3(192), 0, (hipStream_t)stream, pixels, (bf16*)out_bf16, B, S, p);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_vision_assemble(const void* patch_bf16, const float* cls, const float* pos, float* s, int B, int P, int H, void* stream) {
+  MART_CHECK(patch_bf16 && cls && pos && s && B > 0 && P > 0 && H % 4 == 0, "vision_assemble: bad args");
+  hipLaunchKernelGGL(vision_assemble_k, dim3(B * (1 + 2 * P)), dim3(192), 0, (hipStream_t)stream, (const bf16*)patch_bf16, cls, pos, s, B, P, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_vision_assemble_bwd(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, void* stream) {
+  MART_CHECK(ds && dpatch_bf16 && dcls && dpos && B > 0 && P > 0 && H > 0, "vision_assemble_bwd: bad args");
+  hipLaunchKernelGGL(vision_assemble_bwd_k, dim3(P + 1), dim3(256), 0, (hipStream_t)stream, ds, (bf16*)dpatch_bf16, dcls, dpos, B, P, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_softmax_fwd(const float* scores, int lds_, void* probs_bf16, int ldp, int R, int C, void* stream) {
+  MART_CHECK(scores && probs_bf16 && R > 0 && C > 0 && ldp >= C && lds_ >= C, "softmax_fwd: bad args");
+  hipLaunchKernelGGL(softmax_fwd_k, dim3((R + WPB - 1) / WPB), dim3(TPB), 0, (hipStream_t)stream, scores, lds_, (bf16*)probs_bf16, ldp, R, C);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_softmax_bwd(const void* probs_bf16, int ldp, const float* dprobs, int ldd, void* dscores_bf16, int ldo, int R, int C, void* stream) {
+  MART_CHECK(probs_bf16 && dprobs && dscores_bf16 && R > 0 && C > 0 && ldp >= C && ldd >= C && ldo >= C, "softmax_bwd: bad args");
+  hipLaunchKernelGGL(softmax_bwd_k, dim3((R + WPB - 1) / WPB), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)probs_bf16, ldp, dprobs, ldd,
+                     (bf16*)dscores_bf16, ldo, R, C);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_transpose_bf16(const void* in, int ldi, long long stride_i, void* out, int Rp, long long stride_o, int R, int C, int batch, void* stream) {
+  MART_CHECK(in && out && R > 0 && C > 0 && Rp >= R && ldi >= C && batch > 0, "transpose_bf16: bad args");
+  hipLaunchKernelGGL(transpose_k, dim3((C + 31) / 32, (Rp + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, ldi, stride_i,
+                     (bf16*)out, Rp, stride_o, R, C);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_transpose_table(const void* src_bf16, void* dst_bf16, const int64_t* table, int n, void* stream) {
+  MART_CHECK(src_bf16 && dst_bf16 && table && n > 0, "transpose_table: bad args");
+  hipLaunchKernelGGL(transpose_table_k, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_bf16, (bf16*)dst_bf16, table, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}

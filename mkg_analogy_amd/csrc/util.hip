@@ -1,0 +1,172 @@
+// Error plumbing, device check and small memory-bound utility kernels.
+#include "common.h"
+#include "mart_hip.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+extern "C" void mart_set_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+extern "C" const char* mart_last_error(void) { return g_err; }
+extern "C" int mart_abi_version(void) { return 1; }
+extern "C" int mart_check_device(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { mart_set_error("no HIP device"); return -2; }
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, dev) != hipSuccess) { mart_set_error("hipGetDeviceProperties failed"); return -2; }
+  if (strncmp(pr.gcnArchName, "gfx950", 6) != 0) {
+    mart_set_error("libmart_hip is built for gfx950 (MI355X) only");
+    return -1;
+  }
+  return 0;
+}
+
+namespace {
+constexpr int TPB = 256;
+inline int grid_for(long long n, int per_thread = 1) {
+  long long b = (n + (long long)TPB * per_thread - 1) / ((long long)TPB * per_thread);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__global__ void cast_f32_bf16_k(const float* __restrict__ s, bf16* __restrict__ d, long long n) {
+  long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4, stride = (long long)gridDim.x * TPB * 4;
+  for (; i + 3 < n; i += stride) *(bf16x4*)(d + i) = f4_to_bf4(*(const f32x4*)(s + i));
+  if (i < n && i + 3 >= n) for (long long j = i; j < n; ++j) d[j] = f2bf(s[j]);
+}
+__global__ void cast_bf16_f32_k(const bf16* __restrict__ s, float* __restrict__ d, long long n) {
+  long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4, stride = (long long)gridDim.x * TPB * 4;
+  for (; i + 3 < n; i += stride) *(f32x4*)(d + i) = bf4_to_f4(*(const bf16x4*)(s + i));
+  if (i < n && i + 3 >= n) for (long long j = i; j < n; ++j) d[j] = bf2f(s[j]);
+}
+__global__ void add_f32_bf16_k(const float* __restrict__ a, const bf16* __restrict__ b, float* __restrict__ of,
+                               bf16* __restrict__ ob, long long n) {
+  long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4, stride = (long long)gridDim.x * TPB * 4;
+  for (; i + 3 < n; i += stride) {
+    f32x4 v = *(const f32x4*)(a + i);
+    if (b) { f32x4 w = bf4_to_f4(*(const bf16x4*)(b + i)); v += w; }
+    if (of) *(f32x4*)(of + i) = v;
+    if (ob) *(bf16x4*)(ob + i) = f4_to_bf4(v);
+  }
+  if (i < n && i + 3 >= n) for (long long j = i; j < n; ++j) {
+    float v = a[j] + (b ? bf2f(b[j]) : 0.f);
+    if (of) of[j] = v;
+    if (ob) ob[j] = f2bf(v);
+  }
+}
+__global__ void dropout_mask_k(uint8_t* o, long long n, float p, uint64_t seed) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x, stride = (long long)gridDim.x * TPB;
+  for (; i < n; i += stride) o[i] = dropout_keep(seed, (uint64_t)i, p) ? 1 : 0;
+}
+__global__ void dropout_bwd_k(const float* __restrict__ a, const bf16* __restrict__ b, float* __restrict__ o, long long n, float p, uint64_t seed) {
+  long long i = (long long)blockIdx.x * TPB + threadIdx.x, stride = (long long)gridDim.x * TPB;
+  const float sc = 1.f / (1.f - p);
+  for (; i < n; i += stride) {
+    float v = (a ? a[i] : 0.f) + (b ? bf2f(b[i]) : 0.f);
+    o[i] = (p > 0.f) ? (dropout_keep(seed, (uint64_t)i, p) ? v * sc : 0.f) : v;
+  }
+}
+__global__ void find_token_k(const int64_t* ids, int B, int L, int64_t tok, int32_t* pos, int32_t* row) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int found = -1;
+  for (int j = 0; j < L; ++j) if (ids[(long long)b * L + j] == tok) { found = j; break; }
+  pos[b] = found;
+  if (row) row[b] = b * L + (found < 0 ? 0 : found);
+}
+__global__ void gather_rows_k(const float* __restrict__ src, int ld, const int32_t* __restrict__ rows, float* __restrict__ dst, int R, int H) {
+  int r = blockIdx.x;
+  const float* s = src + (long long)rows[r] * ld;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) dst[(long long)r * H + c] = s[c];
+}
+__global__ void gather_rows_bf16_k(const bf16* __restrict__ src, int ld, const int32_t* __restrict__ rows, bf16* __restrict__ dst, int R, int H) {
+  int r = blockIdx.x;
+  const bf16* s = src + (long long)rows[r] * ld;
+  for (int c = threadIdx.x * 8; c < H; c += blockDim.x * 8) *(bf16x8*)(dst + (long long)r * H + c) = *(const bf16x8*)(s + c);
+}
+__global__ void act_bwd_k(const bf16* __restrict__ dy, const bf16* __restrict__ z, int act, bf16* __restrict__ o, long long n) {
+  long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4, stride = (long long)gridDim.x * TPB * 4;
+  for (; i + 3 < n; i += stride) {
+    f32x4 g = bf4_to_f4(*(const bf16x4*)(dy + i)), zz = bf4_to_f4(*(const bf16x4*)(z + i));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] *= act_grad(zz[e], act);
+    *(bf16x4*)(o + i) = f4_to_bf4(g);
+  }
+  if (i < n && i + 3 >= n) for (long long j = i; j < n; ++j) o[j] = f2bf(bf2f(dy[j]) * act_grad(bf2f(z[j]), act));
+}
+__global__ void scatter_add_rows_k(const float* __restrict__ src, const int32_t* __restrict__ rows, float* __restrict__ dst, int ld, int R, int H) {
+  int r = blockIdx.x;
+  float* d = dst + (long long)rows[r] * ld;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) atomicAdd(d + c, src[(long long)r * H + c]);
+}
+}  // namespace
+
+extern "C" int mart_cast_f32_bf16(const float* src, void* dst, long long n, void* stream) {
+  MART_CHECK(src && dst && n >= 0, "cast_f32_bf16: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_f32_bf16_k, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, src, (bf16*)dst, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_cast_bf16_f32(const void* src, float* dst, long long n, void* stream) {
+  MART_CHECK(src && dst && n >= 0, "cast_bf16_f32: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_f32_k, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)src, dst, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_add_f32_bf16(const float* a, const void* b, float* of, void* ob, long long n, void* stream) {
+  MART_CHECK(a && (of || ob) && n >= 0, "add_f32_bf16: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_f32_bf16_k, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, a, (const bf16*)b, of, (bf16*)ob, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_dropout_mask(uint8_t* out, long long n, float p, uint64_t seed, void* stream) {
+  MART_CHECK(out && n >= 0, "dropout_mask: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_mask_k, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, out, n, p, seed);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_dropout_bwd_f32(const float* dy_f32, const void* dy_bf16, float* out, long long n, float p, uint64_t seed, void* stream) {
+  MART_CHECK((dy_f32 || dy_bf16) && out && n >= 0 && p >= 0.f && p < 1.f, "dropout_bwd_f32: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_bwd_k, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, dy_f32, (const bf16*)dy_bf16, out, n, p, seed);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_find_token(const int64_t* ids, int B, int L, int64_t token, int32_t* pos_out, int32_t* row_out, void* stream) {
+  MART_CHECK(ids && pos_out && B > 0 && L > 0, "find_token: bad args");
+  hipLaunchKernelGGL(find_token_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, ids, B, L, token, pos_out, row_out);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_gather_rows_f32(const float* src, int ld, const int32_t* rows, float* dst, int R, int H, void* stream) {
+  MART_CHECK(src && rows && dst && R > 0 && H > 0, "gather_rows_f32: bad args");
+  hipLaunchKernelGGL(gather_rows_k, dim3(R), dim3(256), 0, (hipStream_t)stream, src, ld, rows, dst, R, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_scatter_add_rows_f32(const float* src, const int32_t* rows, float* dst, int ld, int R, int H, void* stream) {
+  MART_CHECK(src && rows && dst && R > 0 && H > 0, "scatter_add_rows_f32: bad args");
+  hipLaunchKernelGGL(scatter_add_rows_k, dim3(R), dim3(256), 0, (hipStream_t)stream, src, rows, dst, ld, R, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mart_gather_rows_bf16(const void* src, int ld, const int32_t* rows, void* dst, int R, int H, void* stream) {
+  MART_CHECK(src && rows && dst && R > 0 && H > 0 && H % 8 == 0 && ld % 8 == 0, "gather_rows_bf16: bad args");
+  hipLaunchKernelGGL(gather_rows_bf16_k, dim3(R), dim3(128), 0, (hipStream_t)stream, (const bf16*)src, ld, rows, (bf16*)dst, R, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_act_bwd(const void* dy_bf16, const void* z_bf16, int act, void* out_bf16, long long n, void* stream) {
+  MART_CHECK(dy_bf16 && z_bf16 && out_bf16 && n >= 0, "act_bwd: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_bwd_k, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)dy_bf16, (const bf16*)z_bf16, act, (bf16*)out_bf16, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,250 @@
+"""Thin tensor-level wrappers over the C ABI (no autograd here; see engine.py / functional.py).
+
+Every function enqueues HIP kernels on torch's current stream and returns immediately.  PyTorch is used for
+device memory only.  bf16 tensors are torch.bfloat16; index tensors for gathers are int32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_GELU, ACT_QGELU = 0, 1, 2
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu() -> None:
+    """Fail loudly when the HIP path cannot run (no silent CPU/eager fallback anywhere in the product)."""
+    if not torch.cuda.is_available():
+        raise L.MartError("mkg_analogy_amd needs a HIP device (MI355X / gfx950); there is no CPU fallback")
+    L.check(L.lib().mart_check_device(), "mart_check_device")
+
+
+def _rows2d(t: torch.Tensor):
+    assert t.stride(-1) == 1, "innermost dimension must be contiguous"
+    return t.stride(-2)
+
+
+def gemm_nt(A, B, out, *, A2=None, B2=None, a_rows=None, b_rows=None, M=None, N=None, bias=None, bias2=None,
+            bias_by_brow=False, act=ACT_NONE, preact=None, mulz=None, mul_act=ACT_NONE, res_f32=None, res_bf16=None,
+            C2=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_aux=0, tile_cfg=0):
+    """out[M,N] = epi(A[M,K] @ B[N,K]^T (+ A2 @ B2^T)).  A/B are 2-D (row stride = ld) bf16; out bf16 or f32."""
+    d = L.GemmNT()
+    K = A.shape[-1]
+    d.A, d.B, d.A2, d.B2 = _p(A), _p(B), _p(A2), _p(B2)
+    d.lda, d.ldb = _rows2d(A), _rows2d(B)
+    d.M = M if M is not None else (a_rows.numel() if a_rows is not None else A.shape[-2])
+    d.N = N if N is not None else (b_rows.numel() if b_rows is not None else B.shape[-2])
+    d.K, d.K2 = K, (A2.shape[-1] if A2 is not None else 0)
+    if A2 is not None:
+        assert _rows2d(A2) == d.lda and _rows2d(B2) == d.ldb
+    d.a_rows, d.b_rows = _p(a_rows), _p(b_rows)
+    d.batch, d.stride_a, d.stride_b, d.stride_c, d.stride_aux = batch, stride_a, stride_b, stride_c, stride_aux
+    d.bias, d.bias2, d.bias_by_brow = _p(bias), _p(bias2), int(bias_by_brow)
+    d.act, d.preact, d.mulz, d.mul_act = act, _p(preact), _p(mulz), mul_act
+    d.res_f32, d.res_bf16 = _p(res_f32), _p(res_bf16)
+    res = res_f32 if res_f32 is not None else (res_bf16 if res_bf16 is not None else mulz)
+    d.ldres = _rows2d(res) if res is not None else 0
+    d.alpha = alpha
+    d.C, d.ldc, d.c_f32 = _p(out), _rows2d(out), int(out.dtype == F32)
+    d.C2, d.ldc2 = _p(C2), (_rows2d(C2) if C2 is not None else 0)
+    d.tile_cfg = tile_cfg
+    L.check(L.lib().mart_gemm_nt(C.byref(d), _stream()), "mart_gemm_nt")
+    return out
+
+
+def gemm_tn(X, Y, out, *, M=None, NX=None, NY=None, out_rows=None, colsum=None, colsum_by_row=False, batch=1,
+            stride_x=0, stride_y=0, stride_o=0, splits=0, alpha=1.0):
+    """out[NX,NY] (f32) += X[M,NX]^T @ Y[M,NY]; colsum[NX] += column sums of X."""
+    d = L.GemmTN()
+    d.X, d.Y, d.ldx, d.ldy = _p(X), _p(Y), _rows2d(X), _rows2d(Y)
+    d.M = M if M is not None else X.shape[-2]
+    d.NX = NX if NX is not None else X.shape[-1]
+    d.NY = NY if NY is not None else Y.shape[-1]
+    d.out, d.ldo, d.out_rows = _p(out), _rows2d(out), _p(out_rows)
+    d.colsum, d.colsum_by_row = _p(colsum), int(colsum_by_row)
+    d.batch, d.stride_x, d.stride_y, d.stride_o = batch, stride_x, stride_y, stride_o
+    d.splits, d.alpha = splits, alpha
+    L.check(L.lib().mart_gemm_tn(C.byref(d), _stream()), "mart_gemm_tn")
+    return out
+
+
+def ln_fwd(*, x_f32=None, y_bf16=None, gamma, beta, eps, M, H, mean, rstd, s_out=None, out_f32=None, out_bf16=None,
+           p_drop=0.0, seed=0):
+    d = L.LnFwd()
+    d.x_f32, d.y_bf16, d.p_drop, d.seed = _p(x_f32), _p(y_bf16), p_drop, seed
+    d.gamma, d.beta, d.eps, d.M, d.H = _p(gamma), _p(beta), eps, M, H
+    d.s_out, d.out_f32, d.out_bf16, d.mean, d.rstd = _p(s_out), _p(out_f32), _p(out_bf16), _p(mean), _p(rstd)
+    L.check(L.lib().mart_ln_fwd(C.byref(d), _stream()), "mart_ln_fwd")
+
+
+def ln_bwd(*, dy_f32=None, dy_bf16=None, s, mean, rstd, gamma, M, H, add_f32=None, ds_f32=None, ds_bf16=None,
+           p_drop=0.0, seed=0, dgamma=None, dbeta=None):
+    d = L.LnBwd()
+    d.dy_f32, d.dy_bf16, d.s, d.mean, d.rstd, d.gamma = _p(dy_f32), _p(dy_bf16), _p(s), _p(mean), _p(rstd), _p(gamma)
+    d.add_f32, d.M, d.H, d.ds_f32, d.ds_bf16 = _p(add_f32), M, H, _p(ds_f32), _p(ds_bf16)
+    d.p_drop, d.seed, d.dgamma, d.dbeta = p_drop, seed, _p(dgamma), _p(dbeta)
+    L.check(L.lib().mart_ln_bwd(C.byref(d), _stream()), "mart_ln_bwd")
+
+
+def patchify(pixels, out, B, S, p):
+    L.check(L.lib().mart_patchify(_p(pixels), _p(out), B, S, p, _stream()), "mart_patchify")
+
+
+def vision_assemble(patch, cls, pos, s, B, P, H):
+    L.check(L.lib().mart_vision_assemble(_p(patch), _p(cls), _p(pos), _p(s), B, P, H, _stream()), "mart_vision_assemble")
+
+
+def vision_assemble_bwd(ds, dpatch, dcls, dpos, B, P, H):
+    L.check(L.lib().mart_vision_assemble_bwd(_p(ds), _p(dpatch), _p(dcls), _p(dpos), B, P, H, _stream()), "mart_vision_assemble_bwd")
+
+
+def text_embed_fwd(*, ids, tt, word, pos, type_, gamma, beta, eps, p_drop, seed, B, Lq, H, s_out, mean, rstd, out_f32, out_bf16):
+    d = L.TextEmbed()
+    d.ids, d.tt, d.word, d.pos, d.type = _p(ids), _p(tt), _p(word), _p(pos), _p(type_)
+    d.gamma, d.beta, d.eps, d.p_drop, d.seed = _p(gamma), _p(beta), eps, p_drop, seed
+    d.B, d.L, d.H = B, Lq, H
+    d.s_out, d.mean, d.rstd, d.out_f32, d.out_bf16 = _p(s_out), _p(mean), _p(rstd), _p(out_f32), _p(out_bf16)
+    L.check(L.lib().mart_text_embed_fwd(C.byref(d), _stream()), "mart_text_embed_fwd")
+
+
+def dropout_bwd_f32(dy_f32, dy_bf16, out, n, p, seed):
+    L.check(L.lib().mart_dropout_bwd_f32(_p(dy_f32), _p(dy_bf16), _p(out), n, p, seed, _stream()), "mart_dropout_bwd_f32")
+
+
+def text_embed_scatter(ds, ids, tt, dword, dpos, dtype, B, Lq, H):
+    L.check(L.lib().mart_text_embed_scatter(_p(ds), _p(ids), _p(tt), _p(dword), _p(dpos), _p(dtype), B, Lq, H, _stream()),
+            "mart_text_embed_scatter")
+
+
+def _attn_desc(d, *, q, k, v, ctx, lse, B, nh, Sq, Sk, scale, pk=None, pv=None, Lp=0, attn_mask=None, sep=None,
+               sep_stride=0, w0=None, w1=None, p_drop=0.0, seed=0):
+    d.q, d.k, d.v = _p(q), _p(k), _p(v)
+    d.ldq, d.ldk, d.ldv = _rows2d(q), _rows2d(k), _rows2d(v)
+    d.pk, d.pv, d.ldp, d.Lp = _p(pk), _p(pv), (_rows2d(pk) if pk is not None else 0), Lp
+    d.B, d.nh, d.Sq, d.Sk, d.scale = B, nh, Sq, Sk, scale
+    d.attn_mask, d.sep, d.sep_stride, d.w0, d.w1 = _p(attn_mask), _p(sep), sep_stride, _p(w0), _p(w1)
+    d.p_drop, d.seed = p_drop, seed
+    d.ctx, d.ldctx, d.lse = _p(ctx), _rows2d(ctx), _p(lse)
+
+
+def attn_fwd(**kw):
+    d = L.AttnFwd()
+    _attn_desc(d, **kw)
+    L.check(L.lib().mart_attn_fwd(C.byref(d), _stream()), "mart_attn_fwd")
+
+
+def attn_bwd(*, dctx, delta, dq, dk, dv, dpk=None, dpv=None, accum_dkv=False, dw=None, **kw):
+    d = L.AttnBwd()
+    _attn_desc(d.f, **kw)
+    d.dctx, d.lddctx, d.delta = _p(dctx), _rows2d(dctx), _p(delta)
+    d.dq, d.dk, d.dv = _p(dq), _p(dk), _p(dv)
+    d.lddq, d.lddk, d.lddv = _rows2d(dq), _rows2d(dk), _rows2d(dv)
+    d.dpk, d.dpv, d.lddp = _p(dpk), _p(dpv), (_rows2d(dpk) if dpk is not None else 0)
+    d.accum_dkv, d.dw = int(accum_dkv), _p(dw)
+    L.check(L.lib().mart_attn_bwd(C.byref(d), _stream()), "mart_attn_bwd")
+
+
+def softmax_fwd(scores, probs, R, Cc):
+    L.check(L.lib().mart_softmax_fwd(_p(scores), _rows2d(scores), _p(probs), _rows2d(probs), R, Cc, _stream()), "mart_softmax_fwd")
+
+
+def softmax_bwd(probs, dprobs, dscores, R, Cc):
+    L.check(L.lib().mart_softmax_bwd(_p(probs), _rows2d(probs), _p(dprobs), _rows2d(dprobs), _p(dscores), _rows2d(dscores), R, Cc,
+                                     _stream()), "mart_softmax_bwd")
+
+
+def transpose_bf16(inp, out, R, Cc, Rp, batch=1, stride_i=0, stride_o=0):
+    L.check(L.lib().mart_transpose_bf16(_p(inp), _rows2d(inp), stride_i, _p(out), Rp, stride_o, R, Cc, batch, _stream()),
+            "mart_transpose_bf16")
+
+
+def lsce_fwd(logits, label, eps, loss_rows, lse):
+    R, Cc = logits.shape
+    L.check(L.lib().mart_lsce_fwd(_p(logits), _rows2d(logits), _p(label), eps, _p(loss_rows), _p(lse), R, Cc, _stream()), "mart_lsce_fwd")
+
+
+def lsce_bwd(logits, label, lse, eps, gscale, rowscale, dl_bf16=None, dl_f32=None):
+    R, Cc = logits.shape
+    ldo = _rows2d(dl_bf16) if dl_bf16 is not None else Cc
+    L.check(L.lib().mart_lsce_bwd(_p(logits), _rows2d(logits), _p(label), _p(lse), eps, _p(gscale), rowscale, _p(dl_bf16), ldo,
+                                  _p(dl_f32), R, Cc, _stream()), "mart_lsce_bwd")
+
+
+def rank(logits, label, out):
+    R, Cc = logits.shape
+    L.check(L.lib().mart_rank(_p(logits), _rows2d(logits), _p(label), _p(out), R, Cc, _stream()), "mart_rank")
+
+
+def simloss_fwd(trans, rel_idx, q_idx, a_idx, loss_rows):
+    B, Lq, H = trans.shape
+    L.check(L.lib().mart_simloss_fwd(_p(trans), _p(rel_idx), _p(q_idx), _p(a_idx), _p(loss_rows), B, Lq, H, _stream()), "mart_simloss_fwd")
+
+
+def simloss_bwd(trans, rel_idx, q_idx, a_idx, gscale, rowscale, dtrans):
+    B, Lq, H = trans.shape
+    L.check(L.lib().mart_simloss_bwd(_p(trans), _p(rel_idx), _p(q_idx), _p(a_idx), _p(gscale), rowscale, _p(dtrans), B, Lq, H, _stream()),
+            "mart_simloss_bwd")
+
+
+def find_token(ids, token, pos_out, row_out=None):
+    B, Lq = ids.shape
+    L.check(L.lib().mart_find_token(_p(ids), B, Lq, token, _p(pos_out), _p(row_out), _stream()), "mart_find_token")
+
+
+def cast_f32_bf16(src, dst):
+    L.check(L.lib().mart_cast_f32_bf16(_p(src), _p(dst), src.numel(), _stream()), "mart_cast_f32_bf16")
+
+
+def cast_bf16_f32(src, dst):
+    L.check(L.lib().mart_cast_bf16_f32(_p(src), _p(dst), src.numel(), _stream()), "mart_cast_bf16_f32")
+
+
+def gather_rows_bf16(src, rows, dst):
+    R, H = dst.shape
+    L.check(L.lib().mart_gather_rows_bf16(_p(src), _rows2d(src), _p(rows), _p(dst), R, H, _stream()), "mart_gather_rows_bf16")
+
+
+def act_bwd(dy, z, act, out):
+    L.check(L.lib().mart_act_bwd(_p(dy), _p(z), act, _p(out), dy.numel(), _stream()), "mart_act_bwd")
+
+
+def gather_rows_f32(src, rows, dst):
+    R, H = dst.shape
+    L.check(L.lib().mart_gather_rows_f32(_p(src), _rows2d(src), _p(rows), _p(dst), R, H, _stream()), "mart_gather_rows_f32")
+
+
+def scatter_add_rows_f32(src, rows, dst):
+    R, H = src.shape
+    L.check(L.lib().mart_scatter_add_rows_f32(_p(src), _p(rows), _p(dst), _rows2d(dst), R, H, _stream()), "mart_scatter_add_rows_f32")
+
+
+def add_f32_bf16(a, b_bf16=None, out_f32=None, out_bf16=None):
+    L.check(L.lib().mart_add_f32_bf16(_p(a), _p(b_bf16), _p(out_f32), _p(out_bf16), a.numel(), _stream()), "mart_add_f32_bf16")
+
+
+def dropout_mask(out_u8, p, seed):
+    L.check(L.lib().mart_dropout_mask(_p(out_u8), out_u8.numel(), p, seed, _stream()), "mart_dropout_mask")
+
+
+def adamw(*, master, grad, m, v, shadow, chunks, n_chunks, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale=1.0):
+    d = L.AdamW()
+    d.master, d.grad, d.m, d.v, d.shadow_bf16 = _p(master), _p(grad), _p(m), _p(v), _p(shadow)
+    d.chunks, d.n_chunks = _p(chunks), n_chunks
+    d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.bc1, d.bc2, d.grad_scale = lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale
+    L.check(L.lib().mart_adamw(C.byref(d), _stream()), "mart_adamw")
+
+
+def transpose_table(src, dst, table, n):
+    L.check(L.lib().mart_transpose_table(_p(src), _p(dst), _p(table), n, _stream()), "mart_transpose_table")

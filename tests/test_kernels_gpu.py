@@ -1,0 +1,457 @@
+"""Kernel-level parity: every C-ABI entry point against a plain PyTorch fp32 reference of the same op,
+on seeded inputs, called through ctypes (mkg_analogy_amd.ops).  GPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mkg_analogy_amd import ops as o
+    o.require_gpu()
+    return o
+
+
+DEV = "cuda"
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=BF):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+def close(got, ref, atol, rtol, what=""):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol)
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} bad, max err {float(err.max()):.4g}, ref max {float(ref.abs().max()):.4g}"
+
+
+# ----------------------------------------------------------------------------------------- NT GEMM
+@pytest.mark.parametrize("M,N,K,cfg", [(300, 200, 128, 128), (1000, 768, 768, 128), (1000, 768, 768, 256),
+                                       (3144, 2304, 768, 0), (64, 393, 768, 0), (257, 2063, 768, 0), (2048, 768, 3072, 256)])
+def test_gemm_nt_plain(ops, M, N, K, cfg):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    out = torch.empty(M, N, device=DEV, dtype=F32)
+    ops.gemm_nt(A, B, out, tile_cfg=cfg)
+    close(out, A.float() @ B.float().t(), 2e-3, 2e-3, "gemm_nt f32 out")
+    outb = torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, B, outb, tile_cfg=cfg)
+    close(outb, A.float() @ B.float().t(), 2e-2, 1e-2, "gemm_nt bf16 out")
+
+
+def test_gemm_nt_asymmetric_identity(ops):
+    """A = I against an asymmetric B catches a transposed / permuted C write."""
+    K = 128
+    A = torch.eye(K, device=DEV, dtype=BF)
+    B = (torch.arange(256 * K, device=DEV).reshape(256, K) % 97).float().to(BF)
+    out = torch.empty(K, 256, device=DEV, dtype=F32)
+    ops.gemm_nt(A, B, out)
+    assert torch.equal(out, B.float().t())
+
+
+@pytest.mark.parametrize("cfg", [128, 256])
+def test_gemm_nt_epilogues(ops, cfg):
+    M, N, K = 520, 768, 256
+    A, B = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.06)
+    bias, bias2 = rnd(N, seed=5, dtype=F32), rnd(N, seed=6, dtype=F32)
+    res = rnd(M, N, seed=7, dtype=F32)
+    resb = rnd(M, N, seed=8)
+    z = rnd(M, N, seed=9)
+    lin = A.float() @ B.float().t()
+    # bias + erf-gelu with pre-activation save
+    out, pre = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, B, out, bias=bias, act=ops.ACT_GELU, preact=pre, tile_cfg=cfg)
+    close(pre, lin + bias, 3e-2, 1e-2, "preact")
+    close(out, torch.nn.functional.gelu(lin + bias), 3e-2, 1e-2, "gelu")
+    # bias + bias2 + quick gelu
+    ops.gemm_nt(A, B, out, bias=bias, bias2=bias2, act=ops.ACT_QGELU, tile_cfg=cfg)
+    y = lin + bias + bias2
+    close(out, y * torch.sigmoid(1.702 * y), 3e-2, 1e-2, "quick_gelu")
+    # bias + f32 residual -> f32 out + bf16 copy
+    of, c2 = torch.empty(M, N, device=DEV, dtype=F32), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, B, of, bias=bias, res_f32=res, C2=c2, tile_cfg=cfg)
+    close(of, lin + bias + res, 2e-3, 2e-3, "res_f32")
+    close(c2, lin + bias + res, 3e-2, 1e-2, "C2")
+    # bf16 residual
+    ops.gemm_nt(A, B, out, res_bf16=resb, tile_cfg=cfg)
+    close(out, lin + resb.float(), 3e-2, 1e-2, "res_bf16")
+    # multiply by act'(z)
+    for act, fn in ((ops.ACT_GELU, torch.nn.functional.gelu), (ops.ACT_QGELU, lambda t: t * torch.sigmoid(1.702 * t))):
+        zz = z.float().clone().requires_grad_(True)
+        fn(zz).sum().backward()
+        ops.gemm_nt(A, B, out, mulz=z, mul_act=act, tile_cfg=cfg)
+        close(out, lin * zz.grad, 3e-2, 1e-2, f"mulz act {act}")
+
+
+def test_gemm_nt_dual_k_gather_batch(ops):
+    M, N, K = 300, 512, 128
+    A, B, A2, B2 = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=.1), rnd(M, K, seed=3), rnd(N, K, seed=4, scale=.1)
+    out = torch.empty(M, N, device=DEV, dtype=F32)
+    ops.gemm_nt(A, B, out, A2=A2, B2=B2)
+    close(out, A.float() @ B.float().t() + A2.float() @ B2.float().t(), 2e-3, 2e-3, "dual-K")
+    # gathers: rows of A and B picked by index, bias picked by the B row index
+    g = torch.Generator().manual_seed(0)
+    ar = torch.randint(0, M, (77,), generator=g).to(DEV).int()
+    br = torch.randperm(N, generator=g)[:203].to(DEV).int()
+    bias = rnd(N, seed=5, dtype=F32)
+    og = torch.empty(77, 203, device=DEV, dtype=F32)
+    ops.gemm_nt(A, B, og, a_rows=ar, b_rows=br, bias=bias, bias_by_brow=True)
+    close(og, A.float()[ar.long()] @ B.float()[br.long()].t() + bias[br.long()], 2e-3, 2e-3, "gather")
+    # batched with strides
+    Bz, m, n = 5, 64, 393
+    Ab, Bb = rnd(Bz, m, K, seed=6), rnd(Bz, n, K, seed=7, scale=.1)
+    ob = torch.empty(Bz, m, 400, device=DEV, dtype=F32)
+    ops.gemm_nt(Ab[0], Bb[0], ob[0], N=n, batch=Bz, stride_a=m * K, stride_b=n * K, stride_c=m * 400)
+    close(ob[:, :, :n], torch.einsum("bmk,bnk->bmn", Ab.float(), Bb.float()), 2e-3, 2e-3, "batched")
+
+
+# ----------------------------------------------------------------------------------------- TN GEMM
+@pytest.mark.parametrize("M,NX,NY", [(256, 256, 256), (1000, 768, 768), (3144, 2304, 768), (3144, 768, 3072), (77, 300, 768)])
+def test_gemm_tn(ops, M, NX, NY):
+    ldx = ((NX + 7) // 8) * 8
+    X = torch.zeros(M, ldx, device=DEV, dtype=BF)
+    X[:, :NX] = rnd(M, NX, seed=1, scale=0.1)
+    Y = rnd(M, NY, seed=2)
+    out = torch.zeros(NX, NY, device=DEV, dtype=F32)
+    cs = torch.zeros(NX, device=DEV, dtype=F32)
+    ops.gemm_tn(X, Y, out, NX=NX, colsum=cs)
+    ref = X[:, :NX].float().t() @ Y.float()
+    close(out, ref, 5e-3 * math.sqrt(M / 256), 2e-3, "gemm_tn")
+    close(cs, X[:, :NX].float().sum(0), 5e-3 * math.sqrt(M / 256), 2e-3, "colsum")
+    # accumulation semantic: second call doubles
+    ops.gemm_tn(X, Y, out, NX=NX)
+    close(out, 2 * ref, 1e-2 * math.sqrt(M / 256), 2e-3, "gemm_tn accumulate")
+
+
+def test_gemm_tn_scatter_and_batch(ops):
+    M, NX, NY, V = 200, 203, 768, 1000
+    X = torch.zeros(M, 208, device=DEV, dtype=BF)
+    X[:, :NX] = rnd(M, NX, seed=1, scale=.1)
+    Y = rnd(M, NY, seed=2)
+    rows = torch.randperm(V)[:NX].to(DEV).int()
+    out = torch.zeros(V, NY, device=DEV, dtype=F32)
+    cs = torch.zeros(V, device=DEV, dtype=F32)
+    ops.gemm_tn(X, Y, out, NX=NX, out_rows=rows, colsum=cs, colsum_by_row=True)
+    ref = torch.zeros_like(out)
+    ref[rows.long()] = X[:, :NX].float().t() @ Y.float()
+    close(out, ref, 5e-3, 2e-3, "tn scatter")
+    rc = torch.zeros_like(cs)
+    rc[rows.long()] = X[:, :NX].float().sum(0)
+    close(cs, rc, 5e-3, 2e-3, "tn scatter colsum")
+    Bz, m, nx = 4, 64, 393
+    Xb = torch.zeros(Bz, m, 448, device=DEV, dtype=BF)
+    Xb[:, :, :nx] = rnd(Bz, m, nx, seed=3, scale=.1)
+    Yb = rnd(Bz, m, 768, seed=4)
+    ob = torch.zeros(Bz, nx, 768, device=DEV, dtype=F32)
+    ops.gemm_tn(Xb[0], Yb[0], ob[0], NX=nx, batch=Bz, stride_x=m * 448, stride_y=m * 768, stride_o=nx * 768)
+    close(ob, torch.einsum("bmx,bmy->bxy", Xb[:, :, :nx].float(), Yb.float()), 5e-3, 2e-3, "tn batched")
+
+
+# ----------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("eps", [1e-5, 1e-12])
+def test_layernorm_fwd_bwd(ops, eps):
+    M, H = 1001, 768
+    x = rnd(M, H, seed=1, dtype=F32, scale=2.0) + 0.3
+    gamma, beta = 1 + 0.1 * rnd(H, seed=2, dtype=F32), 0.1 * rnd(H, seed=3, dtype=F32)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    of, ob = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV, dtype=BF)
+    ops.ln_fwd(x_f32=x, gamma=gamma, beta=beta, eps=eps, M=M, H=H, mean=mean, rstd=rstd, out_f32=of, out_bf16=ob)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (H,), gr, br, eps)
+    close(of, ref, 2e-5, 2e-5, "ln fwd f32")
+    close(ob, ref, 2e-2, 1e-2, "ln fwd bf16")
+    dy = rnd(M, H, seed=4, dtype=F32)
+    dyb = rnd(M, H, seed=5)
+    add = rnd(M, H, seed=6, dtype=F32)
+    ref.backward(dy + dyb.float())
+    ds, dsb = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV, dtype=BF)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ops.ln_bwd(dy_f32=dy, dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_f32=add, ds_f32=ds, ds_bf16=dsb,
+               dgamma=dg, dbeta=db)
+    close(ds, xr.grad + add, 1e-4, 1e-4, "ln bwd dx")
+    close(dsb, xr.grad, 2e-2, 1e-2, "ln bwd dx bf16 (no add)")
+    close(dg, gr.grad, 2e-3, 1e-4, "ln dgamma")
+    close(db, br.grad, 2e-3, 1e-4, "ln dbeta")
+
+
+def test_dropout_add_layernorm(ops):
+    M, H, p, seed = 300, 768, 0.1, 1234567
+    res = rnd(M, H, seed=1, dtype=F32)
+    y = rnd(M, H, seed=2)
+    gamma, beta = 1 + 0.1 * rnd(H, seed=3, dtype=F32), 0.1 * rnd(H, seed=4, dtype=F32)
+    keep = torch.empty(M * H, device=DEV, dtype=torch.uint8)
+    ops.dropout_mask(keep, p, seed)
+    keep = keep.view(M, H).float()
+    frac = float(keep.mean())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    s, of = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV)
+    ops.ln_fwd(x_f32=res, y_bf16=y, p_drop=p, seed=seed, gamma=gamma, beta=beta, eps=1e-12, M=M, H=H, mean=mean, rstd=rstd, s_out=s, out_f32=of)
+    sref = res + y.float() * keep / (1 - p)
+    close(s, sref, 1e-5, 1e-5, "dropout+res sum")
+    close(of, torch.nn.functional.layer_norm(sref, (H,), gamma, beta, 1e-12), 3e-5, 3e-5, "dropout+res LN")
+    # backward: masked bf16 branch gradient
+    dy = rnd(M, H, seed=5, dtype=F32)
+    sr = sref.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(sr, (H,), gamma, beta, 1e-12).backward(dy)
+    ds, dsb = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV, dtype=BF)
+    ops.ln_bwd(dy_f32=dy, s=s, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, ds_f32=ds, ds_bf16=dsb, p_drop=p, seed=seed)
+    close(ds, sr.grad, 1e-4, 1e-4, "ds")
+    close(dsb, sr.grad * keep / (1 - p), 2e-2, 1e-2, "masked branch grad")
+
+
+# ----------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, scale, factor=None, maskadd=None, keep=None, p=0.0):
+    s = torch.einsum("bhqd,bhkd->bhqk", q, k) * scale
+    if factor is not None:
+        s = s * factor
+    if maskadd is not None:
+        s = s + maskadd
+    a = torch.softmax(s, -1)
+    if keep is not None:
+        a = a * keep / (1 - p)
+    return torch.einsum("bhqk,bhkd->bhqd", a, v)
+
+
+def _heads(x, B, S, nh):          # [B*S, nh*64] -> [B,nh,S,64]
+    return x.view(B, S, nh, 64).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("B,nh,S,Lp", [(2, 12, 99, 0), (2, 12, 393, 64), (3, 4, 130, 24), (1, 2, 64, 0)])
+def test_attention_vision(ops, B, nh, S, Lp):
+    H = nh * 64
+    qkv = rnd(B * S, 3 * H, seed=1, scale=1.0)
+    tqkv = rnd(B * max(Lp, 1), 3 * H, seed=2, scale=1.0)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    pk, pv = (tqkv[:, H:2 * H], tqkv[:, 2 * H:]) if Lp else (None, None)
+    ctx = torch.zeros(B * S, H, device=DEV, dtype=BF)
+    lse = torch.empty(B, nh, S, device=DEV)
+    kw = dict(q=q, k=k, v=v, ctx=ctx, lse=lse, B=B, nh=nh, Sq=S, Sk=S, scale=0.125, pk=pk, pv=pv, Lp=Lp)
+    ops.attn_fwd(**kw)
+    qr, kr, vr = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    kk, vv = _heads(kr, B, S, nh), _heads(vr, B, S, nh)
+    if Lp:
+        pkr, pvr = [t.float().clone().requires_grad_(True) for t in (pk, pv)]
+        kk = torch.cat([_heads(pkr, B, Lp, nh), kk], 2)
+        vv = torch.cat([_heads(pvr, B, Lp, nh), vv], 2)
+    o = _attn_ref(_heads(qr, B, S, nh), kk, vv, 0.125)
+    oref = o.permute(0, 2, 1, 3).reshape(B * S, H)
+    close(ctx, oref, 2e-2, 2e-2, "attn fwd")
+    s = torch.einsum("bhqd,bhkd->bhqk", _heads(qr, B, S, nh), kk) * 0.125
+    close(lse, torch.logsumexp(s, -1), 2e-3, 1e-3, "lse")
+    # backward
+    dctx = rnd(B * S, H, seed=3)
+    oref.backward(dctx.float())
+    dqkv = torch.zeros(B * S, 3 * H, device=DEV, dtype=BF)
+    dt = torch.zeros(B * max(Lp, 1), 3 * H, device=DEV, dtype=BF)
+    delta = torch.empty(B, nh, S, device=DEV)
+    ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:],
+                 dpk=dt[:, H:2 * H] if Lp else None, dpv=dt[:, 2 * H:] if Lp else None, **kw)
+    gs = float(qr.grad.abs().max())
+    close(dqkv[:, :H], qr.grad, 2e-2 * max(gs, 1), 3e-2, "dq")
+    close(dqkv[:, H:2 * H], kr.grad, 2e-2 * max(float(kr.grad.abs().max()), 1), 3e-2, "dk")
+    close(dqkv[:, 2 * H:], vr.grad, 2e-2 * max(float(vr.grad.abs().max()), 1), 3e-2, "dv")
+    if Lp:
+        close(dt[:, H:2 * H], pkr.grad, 2e-2 * max(float(pkr.grad.abs().max()), 1), 3e-2, "dpk")
+        close(dt[:, 2 * H:], pvr.grad, 2e-2 * max(float(pvr.grad.abs().max()), 1), 3e-2, "dpv")
+
+
+@pytest.mark.parametrize("B,nh,L,p", [(3, 12, 64, 0.0), (2, 12, 64, 0.1), (2, 4, 24, 0.0), (2, 2, 96, 0.1)])
+def test_attention_text(ops, B, nh, L, p):
+    H = nh * 64
+    seed = 99
+    qkv = rnd(B * L, 3 * H, seed=1, scale=1.0)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    am = torch.ones(B, L, dtype=torch.long)
+    am[0, L - 7:] = 0
+    if B > 1:
+        am[1, L - 2:] = 0
+    am = am.to(DEV)
+    sep = torch.zeros(B, 6, dtype=torch.long)
+    sep[:, 2] = torch.tensor([L // 3 + i for i in range(B)])
+    sep = sep.to(DEV)
+    w0 = torch.tensor([0.25], device=DEV)
+    w1 = torch.tensor([0.5], device=DEV)          # exactly on the clamp bound: gradient must pass
+    ctx = torch.zeros(B * L, H, device=DEV, dtype=BF)
+    lse = torch.empty(B, nh, L, device=DEV)
+    kw = dict(q=q, k=k, v=v, ctx=ctx, lse=lse, B=B, nh=nh, Sq=L, Sk=L, scale=0.125, attn_mask=am, sep=sep[:, 2:], sep_stride=6,
+              w0=w0, w1=w1, p_drop=p, seed=seed)
+    ops.attn_fwd(**kw)
+    keep = None
+    if p > 0:
+        keep = torch.empty(B * nh * L * L, device=DEV, dtype=torch.uint8)
+        ops.dropout_mask(keep, p, seed)
+        keep = keep.view(B, nh, L, L).float()
+    qr, kr, vr = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    w0r, w1r = w0.clone().requires_grad_(True), w1.clone().requires_grad_(True)
+    ar = torch.arange(L, device=DEV)
+    s = sep[:, 2][:, None]
+    col_hi = (ar[None] >= s)[:, None, :]
+    row_lo = (ar[None] < s)[:, :, None]
+    fac = torch.where(col_hi, torch.where(row_lo, torch.clamp(w0r, 0, .5), torch.clamp(w1r, .5, 1)), torch.ones((), device=DEV))[:, None]
+    maskadd = ((1 - am) * -10000.0)[:, None, None, :].float()
+    o = _attn_ref(_heads(qr, B, L, nh), _heads(kr, B, L, nh), _heads(vr, B, L, nh), 0.125, fac, maskadd, keep, p)
+    oref = o.permute(0, 2, 1, 3).reshape(B * L, H)
+    close(ctx, oref, 2e-2, 2e-2, "text attn fwd")
+    dctx = rnd(B * L, H, seed=3)
+    oref.backward(dctx.float())
+    dqkv = torch.zeros(B * L, 3 * H, device=DEV, dtype=BF)
+    pre = rnd(B * L, 3 * H, seed=4)                # pre-existing prefix grads in the k/v blocks (accum_dkv)
+    dqkv[:, H:] = pre[:, H:]
+    delta = torch.empty(B, nh, L, device=DEV)
+    dw = torch.zeros(2, device=DEV)
+    ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:], accum_dkv=True, dw=dw, **kw)
+    close(dqkv[:, :H], qr.grad, 2e-2 * max(float(qr.grad.abs().max()), 1), 3e-2, "text dq")
+    close(dqkv[:, H:2 * H], kr.grad + pre[:, H:2 * H].float(), 3e-2 * max(float(kr.grad.abs().max()), 1), 3e-2, "text dk (+accum)")
+    close(dqkv[:, 2 * H:], vr.grad + pre[:, 2 * H:].float(), 3e-2 * max(float(vr.grad.abs().max()), 1), 3e-2, "text dv (+accum)")
+    gw = torch.stack([w0r.grad[0], w1r.grad[0]])
+    close(dw, gw, 2e-2 * max(float(gw.abs().max()), 1), 3e-2, "d adaptive_weight")
+
+
+# ----------------------------------------------------------------------------------------- small kernels
+def test_softmax_transpose(ops):
+    R, Cc, ldp = 130, 393, 448
+    sc = rnd(R, 400, seed=1, dtype=F32, scale=3.0)
+    pr = torch.full((R, ldp), 7.0, device=DEV, dtype=BF)
+    ops.softmax_fwd(sc[:, :Cc], pr, R, Cc)
+    ref = torch.softmax(sc[:, :Cc], -1)
+    close(pr[:, :Cc], ref, 4e-3, 1e-2, "softmax")
+    assert float(pr[:, Cc:].abs().max()) == 0
+    dp = rnd(R, 400, seed=2, dtype=F32)
+    dsb = torch.full((R, ldp), 7.0, device=DEV, dtype=BF)
+    ops.softmax_bwd(pr, dp[:, :Cc], dsb, R, Cc)
+    pf = pr[:, :Cc].float()
+    close(dsb[:, :Cc], pf * (dp[:, :Cc] - (pf * dp[:, :Cc]).sum(-1, keepdim=True)), 4e-3, 2e-2, "softmax bwd")
+    assert float(dsb[:, Cc:].abs().max()) == 0
+    x = rnd(3, 393, 768, seed=3)
+    xt = torch.full((3, 768, 448), 5.0, device=DEV, dtype=BF)
+    ops.transpose_bf16(x[0], xt[0], 393, 768, 448, batch=3, stride_i=393 * 768, stride_o=768 * 448)
+    assert torch.equal(xt[:, :, :393], x.transpose(1, 2)) and float(xt[:, :, 393:].abs().max()) == 0
+
+
+def test_embeddings(ops):
+    B, S, p, H = 3, 224, 16, 768
+    g = S // p
+    P = g * g
+    pix = rnd(B, 2, 3, S, S, seed=1, dtype=F32)
+    pm = torch.empty(B * 2 * P, 3 * p * p, device=DEV, dtype=BF)
+    ops.patchify(pix, pm, B, S, p)
+    ref = pix.view(B * 2, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B * 2 * P, 3 * p * p)
+    close(pm, ref, 1e-2, 1e-2, "patchify")
+    w = rnd(H, 3 * p * p, seed=2, scale=0.02)
+    pe = torch.empty(B * 2 * P, H, device=DEV, dtype=BF)
+    ops.gemm_nt(pm, w, pe)
+    conv = torch.nn.functional.conv2d(pix.view(B * 2, 3, S, S).to(BF).float(), w.float().view(H, 3, p, p), stride=p)
+    close(pe, conv.flatten(2).transpose(1, 2).reshape(B * 2 * P, H), 2e-2, 2e-2, "patch conv as GEMM")
+    cls, pos = rnd(H, seed=3, dtype=F32), rnd(P + 1, H, seed=4, dtype=F32)
+    s = torch.empty(B, 1 + 2 * P, H, device=DEV)
+    ops.vision_assemble(pe, cls, pos, s, B, P, H)
+    pev = pe.float().view(B, 2 * P, H)
+    sref = torch.cat([cls.expand(B, 1, H), pev], 1) + torch.cat([pos, pos[1:]], 0)[None]
+    close(s, sref, 1e-5, 1e-5, "assemble")
+    ds = rnd(B, 1 + 2 * P, H, seed=5, dtype=F32)
+    dpe = torch.empty(B * 2 * P, H, device=DEV, dtype=BF)
+    dcls, dpos = torch.zeros(H, device=DEV), torch.zeros(P + 1, H, device=DEV)
+    ops.vision_assemble_bwd(ds, dpe, dcls, dpos, B, P, H)
+    close(dpe, ds[:, 1:].reshape(B * 2 * P, H), 2e-2, 1e-2, "dpatch")
+    close(dcls, ds[:, 0].sum(0), 1e-4, 1e-5, "dcls")
+    rp = torch.zeros_like(dpos)
+    rp[0] = ds[:, 0].sum(0)
+    rp[1:] = ds[:, 1:P + 1].sum(0) + ds[:, P + 1:].sum(0)
+    close(dpos, rp, 1e-4, 1e-5, "dpos")
+    # text
+    V, L = 500, 64
+    ids = torch.randint(0, V, (B, L)).to(DEV)
+    tt = torch.randint(0, 2, (B, L)).to(DEV)
+    word, posw, typ = rnd(V, H, seed=6, dtype=F32), rnd(512, H, seed=7, dtype=F32), rnd(2, H, seed=8, dtype=F32)
+    gamma, beta = 1 + .1 * rnd(H, seed=9, dtype=F32), .1 * rnd(H, seed=10, dtype=F32)
+    so, mean, rstd = torch.empty(B * L, H, device=DEV), torch.empty(B * L, device=DEV), torch.empty(B * L, device=DEV)
+    of, ob = torch.empty(B * L, H, device=DEV), torch.empty(B * L, H, device=DEV, dtype=BF)
+    ops.text_embed_fwd(ids=ids, tt=tt, word=word, pos=posw, type_=typ, gamma=gamma, beta=beta, eps=1e-12, p_drop=0.0, seed=1, B=B, Lq=L, H=H,
+                       s_out=so, mean=mean, rstd=rstd, out_f32=of, out_bf16=ob)
+    sr = word[ids] + typ[tt] + posw[:L][None]
+    close(so, sr.view(B * L, H), 1e-5, 1e-5, "text embed sum")
+    close(of, torch.nn.functional.layer_norm(sr, (H,), gamma, beta, 1e-12).view(B * L, H), 3e-5, 3e-5, "text embed LN")
+    ds2 = rnd(B * L, H, seed=11, dtype=F32)
+    dw, dp, dty = torch.zeros_like(word), torch.zeros_like(posw), torch.zeros_like(typ)
+    ops.text_embed_scatter(ds2, ids, tt, dw, dp, dty, B, L, H)
+    rw = torch.zeros_like(word).index_add_(0, ids.view(-1), ds2)
+    close(dw, rw, 1e-4, 1e-5, "dword")
+    close(dp[:L], ds2.view(B, L, H).sum(0), 1e-4, 1e-5, "dpos")
+    close(dty, torch.zeros_like(typ).index_add_(0, tt.view(-1), ds2), 1e-3, 1e-5, "dtype")
+
+
+def test_loss_rank_kernels(ops, golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, "g3_loss_rank.npz"))
+    lg = torch.from_numpy(g["logits"]).to(DEV)
+    label = torch.from_numpy(g["label"]).to(DEV)
+    R, Cc = lg.shape
+    rows, lse = torch.empty(R, device=DEV), torch.empty(R, device=DEV)
+    ops.lsce_fwd(lg, label, 0.1, rows, lse)
+    assert abs(float(rows.mean()) - float(g["lsce"])) < 2e-5
+    dl = torch.empty(R, Cc, device=DEV)
+    dlb = torch.full((R, 64), 3.0, device=DEV, dtype=BF)
+    one = torch.ones(1, device=DEV)
+    ops.lsce_bwd(lg, label, lse, 0.1, one, 1.0 / R, dl_bf16=dlb, dl_f32=dl)
+    close(dl, torch.from_numpy(g["lsce_grad"]).to(DEV), 1e-6, 1e-4, "lsce grad (reference golden)")
+    assert float(dlb[:, Cc:].abs().max()) == 0
+    rk = torch.empty(R, device=DEV, dtype=torch.long)
+    ops.rank(lg, label, rk)
+    np.testing.assert_array_equal(rk.cpu().numpy(), g["ranks"])          # bit-exact ranks (reference golden)
+    h = torch.from_numpy(g["h"]).to(DEV)
+    rel, qh, ah = [torch.from_numpy(g[k]).to(DEV) for k in ("rel_idx", "q_head_idx", "a_head_idx")]
+    lr_ = torch.empty(h.shape[0], device=DEV)
+    ops.simloss_fwd(h, rel, qh, ah, lr_)
+    assert abs(float(lr_.mean()) - float(g["sim"])) < 1e-6
+    dh = torch.zeros_like(h)
+    ops.simloss_bwd(h, rel, qh, ah, one, 1.0 / h.shape[0], dh)
+    close(dh, torch.from_numpy(g["sim_grad"]).to(DEV), 1e-6, 1e-4, "sim grad (reference golden)")
+    # big random case: ranks vs double sort
+    big = rnd(64, 2063, seed=5, dtype=F32, scale=3)
+    lab = torch.randint(0, 2063, (64,)).to(DEV)
+    ops.rank(big, lab, rk2 := torch.empty(64, device=DEV, dtype=torch.long))
+    _, o1 = torch.sort(big, dim=1, descending=True)
+    _, o2 = torch.sort(o1, dim=1)
+    assert torch.equal(rk2, o2[torch.arange(64, device=DEV), lab] + 1)
+
+
+def test_adamw_and_misc(ops):
+    n = 5000
+    flat = 8192
+    p0 = rnd(flat, seed=1, dtype=F32)
+    g = rnd(flat, seed=2, dtype=F32) * 0.01
+    master, m, v = p0.clone(), torch.zeros(flat, device=DEV), torch.zeros(flat, device=DEV)
+    shadow = torch.zeros(flat, device=DEV, dtype=BF)
+    chunks = torch.tensor([[0, 4096, 1], [4096, n - 4096, 0]], dtype=torch.int32).to(DEV)
+    pr = [p0[:4096].clone().requires_grad_(True), p0[4096:n].clone().requires_grad_(True)]
+    opt = torch.optim.AdamW([{"params": [pr[0]], "weight_decay": 0.01}, {"params": [pr[1]], "weight_decay": 0.0}], lr=5e-5, eps=1e-8)
+    for step in range(1, 4):
+        pr[0].grad, pr[1].grad = g[:4096].clone(), g[4096:n].clone()
+        opt.step()
+        ops.adamw(master=master, grad=g, m=m, v=v, shadow=shadow, chunks=chunks, n_chunks=2, lr=5e-5, beta1=0.9, beta2=0.999, eps=1e-8,
+                  weight_decay=0.01, bc1=1 - 0.9 ** step, bc2=1 - 0.999 ** step)
+    close(master[:4096], pr[0].detach(), 1e-6, 1e-6, "adamw decay group")
+    close(master[4096:n], pr[1].detach(), 1e-6, 1e-6, "adamw no-decay group")
+    assert torch.equal(master[n:], p0[n:])
+    close(shadow[:n], master[:n], 1e-2, 1e-2, "bf16 shadow")
+    # transposes of packed weights
+    w = rnd(768 * 2304 + 3072 * 768, seed=3)
+    wt = torch.zeros_like(w)
+    table = torch.tensor([[0, 0, 2304, 768], [768 * 2304, 768 * 2304, 768, 3072]], dtype=torch.int64).to(DEV)
+    ops.transpose_table(w, wt, table, 2)
+    assert torch.equal(wt[:768 * 2304].view(768, 2304), w[:768 * 2304].view(2304, 768).t())
+    assert torch.equal(wt[768 * 2304:].view(3072, 768), w[768 * 2304:].view(768, 3072).t())
+    ids = torch.full((4, 16), 7, dtype=torch.long)
+    ids[0, 3] = 103; ids[1, 15] = 103; ids[2, 0] = 103; ids[3, 9] = 103
+    pos, row = torch.empty(4, dtype=torch.int32, device=DEV), torch.empty(4, dtype=torch.int32, device=DEV)
+    ops.find_token(ids.to(DEV), 103, pos, row)
+    assert pos.tolist() == [3, 15, 0, 9] and row.tolist() == [3, 31, 32, 57]
