@@ -1,0 +1,211 @@
+"""Flat parameter storage for the MKGformer path.
+
+All 451 trainable tensors live in ONE fp32 master buffer (the nn.Parameters are views into it), with
+  * one fp32 gradient buffer of the same layout (``p.grad`` are views; backward kernels accumulate in place,
+    RCCL all-reduces contiguous slices of it),
+  * a bf16 shadow of the same layout that the MFMA GEMMs read (refreshed by the fused AdamW kernel), and
+  * a bf16 buffer of transposed GEMM weights W^T (so data-gradient GEMMs are NT as well).
+Layout order = order in which backward finishes the gradients (head, layer 11 .. 0, embeddings, tied word
+embedding last) so that gradient buckets can be reduced while backward is still running.  Every tensor starts on
+a 256-element boundary; q/k/v projections of a layer are adjacent so the shadow holds a ready [3H,H] fused matrix.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+ALIGN = 256
+NO_DECAY = ("bias", "LayerNorm.weight")          # lit_models/transformer.py:225 (substring match, reproduced as is)
+
+
+@dataclass
+class Slot:
+    name: str
+    shape: Tuple[int, ...]
+    offset: int
+    numel: int
+
+
+def layout_order(n_layers: int) -> List[str]:
+    o: List[str] = []
+    h = "cls.predictions.transform."
+    o += [h + "dense.weight", h + "dense.bias", h + "LayerNorm.weight", h + "LayerNorm.bias"]
+    for l in reversed(range(n_layers)):
+        t = f"unimo.encoder.text_layer.{l}."
+        o += [t + f"attention.self.{n}.weight" for n in ("query", "key", "value")]
+        o += [t + f"attention.self.{n}.bias" for n in ("query", "key", "value")]
+        o += [t + "attention.self.adaptive_weight.0", t + "attention.self.adaptive_weight.1"]
+        o += [t + "attention.output.dense.weight", t + "attention.output.dense.bias",
+              t + "attention.output.LayerNorm.weight", t + "attention.output.LayerNorm.bias",
+              t + "intermediate.dense.weight", t + "intermediate.dense.bias",
+              t + "intermediate.fusion_dense.weight", t + "intermediate.fusion_dense.bias",
+              t + "output.dense.weight", t + "output.dense.bias", t + "output.LayerNorm.weight", t + "output.LayerNorm.bias"]
+        v = f"unimo.encoder.vision_layers.{l}."
+        o += [v + f"self_attn.{n}.weight" for n in ("q_proj", "k_proj", "v_proj")]
+        o += [v + f"self_attn.{n}.bias" for n in ("q_proj", "k_proj", "v_proj")]
+        o += [v + "self_attn.out_proj.weight", v + "self_attn.out_proj.bias", v + "layer_norm1.weight", v + "layer_norm1.bias",
+              v + "mlp.fc1.weight", v + "mlp.fc1.bias", v + "mlp.fc2.weight", v + "mlp.fc2.bias",
+              v + "layer_norm2.weight", v + "layer_norm2.bias"]
+    u = "unimo."
+    o += [u + "text_embeddings.LayerNorm.weight", u + "text_embeddings.LayerNorm.bias",
+          u + "text_embeddings.position_embeddings.weight", u + "text_embeddings.token_type_embeddings.weight",
+          u + "vision_pre_layrnorm.weight", u + "vision_pre_layrnorm.bias",
+          u + "vision_embeddings.class_embedding", u + "vision_embeddings.position_embedding.weight",
+          u + "vision_embeddings.patch_embedding.weight",
+          # never receive a gradient in the reference (dead pooler :748, unused post layernorm :683)
+          u + "vision_post_layernorm.weight", u + "vision_post_layernorm.bias",
+          u + "text_pooler.dense.weight", u + "text_pooler.dense.bias",
+          "cls.predictions.bias", u + "text_embeddings.word_embeddings.weight"]
+    return o
+
+
+DEAD = ("unimo.vision_post_layernorm.", "unimo.text_pooler.")
+PACK_WITH_PREV = ("adaptive_weight.1",)           # shares the 256-element slot of adaptive_weight.0 (contiguous [2])
+
+
+def gemm_weight_names(n_layers: int) -> List[Tuple[str, Tuple[str, ...]]]:
+    """(key, member weight names) of every matrix that needs a transposed shadow; members are adjacent in the flat
+    layout and are treated as one [sum(out), in] matrix."""
+    g: List[Tuple[str, Tuple[str, ...]]] = [("head", ("cls.predictions.transform.dense.weight",))]
+    for l in range(n_layers):
+        t = f"unimo.encoder.text_layer.{l}."
+        g += [(f"t{l}.qkv", tuple(t + f"attention.self.{n}.weight" for n in ("query", "key", "value"))),
+              (f"t{l}.ao", (t + "attention.output.dense.weight",)),
+              (f"t{l}.int", (t + "intermediate.dense.weight",)),
+              (f"t{l}.fus", (t + "intermediate.fusion_dense.weight",)),
+              (f"t{l}.out", (t + "output.dense.weight",))]
+        v = f"unimo.encoder.vision_layers.{l}."
+        g += [(f"v{l}.qkv", tuple(v + f"self_attn.{n}.weight" for n in ("q_proj", "k_proj", "v_proj"))),
+              (f"v{l}.o", (v + "self_attn.out_proj.weight",)),
+              (f"v{l}.fc1", (v + "mlp.fc1.weight",)),
+              (f"v{l}.fc2", (v + "mlp.fc2.weight",))]
+    return g
+
+
+class FlatStore:
+    def __init__(self, named_params: Dict[str, torch.nn.Parameter], n_layers: int, device: torch.device):
+        order = layout_order(n_layers)
+        missing = set(named_params) - set(order)
+        extra = set(order) - set(named_params)
+        assert not missing and not extra, f"parameter set mismatch: missing {sorted(missing)[:4]} extra {sorted(extra)[:4]}"
+        self.device = device
+        self.slots: Dict[str, Slot] = {}
+        off = 0
+        for name in order:
+            p = named_params[name]
+            n = p.numel()
+            if name.endswith(PACK_WITH_PREV):
+                prev = self.slots[name[:-1] + "0"]
+                self.slots[name] = Slot(name, tuple(p.shape), prev.offset + prev.numel, n)
+                continue
+            self.slots[name] = Slot(name, tuple(p.shape), off, n)
+            off += ((n + ALIGN - 1) // ALIGN) * ALIGN
+        self.total = off
+        self.master = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=device, dtype=torch.float32)
+        self.shadow = torch.zeros(off, device=device, dtype=torch.bfloat16)
+        with torch.no_grad():
+            for name, s in self.slots.items():
+                p = named_params[name]
+                view = self.master[s.offset:s.offset + s.numel].view(s.shape)
+                view.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = view
+                p.grad = self.grad[s.offset:s.offset + s.numel].view(s.shape)
+        # transposed GEMM weights
+        self.tslots: Dict[str, Tuple[int, int, int]] = {}        # key -> (offset, rows(out), cols(in))
+        toff = 0
+        table = []
+        for key, names in gemm_weight_names(n_layers):
+            first = self.slots[names[0]]
+            rows = sum(self.slots[n].shape[0] for n in names)
+            cols = first.shape[1]
+            exp = first.offset
+            for n in names:                                       # adjacency check
+                assert self.slots[n].offset == exp, f"{n} not adjacent"
+                exp += self.slots[n].numel
+                assert self.slots[n].numel % ALIGN == 0
+            self.tslots[key] = (toff, rows, cols)
+            table.append([first.offset, toff, rows, cols])
+            toff += rows * cols
+        self.shadow_t = torch.zeros(toff, device=device, dtype=torch.bfloat16)
+        self.ttable = torch.tensor(table, dtype=torch.int64, device=device)
+        # AdamW chunk table: (start, len, decay_flag); dead tensors are excluded (grad None in the reference => untouched)
+        chunks = []
+        CH = 1 << 16
+        for name in order:
+            if name.startswith(DEAD) or name.endswith(PACK_WITH_PREV):
+                continue
+            s = self.slots[name]
+            n = s.numel + (1 if name.endswith("adaptive_weight.0") else 0)
+            decay = 0 if any(nd in name for nd in NO_DECAY) else 1
+            for c0 in range(0, n, CH):
+                chunks.append([s.offset + c0, min(CH, n - c0), decay])
+        self.chunks = torch.tensor(chunks, dtype=torch.int32, device=device)
+        self.n_chunks = len(chunks)
+        self.live_end = self.slots["unimo.vision_post_layernorm.weight"].offset
+        self.tail_start = self.slots["cls.predictions.bias"].offset
+        self.refresh_shadows()
+
+    # ------------------------------------------------------------------ views
+    def m(self, name: str) -> torch.Tensor:
+        s = self.slots[name]
+        return self.master[s.offset:s.offset + s.numel].view(s.shape)
+
+    def g(self, name: str) -> torch.Tensor:
+        s = self.slots[name]
+        return self.grad[s.offset:s.offset + s.numel].view(s.shape)
+
+    def w(self, name: str) -> torch.Tensor:
+        """bf16 shadow of a (2-D) tensor."""
+        s = self.slots[name]
+        return self.shadow[s.offset:s.offset + s.numel].view(s.shape)
+
+    def fused(self, names: Sequence[str], buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Adjacent tensors as one [sum(rows), ...] view of ``buf`` (default: bf16 shadow)."""
+        buf = self.shadow if buf is None else buf
+        first = self.slots[names[0]]
+        rows = sum(self.slots[n].shape[0] for n in names)
+        tail = first.shape[1:]
+        n = rows
+        for t in tail:
+            n *= t
+        # members are 256-aligned multiples, so the concatenation is gap-free (checked for GEMM groups in __init__)
+        return buf[first.offset:first.offset + n].view((rows,) + tuple(tail))
+
+    def wt(self, key: str) -> torch.Tensor:
+        """bf16 transposed shadow [in, sum(out)] of a GEMM weight group."""
+        off, rows, cols = self.tslots[key]
+        return self.shadow_t[off:off + rows * cols].view(cols, rows)
+
+    def owns(self, named_params: Dict[str, torch.nn.Parameter]) -> bool:
+        base = self.master.data_ptr()
+        for name, p in named_params.items():
+            s = self.slots.get(name)
+            if s is None or tuple(p.shape) != s.shape or p.data_ptr() != base + 4 * s.offset:
+                return False
+        return len(named_params) == len(self.slots)
+
+    def refresh_shadows(self) -> None:
+        """master -> bf16 shadow and W^T shadow (after loading weights; AdamW keeps the first one fresh itself)."""
+        from . import ops
+        ops.cast_f32_bf16(self.master, self.shadow)
+        ops.transpose_table(self.shadow, self.shadow_t, self.ttable, self.ttable.shape[0])
+
+    def refresh_transposed(self) -> None:
+        from . import ops
+        ops.transpose_table(self.shadow, self.shadow_t, self.ttable, self.ttable.shape[0])
+
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+    def buckets(self, bucket_elems: int = 16 << 20) -> List[Tuple[int, int]]:
+        """Contiguous (start, end) slices of the gradient buffer in backward-completion order."""
+        out = []
+        s = 0
+        while s < self.total:
+            e = min(self.total, s + bucket_elems)
+            out.append((s, e))
+            s = e
+        return out
