@@ -139,72 +139,112 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   const bf16* Rb = p.res_bf16 ? p.res_bf16 + bz * p.sAux : nullptr;
   const bf16* MZ = p.mulz ? p.mulz + bz * p.sAux : nullptr;
 
+  // one register quad = 4 consecutive columns of one row; every loop below has a compile-time trip count so the
+  // accumulators stay in registers (a runtime-indexed accumulator array would be demoted to scratch)
+  auto emit = [&](int m, int n, float v0, float v1, float v2, float v3) {
+    float v[4] = {v0 * p.alpha, v1 * p.alpha, v2 * p.alpha, v3 * p.alpha};
+    const int nv = p.N - n;                                  // >= 1
+    const bool full = vec && nv >= 4;
+    if (p.bias && full && !p.bias_by_brow) {
+      const f32x4 b = *(const f32x4*)(p.bias + n);
+      v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+      if (p.bias2) { const f32x4 c = *(const f32x4*)(p.bias2 + n); v[0] += c[0]; v[1] += c[1]; v[2] += c[2]; v[3] += c[3]; }
+    } else if (p.bias) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm0 + i * 32 + l31;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn0 + j * 32 + 8 * q + 4 * h;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
-        const int nv = min(4, p.N - n);
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (e < nv) {
-              int bi = p.bias_by_brow ? p.b_rows[n + e] : n + e;
-              v[e] += p.bias[bi];
-              if (p.bias2) v[e] += p.bias2[bi];
-            }
+      for (int e = 0; e < 4; ++e)
+        if (e < nv) {
+          const int bi = p.bias_by_brow ? p.b_rows[n + e] : n + e;
+          v[e] += p.bias[bi];
+          if (p.bias2) v[e] += p.bias2[bi];
         }
-        const long long oc = (long long)m * p.ldc + n;
-        if (PA) {
-          if (vec && nv == 4) *(bf16x4*)(PA + oc) = f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
-          else for (int e = 0; e < nv; ++e) PA[oc + e] = f2bf(v[e]);
-        }
-        if (p.act != ACT_NONE) {
+    }
+    const long long oc = (long long)m * p.ldc + n;
+    if (PA) {
+      if (full) *(bf16x4*)(PA + oc) = f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
+      else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
-        }
-        const long long orr = (long long)m * p.ldres + n;
-        if (MZ) {
-          if (vec && nv == 4) {
-            f32x4 z = bf4_to_f4(*(const bf16x4*)(MZ + orr));
+        for (int e = 0; e < 4; ++e) if (e < nv) PA[oc + e] = f2bf(v[e]);
+      }
+    }
+    if (p.act != ACT_NONE) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= act_grad(z[e], p.mul_act);
-          } else for (int e = 0; e < nv; ++e) v[e] *= act_grad(bf2f(MZ[orr + e]), p.mul_act);
-        }
-        if (Rf) {
-          if (vec && nv == 4) {
-            f32x4 r = *(const f32x4*)(Rf + orr);
+      for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
+    }
+    const long long orr = (long long)m * p.ldres + n;
+    if (MZ) {
+      float z[4] = {0.f, 0.f, 0.f, 0.f};
+      if (full) { f32x4 t = bf4_to_f4(*(const bf16x4*)(MZ + orr)); z[0] = t[0]; z[1] = t[1]; z[2] = t[2]; z[3] = t[3]; }
+      else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r[e];
-          } else for (int e = 0; e < nv; ++e) v[e] += Rf[orr + e];
-        }
-        if (Rb) {
-          if (vec && nv == 4) {
-            f32x4 r = bf4_to_f4(*(const bf16x4*)(Rb + orr));
+        for (int e = 0; e < 4; ++e) if (e < nv) z[e] = bf2f(MZ[orr + e]);
+      }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += r[e];
-          } else for (int e = 0; e < nv; ++e) v[e] += bf2f(Rb[orr + e]);
-        }
-        if (Cf) {
-          if (vec && nv == 4) *(f32x4*)(Cf + oc) = f32x4{v[0], v[1], v[2], v[3]};
-          else for (int e = 0; e < nv; ++e) Cf[oc + e] = v[e];
-        } else {
-          if (vec && nv == 4) *(bf16x4*)(Cb + oc) = f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
-          else for (int e = 0; e < nv; ++e) Cb[oc + e] = f2bf(v[e]);
-        }
-        if (C2) {
-          const long long o2 = (long long)m * p.ldc2 + n;
-          if (vec && nv == 4) *(bf16x4*)(C2 + o2) = f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
-          else for (int e = 0; e < nv; ++e) C2[o2 + e] = f2bf(v[e]);
-        }
+      for (int e = 0; e < 4; ++e) v[e] *= act_grad(z[e], p.mul_act);
+    }
+    if (Rf) {
+      if (full) { f32x4 t = *(const f32x4*)(Rf + orr); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) v[e] += Rf[orr + e];
+      }
+    }
+    if (Rb) {
+      if (full) { f32x4 t = bf4_to_f4(*(const bf16x4*)(Rb + orr)); v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3]; }
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) v[e] += bf2f(Rb[orr + e]);
+      }
+    }
+    if (Cf) {
+      if (full) *(f32x4*)(Cf + oc) = f32x4{v[0], v[1], v[2], v[3]};
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) Cf[oc + e] = v[e];
+      }
+    } else {
+      if (full) *(bf16x4*)(Cb + oc) = f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) Cb[oc + e] = f2bf(v[e]);
+      }
+    }
+    if (C2) {
+      const long long o2 = (long long)m * p.ldc2 + n;
+      if (full) *(bf16x4*)(C2 + o2) = f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]});
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) C2[o2 + e] = f2bf(v[e]);
+      }
+    }
+  };
+  // Accumulators -> LDS (f32, one wave-row of the tile at a time, row stride BN+4 floats: conflict-free 16-byte
+  // writes) -> every thread picks 4 consecutive columns of a row so that ALL global epilogue traffic (bias,
+  // residual, pre-activation, output) is coalesced: 64 lanes cover 256 consecutive columns of one row.
+  constexpr int EP_LD = BN + 4;
+  float* ep = (float*)smem;
+  const int wave_m = wave / WAVES_N;
+#pragma unroll 1
+  for (int pass = 0; pass < WAVES_M; ++pass) {
+    __syncthreads();
+    if (wave_m == pass) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *(f32x4*)(ep + (i * 32 + l31) * EP_LD + wn0 + j * 32 + 8 * q + 4 * h) =
+                f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    }
+    __syncthreads();
+    constexpr int QUADS = WM * (BN / 4);
+#pragma unroll 4
+    for (int idx = tid; idx < QUADS; idx += NT) {
+      const int row = idx / (BN / 4), cg = idx % (BN / 4);
+      const int m = m0 + pass * WM + row, n = n0 + cg * 4;
+      if (m < p.M && n < p.N) {
+        const f32x4 a = *(const f32x4*)(ep + row * EP_LD + cg * 4);
+        emit(m, n, a[0], a[1], a[2], a[3]);
       }
     }
   }
@@ -213,7 +253,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch(const Args& a, int batch, hipStream_t st) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
-  constexpr int LDS = 2 * (BM + BN) * 64 * 2;
+  constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2, LDS_EPI = (BM / WAVES_M) * (BN + 4) * 4;
+  constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
   static bool attr_set = false;
   auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N>;
   if (!attr_set) {
