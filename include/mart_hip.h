@@ -180,6 +180,8 @@ int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, const int64_t* 
 int mart_find_token(const int64_t* ids, int B, int L, int64_t token, int32_t* pos_out, int32_t* row_out, void* stream);
 int mart_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
 int mart_cast_bf16_f32(const void* src, float* dst, long long n, void* stream);
+/* dst[r, 0:C] = bf16(src[r, 0:C]), dst[r, C:ldd] = 0 */
+int mart_cast_pad_f32_bf16(const float* src, int lds_, void* dst, int ldd, int R, int C, void* stream);
 /* dst[r,:] = src[rows[r],:] for 2-byte (bf16) elements; H multiple of 8 */
 int mart_gather_rows_bf16(const void* src, int ld, const int32_t* rows, void* dst, int R, int H, void* stream);
 /* out = dy * act'(z), all bf16 (backward of the head transform activation, modeling_unimo.py:974) */

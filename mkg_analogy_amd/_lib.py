@@ -97,6 +97,7 @@ _SIGS = {
     "mart_find_token": (i32, [vp, i32, i32, i64, vp, vp, vp]),
     "mart_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "mart_cast_bf16_f32": (i32, [vp, vp, i64, vp]),
+    "mart_cast_pad_f32_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "mart_gather_rows_bf16": (i32, [vp, i32, vp, vp, i32, i32, vp]),
     "mart_act_bwd": (i32, [vp, vp, i32, vp, i64, vp]),
     "mart_gather_rows_f32": (i32, [vp, i32, vp, vp, i32, i32, vp]),

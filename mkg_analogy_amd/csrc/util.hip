@@ -41,6 +41,10 @@ __global__ void cast_bf16_f32_k(const bf16* __restrict__ s, float* __restrict__ 
   for (; i + 3 < n; i += stride) *(f32x4*)(d + i) = bf4_to_f4(*(const bf16x4*)(s + i));
   if (i < n && i + 3 >= n) for (long long j = i; j < n; ++j) d[j] = bf2f(s[j]);
 }
+__global__ void cast_pad_k(const float* __restrict__ s, int lds_, bf16* __restrict__ d, int ldd, int R, int C) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < ldd; c += blockDim.x) d[(long long)r * ldd + c] = c < C ? f2bf(s[(long long)r * lds_ + c]) : (bf16)0.f;
+}
 __global__ void add_f32_bf16_k(const float* __restrict__ a, const bf16* __restrict__ b, float* __restrict__ of,
                                bf16* __restrict__ ob, long long n) {
   long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4, stride = (long long)gridDim.x * TPB * 4;
@@ -167,6 +171,13 @@ extern "C" int mart_act_bwd(const void* dy_bf16, const void* z_bf16, int act, vo
   MART_CHECK(dy_bf16 && z_bf16 && out_bf16 && n >= 0, "act_bwd: bad args");
   if (n == 0) return 0;
   hipLaunchKernelGGL(act_bwd_k, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)dy_bf16, (const bf16*)z_bf16, act, (bf16*)out_bf16, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mart_cast_pad_f32_bf16(const float* src, int lds_, void* dst, int ldd, int R, int C, void* stream) {
+  MART_CHECK(src && dst && R > 0 && C > 0 && ldd >= C && lds_ >= C, "cast_pad_f32_bf16: bad args");
+  hipLaunchKernelGGL(cast_pad_k, dim3(R), dim3(256), 0, (hipStream_t)stream, src, lds_, (bf16*)dst, ldd, R, C);
   MART_LAUNCH_CHECK();
   return 0;
 }

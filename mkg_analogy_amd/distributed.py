@@ -1,0 +1,98 @@
+"""Data-parallel gradient synchronisation: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+The reference has no collective code at all; under PL-DDP it would average gradients across ranks.
+Here the flat fp32 gradient buffer is all-reduced in a few large contiguous buckets.  Buckets are issued on a side
+stream as soon as the manual backward reports that every gradient below a flat offset is final (layout order ==
+backward completion order, params.layout_order), so the collectives overlap the remaining backward kernels.
+The 1/world_size factor is folded into the fused AdamW kernel (grad_scale), so no extra pass touches the buffer.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class BucketedAllReduce:
+    """All-reduce(sum) of ``flat[s:e]`` slices, launched in order as ``ready(upto)`` advances."""
+
+    def __init__(self, flat: torch.Tensor, buckets: List[Tuple[int, int]], group=None):
+        self.flat, self.buckets, self.group = flat, buckets, group
+        self.next = 0
+        self.handles = []
+        self.side: Optional[torch.cuda.Stream] = torch.cuda.Stream() if flat.is_cuda else None
+
+    def begin(self) -> None:
+        self.next = 0
+        self.handles = []
+
+    def ready(self, upto: int) -> None:
+        while self.next < len(self.buckets) and self.buckets[self.next][1] <= upto:
+            s, e = self.buckets[self.next]
+            self.next += 1
+            if self.side is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(ev)
+                    self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> None:
+        self.ready(self.flat.numel())
+        for h in self.handles:
+            h.wait()
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.handles = []
+
+
+class GradSync:
+    """Glue between a finalized model's engine and ``BucketedAllReduce``."""
+
+    def __init__(self, model, bucket_elems: int = 32 << 20, group=None):
+        self.model = model
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        st = model.store
+        self.reducer = BucketedAllReduce(st.grad, st.buckets(bucket_elems), group) if self.world > 1 else None
+        if self.reducer is not None:
+            model.engine.grad_ready = self.reducer.ready
+
+    def begin(self) -> None:
+        if self.reducer is not None:
+            self.reducer.begin()
+
+    def finish(self) -> None:
+        if self.reducer is not None:
+            self.reducer.finish()
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from torchrun's environment; initialises the default process group when world > 1."""
+    import os
+    rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, local, world
+
+
+def all_gather_ranks(ranks, group=None):
+    """Concatenate per-rank numpy rank arrays (eval: SURVEY 8(e))."""
+    import numpy as np
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ranks
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, ranks, group=group)
+    return np.concatenate(out)

@@ -1,0 +1,335 @@
+"""Hand-written forward/backward of the MKGformer ("Unimo") encoder + MLM head transform on the HIP kernels.
+
+This is the hot loop of the reference (MarT/models/modeling_unimo.py:589-658 UnimoEncoder.forward and everything
+it calls) re-scheduled for MI355X: bf16 MFMA contractions with fused epilogues, flash attention with the text K/V
+prefix read in place, fp32 residual streams / LayerNorm statistics / softmax, activations saved once for a manual
+backward that accumulates straight into the flat fp32 gradient buffer (params.FlatStore).  PyTorch supplies device
+memory and the outer autograd node (functional.py) only.
+
+Cross-wiring reproduced exactly (modeling_unimo.py:616,627-628): vision layer idx prepends the (K,V) of text layer
+idx-1 as key/value prefix iff idx>=8; text layer idx fuses with the output of vision layer idx iff idx>=8.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import ops
+from .params import FlatStore
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def _e(shape, dtype, dev):
+    return torch.empty(shape, device=dev, dtype=dtype)
+
+
+class UnimoEngine:
+    def __init__(self, store: FlatStore, vision_cfg, text_cfg):
+        self.st = store
+        self.vc, self.tc = vision_cfg, text_cfg
+        self.H = text_cfg.hidden_size
+        self.nh = text_cfg.num_attention_heads
+        self.I = text_cfg.intermediate_size
+        self.n_layers = text_cfg.num_hidden_layers
+        assert vision_cfg.hidden_size == self.H and vision_cfg.num_attention_heads == self.nh, \
+            "the HIP path is built for equal text/vision widths (BERT-base + CLIP ViT-B)"
+        assert self.H // self.nh == 64, "attention kernels are specialised for head_dim 64"
+        assert vision_cfg.num_hidden_layers == self.n_layers
+        self.eps_t = float(text_cfg.layer_norm_eps)
+        self.eps_v = 1e-5                      # nn.LayerNorm default: modeling_unimo.py:486-488,682 ignore the config eps
+        self.p_hidden = float(text_cfg.hidden_dropout_prob)
+        self.p_attn = float(text_cfg.attention_probs_dropout_prob)
+        self.fuse_from = 8                     # modeling_unimo.py:616,627
+        self.export_from = 7                   # modeling_unimo.py:628
+        self.grad_ready: Optional[Callable[[int], None]] = None      # DDP hook: gradients below this flat offset are final
+
+    # ------------------------------------------------------------------ helpers
+    def _lin(self, name):
+        st = self.st
+        return st.w(name + ".weight"), st.m(name + ".bias")
+
+    def _wgrad(self, X, Y, wname, bname=None, NX=None):
+        """dW[wname] += X^T Y ; db[bname] += colsum(X)."""
+        g = self.st.g(wname)
+        ops.gemm_tn(X, Y, g.view(g.shape[0], -1), NX=NX, colsum=self.st.g(bname) if bname else None)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train: bool, seed: int):
+        st, H, nh, I = self.st, self.H, self.nh, self.I
+        dev = input_ids.device
+        B, Lq = input_ids.shape
+        S, p = self.vc.image_size, self.vc.patch_size
+        P = (S // p) ** 2
+        Nv = 1 + 2 * P
+        Mv, Mt = B * Nv, B * Lq
+        Nvp = ((Nv + 63) // 64) * 64
+        sv: Dict[str, object] = dict(B=B, L=Lq, P=P, Nv=Nv, Nvp=Nvp, train=train, seed=seed,
+                                     ids=input_ids, tt=token_type_ids, am=attention_mask, sep=sep_idx)
+        p_h = self.p_hidden if train else 0.0
+        p_a = self.p_attn if train else 0.0
+
+        # ---- vision embeddings: patchify -> GEMM -> assemble(+cls,+pos) -> pre-LN    (modeling_unimo.py:119-132,711)
+        pix = pixel_values.contiguous()
+        assert pix.dtype == F32 and tuple(pix.shape) == (B, 2, 3, S, S), "pixel_values must be f32 [B,2,3,S,S]"
+        Kp = 3 * p * p
+        patches = _e((B * 2 * P, Kp), BF, dev)
+        ops.patchify(pix, patches, B, S, p)
+        pe = _e((B * 2 * P, H), BF, dev)
+        ops.gemm_nt(patches, st.w("unimo.vision_embeddings.patch_embedding.weight").view(H, Kp), pe)
+        s_v = _e((Mv, H), F32, dev)
+        ops.vision_assemble(pe, st.m("unimo.vision_embeddings.class_embedding"), st.m("unimo.vision_embeddings.position_embedding.weight"),
+                            s_v, B, P, H)
+        xv = _e((Mv, H), F32, dev)
+        mean, rstd = _e((Mv,), F32, dev), _e((Mv,), F32, dev)
+        ops.ln_fwd(x_f32=s_v, gamma=st.m("unimo.vision_pre_layrnorm.weight"), beta=st.m("unimo.vision_pre_layrnorm.bias"), eps=self.eps_v,
+                   M=Mv, H=H, mean=mean, rstd=rstd, out_f32=xv)
+        sv["vemb"] = (patches, s_v, mean, rstd)
+
+        # ---- text embeddings (modeling_unimo.py:152-186)
+        u = "unimo.text_embeddings."
+        s_t, tmean, trstd = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
+        xt, xtb = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+        ops.text_embed_fwd(ids=input_ids, tt=token_type_ids, word=st.m(u + "word_embeddings.weight"), pos=st.m(u + "position_embeddings.weight"),
+                           type_=st.m(u + "token_type_embeddings.weight"), gamma=st.m(u + "LayerNorm.weight"), beta=st.m(u + "LayerNorm.bias"),
+                           eps=self.eps_t, p_drop=p_h, seed=seed + 1, B=B, Lq=Lq, H=H, s_out=s_t, mean=tmean, rstd=trstd, out_f32=xt, out_bf16=xtb)
+        sv["temb"] = (s_t, tmean, trstd)
+
+        t_qkv_prev = None
+        for l in range(self.n_layers):
+            # ================= vision layer l (CLIPEncoderLayer.forward, modeling_unimo.py:490-527)
+            v = f"unimo.encoder.vision_layers.{l}."
+            h1, m1, r1 = _e((Mv, H), BF, dev), _e((Mv,), F32, dev), _e((Mv,), F32, dev)
+            ops.ln_fwd(x_f32=xv, gamma=st.m(v + "layer_norm1.weight"), beta=st.m(v + "layer_norm1.bias"), eps=self.eps_v, M=Mv, H=H,
+                       mean=m1, rstd=r1, out_bf16=h1)
+            qkv = _e((Mv, 3 * H), BF, dev)
+            names = [v + f"self_attn.{n}" for n in ("q_proj", "k_proj", "v_proj")]
+            ops.gemm_nt(h1, st.fused([n + ".weight" for n in names]), qkv, bias=st.fused([n + ".bias" for n in names], st.master))
+            ctx, lse = _e((Mv, H), BF, dev), _e((B, nh, Nv), F32, dev)
+            pre = t_qkv_prev if l >= self.fuse_from else None
+            akw = dict(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, lse=lse, B=B, nh=nh, Sq=Nv, Sk=Nv, scale=0.125,
+                       pk=pre[:, H:2 * H] if pre is not None else None, pv=pre[:, 2 * H:] if pre is not None else None,
+                       Lp=Lq if pre is not None else 0)
+            ops.attn_fwd(**akw)
+            x1 = _e((Mv, H), F32, dev)
+            w, b = self._lin(v + "self_attn.out_proj")
+            ops.gemm_nt(ctx, w, x1, bias=b, res_f32=xv)
+            h2, m2, r2 = _e((Mv, H), BF, dev), _e((Mv,), F32, dev), _e((Mv,), F32, dev)
+            ops.ln_fwd(x_f32=x1, gamma=st.m(v + "layer_norm2.weight"), beta=st.m(v + "layer_norm2.bias"), eps=self.eps_v, M=Mv, H=H,
+                       mean=m2, rstd=r2, out_bf16=h2)
+            z, f = _e((Mv, I), BF, dev), _e((Mv, I), BF, dev)
+            w, b = self._lin(v + "mlp.fc1")
+            ops.gemm_nt(h2, w, f, bias=b, act=ops.ACT_QGELU, preact=z)
+            x2 = _e((Mv, H), F32, dev)
+            x2b = _e((Mv, H), BF, dev) if l >= self.fuse_from else None
+            w, b = self._lin(v + "mlp.fc2")
+            ops.gemm_nt(f, w, x2, bias=b, res_f32=x1, C2=x2b)
+            sv[f"v{l}"] = dict(x=xv, m1=m1, r1=r1, h1=h1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, m2=m2, r2=r2, h2=h2, z=z, f=f, pre=pre)
+            xv = x2
+
+            # ================= text layer l (BertLayer.forward, modeling_unimo.py:540-577)
+            t = f"unimo.encoder.text_layer.{l}."
+            tqkv = _e((Mt, 3 * H), BF, dev)
+            names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
+            ops.gemm_nt(xtb, st.fused([n + ".weight" for n in names]), tqkv, bias=st.fused([n + ".bias" for n in names], st.master))
+            tctx, tlse = _e((Mt, H), BF, dev), _e((B, nh, Lq), F32, dev)
+            w0 = st.m(t + "attention.self.adaptive_weight.0")
+            w1 = st.m(t + "attention.self.adaptive_weight.1")
+            tkw = dict(q=tqkv[:, :H], k=tqkv[:, H:2 * H], v=tqkv[:, 2 * H:], ctx=tctx, lse=tlse, B=B, nh=nh, Sq=Lq, Sk=Lq, scale=0.125,
+                       attn_mask=attention_mask, sep=sep_idx[:, 2:] if sep_idx is not None else None,
+                       sep_stride=sep_idx.shape[1] if sep_idx is not None else 0,
+                       w0=w0 if sep_idx is not None else None, w1=w1 if sep_idx is not None else None,
+                       p_drop=p_a, seed=seed + 10 + 4 * l)
+            ops.attn_fwd(**tkw)
+            fus = probs = visT = None
+            if l >= self.fuse_from:                                   # BertFusion.forward, modeling_unimo.py:400-414
+                scores = _e((Mt, Nvp), F32, dev)
+                ops.gemm_nt(tctx, x2b, scores, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
+                probs = _e((Mt, Nvp), BF, dev)
+                ops.softmax_fwd(scores, probs, Mt, Nv)
+                visT = _e((B * H, Nvp), BF, dev)
+                ops.transpose_bf16(x2b, visT, Nv, H, Nvp, batch=B, stride_i=Nv * H, stride_o=H * Nvp)
+                fus = _e((Mt, H), BF, dev)
+                ops.gemm_nt(probs, visT, fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
+            so = _e((Mt, H), BF, dev)
+            w, b = self._lin(t + "attention.output.dense")
+            ops.gemm_nt(tctx, w, so, bias=b)
+            s1, am1, ar1 = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
+            a, ab = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+            ops.ln_fwd(x_f32=xt, y_bf16=so, p_drop=p_h, seed=seed + 11 + 4 * l, gamma=st.m(t + "attention.output.LayerNorm.weight"),
+                       beta=st.m(t + "attention.output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=am1, rstd=ar1, s_out=s1, out_f32=a, out_bf16=ab)
+            zt, ht = _e((Mt, I), BF, dev), _e((Mt, I), BF, dev)
+            w, b = self._lin(t + "intermediate.dense")
+            if fus is not None:
+                wf, bf_ = self._lin(t + "intermediate.fusion_dense")
+                ops.gemm_nt(ab, w, ht, A2=fus, B2=wf, bias=b, bias2=bf_, act=ops.ACT_GELU, preact=zt)
+            else:
+                ops.gemm_nt(ab, w, ht, bias=b, act=ops.ACT_GELU, preact=zt)
+            oo = _e((Mt, H), BF, dev)
+            w, b = self._lin(t + "output.dense")
+            ops.gemm_nt(ht, w, oo, bias=b)
+            s2, om, orr = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
+            xo, xob = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+            ops.ln_fwd(x_f32=a, y_bf16=oo, p_drop=p_h, seed=seed + 12 + 4 * l, gamma=st.m(t + "output.LayerNorm.weight"),
+                       beta=st.m(t + "output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=om, rstd=orr, s_out=s2, out_f32=xo, out_bf16=xob)
+            sv[f"t{l}"] = dict(xb=xtb, qkv=tqkv, ctx=tctx, lse=tlse, tkw=tkw, fus=fus, probs=probs, visT=visT, visb=x2b,
+                               s1=s1, m1=am1, r1=ar1, ab=ab, zt=zt, ht=ht, s2=s2, m2=om, r2=orr)
+            xt, xtb = xo, xob
+            t_qkv_prev = tqkv if l >= self.export_from else None
+
+        # ---- MLM head transform (BertPredictionHeadTransform.forward, modeling_unimo.py:972-975)
+        hp = "cls.predictions.transform."
+        y, zh = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+        w, b = self._lin(hp + "dense")
+        ops.gemm_nt(xtb, w, y, bias=b, act=ops.ACT_GELU, preact=zh)
+        trans, transb = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+        hm, hr = _e((Mt,), F32, dev), _e((Mt,), F32, dev)
+        ops.ln_fwd(x_f32=y, gamma=st.m(hp + "LayerNorm.weight"), beta=st.m(hp + "LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=hm, rstd=hr,
+                   out_f32=trans, out_bf16=transb)
+        sv["head"] = (xtb, y, zh, hm, hr)
+        return trans.view(B, Lq, H), transb, sv
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, sv, dtrans: torch.Tensor) -> None:
+        """Accumulates d(loss)/d(param) into FlatStore.grad given d(loss)/d(trans_hidden_states) (f32 [B,L,H])."""
+        st, H, nh, I = self.st, self.H, self.nh, self.I
+        dev = dtrans.device
+        B, Lq, P, Nv, Nvp = sv["B"], sv["L"], sv["P"], sv["Nv"], sv["Nvp"]
+        train, seed = sv["train"], sv["seed"]
+        Mv, Mt = B * Nv, B * Lq
+        p_h = self.p_hidden if train else 0.0
+        notify = self.grad_ready or (lambda off: None)
+
+        # ---- head transform
+        xtb, y, zh, hm, hr = sv["head"]
+        hp = "cls.predictions.transform."
+        dyb = _e((Mt, H), BF, dev)
+        ops.ln_bwd(dy_f32=dtrans.contiguous().view(Mt, H), s=y, mean=hm, rstd=hr, gamma=st.m(hp + "LayerNorm.weight"), M=Mt, H=H, ds_bf16=dyb,
+                   dgamma=st.g(hp + "LayerNorm.weight"), dbeta=st.g(hp + "LayerNorm.bias"))
+        dzh = _e((Mt, H), BF, dev)
+        ops.act_bwd(dyb, zh, ops.ACT_GELU, dzh)
+        self._wgrad(dzh, xtb, hp + "dense.weight", hp + "dense.bias")
+        d_f32 = _e((Mt, H), F32, dev)                                 # gradient w.r.t. the text stream, f32 part
+        ops.gemm_nt(dzh, st.wt("head"), d_f32)
+        d_b16 = None                                                  # ... plus an optional bf16 part
+        notify(st.slots["unimo.encoder.text_layer.%d.attention.self.query.weight" % (self.n_layers - 1)].offset)
+
+        dxv = torch.zeros((Mv, H), device=dev, dtype=F32)             # gradient w.r.t. the vision stream
+        dxvb = _e((Mv, H), BF, dev)
+        for l in reversed(range(self.n_layers)):
+            # ================= text layer l
+            t = f"unimo.encoder.text_layer.{l}."
+            s = sv[f"t{l}"]
+            fused = s["fus"] is not None
+            ds2, doo = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+            ops.ln_bwd(dy_f32=d_f32, dy_bf16=d_b16, s=s["s2"], mean=s["m2"], rstd=s["r2"], gamma=st.m(t + "output.LayerNorm.weight"), M=Mt, H=H,
+                       ds_f32=ds2, ds_bf16=doo, p_drop=p_h, seed=seed + 12 + 4 * l,
+                       dgamma=st.g(t + "output.LayerNorm.weight"), dbeta=st.g(t + "output.LayerNorm.bias"))
+            self._wgrad(doo, s["ht"], t + "output.dense.weight", t + "output.dense.bias")
+            dzt = _e((Mt, I), BF, dev)
+            ops.gemm_nt(doo, st.wt(f"t{l}.out"), dzt, mulz=s["zt"], mul_act=ops.ACT_GELU)
+            self._wgrad(dzt, s["ab"], t + "intermediate.dense.weight", t + "intermediate.dense.bias")
+            da2 = _e((Mt, H), BF, dev)
+            ops.gemm_nt(dzt, st.wt(f"t{l}.int"), da2)
+            dctx_fus = None
+            if fused:
+                self._wgrad(dzt, s["fus"], t + "intermediate.fusion_dense.weight", t + "intermediate.fusion_dense.bias")
+                dfus = _e((Mt, H), BF, dev)
+                ops.gemm_nt(dzt, st.wt(f"t{l}.fus"), dfus)
+                dprobs = _e((Mt, Nvp), F32, dev)
+                ops.gemm_nt(dfus, s["visb"], dprobs, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
+                dsc = _e((Mt, Nvp), BF, dev)
+                ops.softmax_bwd(s["probs"], dprobs, dsc, Mt, Nv)
+                dctx_fus = _e((Mt, H), BF, dev)
+                ops.gemm_nt(dsc, s["visT"], dctx_fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
+                # d(vis) = dS^T ctx + P^T d(fus), accumulated into the vision-stream gradient
+                ops.gemm_tn(dsc, s["ctx"], dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
+                ops.gemm_tn(s["probs"], dfus, dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
+            ds1, dso = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+            ops.ln_bwd(dy_f32=ds2, dy_bf16=da2, s=s["s1"], mean=s["m1"], rstd=s["r1"], gamma=st.m(t + "attention.output.LayerNorm.weight"), M=Mt, H=H,
+                       ds_f32=ds1, ds_bf16=dso, p_drop=p_h, seed=seed + 11 + 4 * l,
+                       dgamma=st.g(t + "attention.output.LayerNorm.weight"), dbeta=st.g(t + "attention.output.LayerNorm.bias"))
+            self._wgrad(dso, s["ctx"], t + "attention.output.dense.weight", t + "attention.output.dense.bias")
+            dctx = _e((Mt, H), BF, dev)
+            ops.gemm_nt(dso, st.wt(f"t{l}.ao"), dctx, res_bf16=dctx_fus)
+            # attention backward; for layers whose (K,V) fed a vision layer the k/v blocks already hold the prefix grads
+            has_prefix_grad = self.export_from <= l < self.n_layers - 1
+            dqkv = s.get("dqkv")
+            if dqkv is None:
+                dqkv = _e((Mt, 3 * H), BF, dev)
+            delta = _e((B, nh, Lq), F32, dev)
+            sep_on = s["tkw"]["sep"] is not None
+            ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:], accum_dkv=has_prefix_grad,
+                         dw=st.g(t + "attention.self.adaptive_weight.0") if sep_on else None, **s["tkw"])
+            names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
+            gw = st.fused([n + ".weight" for n in names], st.grad)
+            ops.gemm_tn(dqkv, s["xb"], gw, colsum=st.fused([n + ".bias" for n in names], st.grad))
+            dtb = _e((Mt, H), BF, dev)
+            ops.gemm_nt(dqkv, st.wt(f"t{l}.qkv"), dtb)
+            d_f32, d_b16 = ds1, dtb
+
+            # ================= vision layer l
+            v = f"unimo.encoder.vision_layers.{l}."
+            s = sv[f"v{l}"]
+            ops.add_f32_bf16(dxv, None, None, dxvb)                    # bf16 copy of the (possibly fusion-updated) stream gradient
+            self._wgrad(dxvb, s["f"], v + "mlp.fc2.weight", v + "mlp.fc2.bias")
+            dz = _e((Mv, I), BF, dev)
+            ops.gemm_nt(dxvb, st.wt(f"v{l}.fc2"), dz, mulz=s["z"], mul_act=ops.ACT_QGELU)
+            self._wgrad(dz, s["h2"], v + "mlp.fc1.weight", v + "mlp.fc1.bias")
+            dh2 = _e((Mv, H), BF, dev)
+            ops.gemm_nt(dz, st.wt(f"v{l}.fc1"), dh2)
+            del dz
+            dx1, dx1b = _e((Mv, H), F32, dev), _e((Mv, H), BF, dev)
+            ops.ln_bwd(dy_bf16=dh2, s=s["x1"], mean=s["m2"], rstd=s["r2"], gamma=st.m(v + "layer_norm2.weight"), M=Mv, H=H, add_f32=dxv,
+                       ds_f32=dx1, dgamma=st.g(v + "layer_norm2.weight"), dbeta=st.g(v + "layer_norm2.bias"))
+            ops.add_f32_bf16(dx1, None, None, dx1b)
+            self._wgrad(dx1b, s["ctx"], v + "self_attn.out_proj.weight", v + "self_attn.out_proj.bias")
+            dctx = dh2                                                 # reuse
+            ops.gemm_nt(dx1b, st.wt(f"v{l}.o"), dctx)
+            dqkv = _e((Mv, 3 * H), BF, dev)
+            delta = _e((B, nh, Nv), F32, dev)
+            pre = s["pre"]
+            dpre = None
+            if pre is not None:                                        # prefix grads land in text layer l-1's dqkv buffer (k,v blocks)
+                dpre = _e((Mt, 3 * H), BF, dev)
+                sv[f"t{l - 1}"]["dqkv"] = dpre
+            q = s["qkv"]
+            ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:],
+                         dpk=dpre[:, H:2 * H] if dpre is not None else None, dpv=dpre[:, 2 * H:] if dpre is not None else None,
+                         q=q[:, :H], k=q[:, H:2 * H], v=q[:, 2 * H:], ctx=s["ctx"], lse=s["lse"], B=B, nh=nh, Sq=Nv, Sk=Nv, scale=0.125,
+                         pk=pre[:, H:2 * H] if pre is not None else None, pv=pre[:, 2 * H:] if pre is not None else None,
+                         Lp=Lq if pre is not None else 0)
+            names = [v + f"self_attn.{n}" for n in ("q_proj", "k_proj", "v_proj")]
+            ops.gemm_tn(dqkv, s["h1"], st.fused([n + ".weight" for n in names], st.grad), colsum=st.fused([n + ".bias" for n in names], st.grad))
+            dh1 = dctx
+            ops.gemm_nt(dqkv, st.wt(f"v{l}.qkv"), dh1)
+            del dqkv
+            ops.ln_bwd(dy_bf16=dh1, s=s["x"], mean=s["m1"], rstd=s["r1"], gamma=st.m(v + "layer_norm1.weight"), M=Mv, H=H, add_f32=dx1,
+                       ds_f32=dxv, dgamma=st.g(v + "layer_norm1.weight"), dbeta=st.g(v + "layer_norm1.bias"))
+            sv[f"v{l}"] = None
+            sv[f"t{l}"] = None
+            if l > 0:
+                notify(st.slots[f"unimo.encoder.text_layer.{l - 1}.attention.self.query.weight"].offset)
+
+        # ---- text embeddings backward: dropout -> LN -> scatter
+        s_t, tmean, trstd = sv["temb"]
+        u = "unimo.text_embeddings."
+        dyd = _e((Mt, H), F32, dev)
+        ops.dropout_bwd_f32(d_f32, d_b16, dyd, Mt * H, p_h, seed + 1)
+        dse = _e((Mt, H), F32, dev)
+        ops.ln_bwd(dy_f32=dyd, s=s_t, mean=tmean, rstd=trstd, gamma=st.m(u + "LayerNorm.weight"), M=Mt, H=H, ds_f32=dse,
+                   dgamma=st.g(u + "LayerNorm.weight"), dbeta=st.g(u + "LayerNorm.bias"))
+        ops.text_embed_scatter(dse, sv["ids"], sv["tt"], st.g(u + "word_embeddings.weight"), st.g(u + "position_embeddings.weight"),
+                               st.g(u + "token_type_embeddings.weight"), B, Lq, H)
+        # ---- vision embeddings backward: pre-LN -> assemble -> patch GEMM weight gradient
+        patches, s_v, vmean, vrstd = sv["vemb"]
+        dsv = _e((Mv, H), F32, dev)
+        ops.ln_bwd(dy_f32=dxv, s=s_v, mean=vmean, rstd=vrstd, gamma=st.m("unimo.vision_pre_layrnorm.weight"), M=Mv, H=H, ds_f32=dsv,
+                   dgamma=st.g("unimo.vision_pre_layrnorm.weight"), dbeta=st.g("unimo.vision_pre_layrnorm.bias"))
+        dpe = _e((B * 2 * P, H), BF, dev)
+        ops.vision_assemble_bwd(dsv, dpe, st.g("unimo.vision_embeddings.class_embedding"), st.g("unimo.vision_embeddings.position_embedding.weight"),
+                                B, P, H)
+        gw = st.g("unimo.vision_embeddings.patch_embedding.weight")
+        ops.gemm_tn(dpe, patches, gw.view(H, -1))
+        notify(st.total)

@@ -1,0 +1,193 @@
+"""Autograd nodes that hang the HIP engine into ``loss.backward()``.
+
+Coarse on purpose: one node for the whole encoder + head transform, one for the scoring slice of the tied decoder,
+one each for the two loss terms.  Parameter gradients are NOT returned through autograd; the kernels accumulate
+into ``FlatStore.grad`` (which ``p.grad`` views), the way fused wgrad accumulation is usually done.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+class _MKGformerFn(torch.autograd.Function):
+    """trans_hidden_states = head_transform(encoder(...)).  UnimoForMaskedLM.forward, modeling_unimo.py:848-893."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder):
+        trans, transb, sv = engine.forward(input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed)
+        ctx.engine, ctx.sv = engine, sv
+        holder["trans_bf16"] = transb
+        return trans
+
+    @staticmethod
+    def backward(ctx, dtrans):
+        sv, ctx.sv = ctx.sv, None
+        if sv is None:
+            raise RuntimeError("MKGformer backward called twice (activations are freed after the first pass)")
+        ctx.engine.backward(sv, dtrans)
+        return (None,) * 10
+
+
+class _ScoreFn(torch.autograd.Function):
+    """logits[rows][:, ids] of the tied decoder: trans[rows] @ word_emb[ids]^T + bias[ids]
+    (modeling_unimo.py:958 restricted to what lit_models/transformer.py:75-95,131-160 actually read)."""
+
+    @staticmethod
+    def forward(ctx, trans, transb, rows, ids, store):
+        R, A = rows.numel(), ids.numel()
+        W = store.w("unimo.text_embeddings.word_embeddings.weight")
+        out = torch.empty((R, A), device=trans.device, dtype=F32)
+        ops.gemm_nt(transb, W, out, a_rows=rows, b_rows=ids, bias=store.m("cls.predictions.bias"), bias_by_brow=True)
+        ctx.store, ctx.rows, ctx.ids, ctx.transb, ctx.shape = store, rows, ids, transb, trans.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        store, rows, ids, transb = ctx.store, ctx.rows, ctx.ids, ctx.transb
+        dev = dlogits.device
+        R, A = dlogits.shape
+        H = transb.shape[1]
+        Ap = ((A + 63) // 64) * 64
+        dl = torch.empty((R, Ap), device=dev, dtype=BF)
+        ops.cast_pad_f32_bf16(dlogits.contiguous(), dl, R, A)
+        W = store.w("unimo.text_embeddings.word_embeddings.weight")
+        Wg = torch.empty((A, H), device=dev, dtype=BF)
+        ops.gather_rows_bf16(W, ids, Wg)
+        WgT = torch.empty((H, Ap), device=dev, dtype=BF)
+        ops.transpose_bf16(Wg, WgT, A, H, Ap)
+        drows = torch.empty((R, H), device=dev, dtype=F32)
+        ops.gemm_nt(dl, WgT, drows)
+        dtrans = torch.zeros(ctx.shape, device=dev, dtype=F32)
+        ops.scatter_add_rows_f32(drows, rows, dtrans.view(-1, H))
+        trows = torch.empty((R, H), device=dev, dtype=BF)
+        ops.gather_rows_bf16(transb, rows, trows)
+        ops.gemm_tn(dl, trows, store.g("unimo.text_embeddings.word_embeddings.weight"), NX=A, out_rows=ids,
+                    colsum=store.g("cls.predictions.bias"), colsum_by_row=True)
+        return dtrans, None, None, None, None
+
+
+class _LSCEFn(torch.autograd.Function):
+    """LabelSmoothSoftmaxCEV1.forward, lit_models/utils.py:42-66 (reduction='mean', no ignored labels)."""
+
+    @staticmethod
+    def forward(ctx, logits, label, eps):
+        logits = logits.contiguous()
+        R = logits.shape[0]
+        rows = torch.empty(R, device=logits.device, dtype=F32)
+        lse = torch.empty(R, device=logits.device, dtype=F32)
+        ops.lsce_fwd(logits, label, eps, rows, lse)
+        ctx.save_for_backward(logits, label, lse)
+        ctx.eps = eps
+        return rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, label, lse = ctx.saved_tensors
+        dl = torch.empty_like(logits)
+        ops.lsce_bwd(logits, label, lse, ctx.eps, g.contiguous().view(1).float(), 1.0 / logits.shape[0], dl_f32=dl)
+        return dl, None, None
+
+
+class _SimLossFn(torch.autograd.Function):
+    """Relaxation loss, lit_models/transformer.py:103-108."""
+
+    @staticmethod
+    def forward(ctx, trans, rel_idx, q_idx, a_idx):
+        trans = trans.contiguous()
+        rows = torch.empty(trans.shape[0], device=trans.device, dtype=F32)
+        ops.simloss_fwd(trans, rel_idx, q_idx, a_idx, rows)
+        ctx.save_for_backward(trans, rel_idx, q_idx, a_idx)
+        return rows.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        trans, rel_idx, q_idx, a_idx = ctx.saved_tensors
+        d = torch.zeros_like(trans)
+        ops.simloss_bwd(trans, rel_idx, q_idx, a_idx, g.contiguous().view(1).float(), 1.0 / trans.shape[0], d)
+        return d, None, None, None
+
+
+def label_smooth_ce(logits: torch.Tensor, label: torch.Tensor, eps: float = 0.1) -> torch.Tensor:
+    return _LSCEFn.apply(logits, label.to(torch.int64).contiguous(), float(eps))
+
+
+def relaxation_loss(trans: torch.Tensor, rel_idx: torch.Tensor, q_head_idx: torch.Tensor, a_head_idx: torch.Tensor) -> torch.Tensor:
+    return _SimLossFn.apply(trans, rel_idx.to(torch.int64).contiguous(), q_head_idx.to(torch.int64).contiguous(),
+                            a_head_idx.to(torch.int64).contiguous())
+
+
+def entity_ranks(logits: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+    """1 + #(logit > logit[label]); equals argsort(argsort(-logits))[label]+1 of lit_models/transformer.py:162-164
+    whenever the label's logit is not tied."""
+    logits = logits.detach().contiguous().float()
+    out = torch.empty(logits.shape[0], device=logits.device, dtype=torch.int64)
+    ops.rank(logits, label.to(torch.int64).contiguous(), out)
+    return out
+
+
+class LazyRows:
+    """``logits[arange(B), mask_idx]`` without the [B,L,V] tensor; supports ``[:, ids]``, ``[rows, st:ed]``, ``[rows, ids]``."""
+
+    def __init__(self, owner: "LazyLogits", rows_i32: torch.Tensor):
+        self.owner, self.rows = owner, rows_i32
+
+    @property
+    def shape(self):
+        return (self.rows.numel(), self.owner.vocab)
+
+    def _ids(self, sel) -> torch.Tensor:
+        dev = self.rows.device
+        if isinstance(sel, slice):
+            st, ed, step = sel.indices(self.owner.vocab)
+            return torch.arange(st, ed, step, device=dev, dtype=torch.int32)
+        if isinstance(sel, (list, tuple)):
+            return torch.tensor(list(sel), device=dev, dtype=torch.int32)
+        return sel.to(device=dev, dtype=torch.int32).contiguous()
+
+    def __getitem__(self, key):
+        rsel, csel = key if isinstance(key, tuple) else (key, slice(None))
+        rows = self.rows
+        if not (isinstance(rsel, slice) and rsel == slice(None)):
+            rows = rows[rsel].contiguous()
+        o = self.owner
+        return _ScoreFn.apply(o.trans, o.trans_bf16, rows, self._ids(csel), o.store)
+
+
+class LazyLogits:
+    """Stand-in for ``MaskedLMOutput.logits`` [B,L,V] (2.75 GB fp32 at B=256 in the reference, modeling_unimo.py:958).
+    Indexing patterns used by the trainer surface are scored on demand; ``materialize()`` builds the full tensor."""
+
+    def __init__(self, trans: torch.Tensor, trans_bf16: torch.Tensor, store):
+        self.trans, self.trans_bf16, self.store = trans, trans_bf16, store
+        self.vocab = store.slots["unimo.text_embeddings.word_embeddings.weight"].shape[0]
+
+    @property
+    def shape(self):
+        return tuple(self.trans.shape[:2]) + (self.vocab,)
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple) and len(key) == 2 and torch.is_tensor(key[0]) and torch.is_tensor(key[1]):
+            L = self.trans.shape[1]
+            rows = (key[0].to(self.trans.device).to(torch.int64) * L + key[1].to(self.trans.device).to(torch.int64)).to(torch.int32).contiguous()
+            return LazyRows(self, rows)
+        return self.materialize()[key]
+
+    def mask_rows(self, input_ids: torch.Tensor, mask_token_id: int) -> LazyRows:
+        """Device-side ``(input_ids == mask).nonzero()`` + row gather (no host sync; lit_models/transformer.py:94)."""
+        B, L = input_ids.shape
+        pos = torch.empty(B, device=input_ids.device, dtype=torch.int32)
+        row = torch.empty(B, device=input_ids.device, dtype=torch.int32)
+        ops.find_token(input_ids.contiguous(), mask_token_id, pos, row)
+        return LazyRows(self, row)
+
+    def materialize(self) -> torch.Tensor:
+        B, L, _ = self.trans.shape
+        rows = torch.arange(B * L, device=self.trans.device, dtype=torch.int32)
+        ids = torch.arange(self.vocab, device=self.trans.device, dtype=torch.int32)
+        return _ScoreFn.apply(self.trans, self.trans_bf16, rows, ids, self.store).view(B, L, self.vocab)

@@ -1,0 +1,173 @@
+"""TransformerLitModel: loss, ranking eval, metrics and optimizer config of the MarT trainer surface
+(reference: MarT/lit_models/transformer.py:18-262), with every tensor op on the HIP kernels.
+
+Same constructor, hooks and return types; differences that do not change results:
+  * ``logits`` is a lazy object -- only the [MASK] row x the scored vocabulary slice is ever computed,
+  * the [MASK] position is found on the device (no ``nonzero`` host sync),
+  * ranks are computed as 1 + #(logit > logit[label]) instead of two full sorts (identical without ties),
+  * AdamW is the fused multi-tensor kernel over the flat parameter buffer.
+"""
+from functools import partial
+
+import numpy as np
+import torch
+
+from .. import functional as Fn
+from ..optim import FusedAdamW, LinearWarmupSchedule
+from .base import BaseLitModel
+from .utils import LabelSmoothSoftmaxCEV1
+
+
+def decode(output_ids, tokenizer):
+    return [s.strip() for s in tokenizer.batch_decode(output_ids, skip_special_tokens=False, clean_up_tokenization_spaces=True)]
+
+
+class TransformerLitModel(BaseLitModel):
+    def __init__(self, model, args, tokenizer=None, data_config={}):
+        super().__init__(model, args)
+        self.save_hyperparameters(args)
+        if args.label_smoothing != 0.0:
+            self.loss_fn = LabelSmoothSoftmaxCEV1(lb_smooth=args.label_smoothing)
+        else:
+            self.loss_fn = LabelSmoothSoftmaxCEV1(lb_smooth=0.0)        # plain CE == label smoothing with eps 0
+        self.best_acc = 0
+        self.first = True
+        self.tokenizer = tokenizer
+        self.__dict__.update(data_config)
+        self.model.resize_token_embeddings(len(self.tokenizer))
+        self.alpha = args.alpha
+        self._ids_cache = {}
+
+    # -- lit_models/transformer.py:41-54
+    def _init_relation_word(self):
+        self.tokenizer.add_special_tokens({"additional_special_tokens": ["[R]"]})
+        self.model.resize_token_embeddings(len(self.tokenizer))
+        self.decode = partial(decode, tokenizer=self.tokenizer)
+        with torch.no_grad():
+            emb = self.model.get_input_embeddings()
+            rel_word = [a[0] for a in self.tokenizer(["[R]"], add_special_tokens=False)["input_ids"]]
+            src = torch.as_tensor(list(self.analogy_relation_ids), dtype=torch.long, device=emb.weight.device)
+            for idx in rel_word:
+                emb.weight[idx] = torch.mean(emb.weight[src], dim=0)
+            assert self.model.get_input_embeddings().weight is self.model.get_output_embeddings().weight
+        if getattr(self.model, "_store", None) is not None:
+            self.model.sync_shadows()
+
+    def _ids(self, key):
+        v = getattr(self, key)
+        dev = self.model.store.device
+        c = self._ids_cache.get(key)
+        if c is None or c.device != dev:
+            c = torch.as_tensor(list(v) if not torch.is_tensor(v) else v, dtype=torch.int32, device=dev).contiguous()
+            self._ids_cache[key] = c
+        return c
+
+    def _mask_rows(self, logits, input_ids):
+        return logits.mask_rows(input_ids, int(self.tokenizer.mask_token_id))
+
+    # -- lit_models/transformer.py:59-113
+    def training_step(self, batch, batch_idx):
+        label = batch.pop("label")
+        batch.pop("rel_label", None)
+        pre_type = batch.pop("pre_type", None)
+        rel_idx = batch.pop("rel_idx", None)
+        q_head_idx = batch.pop("q_head_idx", None)
+        a_head_idx = batch.pop("a_head_idx", None)
+        input_ids = batch["input_ids"]
+        model_output = self.model(**batch, return_dict=True)
+        logits = model_output[0].logits
+        dev = logits.trans.device
+        label = label.to(dev)
+        rows = self._mask_rows(logits, input_ids.to(dev))
+        if self.args.pretrain:
+            pre_type = pre_type.to(dev)
+            loss = 0
+            entity_mask = (pre_type != 2).nonzero(as_tuple=True)[0]
+            if len(entity_mask) > 0:
+                loss = loss + self.loss_fn(rows[entity_mask, self.entity_id_st:self.entity_id_ed], label[entity_mask])
+            relation_mask = (pre_type == 2).nonzero(as_tuple=True)[0]
+            if len(relation_mask) > 0:
+                loss = loss + self.loss_fn(rows[relation_mask, self.relation_id_st:self.relation_id_ed], label[relation_mask])
+        else:
+            mask_logits = rows[:, self._ids("analogy_entity_ids")]
+            trans_hidden_states = model_output[1]
+            sim_loss = Fn.relaxation_loss(trans_hidden_states, rel_idx.to(dev), q_head_idx.to(dev), a_head_idx.to(dev))
+            loss = self.loss_fn(mask_logits, label) + self.alpha * sim_loss
+        if batch_idx == 0 and getattr(self, "decode", None) is not None and getattr(self.args, "print_first_batch", False):
+            print("\n".join(self.decode(batch["input_ids"][:4])))
+        return loss
+
+    # -- lit_models/transformer.py:115-166
+    @torch.no_grad()
+    def _eval(self, batch, batch_idx):
+        label = batch.pop("label")
+        pre_type = batch.pop("pre_type", None)
+        for k in ("rel_idx", "rel_label", "q_head_idx", "a_head_idx"):
+            batch.pop(k, None)
+        input_ids = batch["input_ids"]
+        model_output = self.model(**batch, return_dict=True)
+        logits = model_output[0].logits
+        dev = logits.trans.device
+        label = label.to(dev)
+        rows = self._mask_rows(logits, input_ids.to(dev))
+        if self.args.pretrain:
+            pre_type = pre_type.to(dev)
+            out = {}
+            entity_mask = (pre_type != 2).nonzero(as_tuple=True)[0]
+            if len(entity_mask) > 0:
+                lg = rows[entity_mask, self.entity_id_st:self.entity_id_ed]
+                out["entity_ranks"] = Fn.entity_ranks(lg, label[entity_mask]).cpu().numpy()
+            relation_mask = (pre_type == 2).nonzero(as_tuple=True)[0]
+            if len(relation_mask) > 0:
+                lg = rows[relation_mask, self.relation_id_st:self.relation_id_ed]
+                out["relation_ranks"] = Fn.entity_ranks(lg, label[relation_mask]).cpu().numpy()
+            if not out:
+                raise ValueError("entity and relation cannot be None at the same time.")
+            return out
+        mask_logits = rows[:, self._ids("analogy_entity_ids")]
+        return dict(entity_ranks=Fn.entity_ranks(mask_logits, label).cpu().numpy())
+
+    def validation_step(self, batch, batch_idx):
+        return self._eval(batch, batch_idx)
+
+    def test_step(self, batch, batch_idx):
+        return self._eval(batch, batch_idx)
+
+    # -- lit_models/transformer.py:173-222
+    def _epoch_end(self, outputs):
+        entity_ranks = [o["entity_ranks"] for o in outputs if "entity_ranks" in o]
+        if len(entity_ranks) > 0:
+            r = np.concatenate(entity_ranks)
+            for k in (1, 3, 5, 10, 20):
+                self.log(f"Eval_entity/hits{k}", (r <= k).mean())
+            self.log("Eval_entity/mean_rank", r.mean())
+            self.log("Eval_entity/mrr", (1.0 / r).mean())
+            self.log("entity_hits10", (r <= 10).mean(), prog_bar=True)
+            self.log("entity_hits1", (r <= 1).mean(), prog_bar=True)
+
+    def validation_epoch_end(self, outputs) -> None:
+        self._epoch_end(outputs)
+
+    def test_epoch_end(self, outputs) -> None:
+        self._epoch_end(outputs)
+
+    # -- lit_models/transformer.py:224-241
+    def configure_optimizers(self):
+        if self.optimizer_name != "AdamW":
+            raise NotImplementedError("the HIP path implements AdamW (the only optimizer MarT's scripts use)")
+        optimizer = FusedAdamW(self.model, lr=self.lr, eps=1e-8, weight_decay=self.args.weight_decay)
+        steps = self.num_training_steps
+        scheduler = LinearWarmupSchedule(optimizer, num_warmup_steps=steps * self.args.warm_up_radio, num_training_steps=steps)
+        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "interval": "step", "frequency": 1}}
+
+    def _freeze_attention(self):
+        raise NotImplementedError("parameter freezing is commented out in the reference (transformer.py:36-39) and unsupported here")
+
+    _freeze_word_embedding = _freeze_attention
+
+    @staticmethod
+    def add_to_argparse(parser):
+        parser = BaseLitModel.add_to_argparse(parser)
+        parser.add_argument("--label_smoothing", type=float, default=0.1, help="")
+        parser.add_argument("--bce", type=int, default=0, help="")
+        return parser

@@ -211,6 +211,10 @@ def cast_bf16_f32(src, dst):
     L.check(L.lib().mart_cast_bf16_f32(_p(src), _p(dst), src.numel(), _stream()), "mart_cast_bf16_f32")
 
 
+def cast_pad_f32_bf16(src, dst, R, Cc):
+    L.check(L.lib().mart_cast_pad_f32_bf16(_p(src), _rows2d(src), _p(dst), _rows2d(dst), R, Cc, _stream()), "mart_cast_pad_f32_bf16")
+
+
 def gather_rows_bf16(src, rows, dst):
     R, H = dst.shape
     L.check(L.lib().mart_gather_rows_bf16(_p(src), _rows2d(src), _p(rows), _p(dst), R, H, _stream()), "mart_gather_rows_bf16")

@@ -1,0 +1,87 @@
+"""Fused AdamW over the flat parameter buffer + the linear warmup/decay schedule
+(reference: lit_models/transformer.py:224-241; torch.optim.AdamW and HF get_linear_schedule_with_warmup semantics)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .params import NO_DECAY
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """One multi-tensor HIP launch per step: fp32 master/m/v update + bf16 shadow refresh, then W^T shadows.
+
+    ``param_groups`` mirrors the reference's two groups (decay 0.01 / 0 by the substring rule) for inspection and
+    for the scheduler's ``lr`` plumbing; tensors that never receive a gradient in the reference (dead pooler /
+    post-layernorm: grad None => torch skips them entirely) are left untouched.
+    """
+
+    def __init__(self, model, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale: float = 1.0):
+        self.model = model
+        store = model.store
+        named = dict(model.named_parameters())
+        decay = [p for n, p in named.items() if p.requires_grad and not any(nd in n for nd in NO_DECAY)]
+        no_decay = [p for n, p in named.items() if p.requires_grad and any(nd in n for nd in NO_DECAY)]
+        groups = [{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0}]
+        super().__init__(groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.m = torch.zeros_like(store.master)
+        self.v = torch.zeros_like(store.master)
+        self.steps = 0
+        self.grad_scale = grad_scale
+        self._store_id = id(store)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.store.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        store = self.model.store
+        if id(store) != self._store_id:
+            raise RuntimeError("the model's parameter storage was rebuilt (resize/.to()) after the optimizer was created")
+        self.steps += 1
+        g0 = self.param_groups[0]
+        b1, b2 = g0["betas"]
+        ops.adamw(master=store.master, grad=store.grad, m=self.m, v=self.v, shadow=store.shadow, chunks=store.chunks, n_chunks=store.n_chunks,
+                  lr=float(g0["lr"]), beta1=b1, beta2=b2, eps=g0["eps"], weight_decay=float(g0["weight_decay"]),
+                  bc1=1.0 - b1 ** self.steps, bc2=1.0 - b2 ** self.steps, grad_scale=self.grad_scale)
+        store.refresh_transposed()
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "steps": self.steps, "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["m"]); self.v.copy_(sd["v"]); self.steps = int(sd["steps"])
+        for g in self.param_groups:
+            g["lr"] = sd["lr"]
+
+
+class LinearWarmupSchedule:
+    """lambda(t) = t/max(1,w) for t<w else max(0,(T-t)/max(1,T-w)); w may be fractional (0.1*T)."""
+
+    def __init__(self, optimizer, num_warmup_steps, num_training_steps, last_epoch: int = -1):
+        self.optimizer = optimizer
+        self.w, self.T = num_warmup_steps, num_training_steps
+        self.base_lrs = [g["lr"] for g in optimizer.param_groups]
+        self.last_epoch = last_epoch
+        self.step()                                                    # like torch's LambdaLR: lr(0) applied at construction
+
+    def lr_lambda(self, t: int) -> float:
+        if t < self.w:
+            return float(t) / float(max(1, self.w))
+        return max(0.0, float(self.T - t) / float(max(1, self.T - self.w)))
+
+    def step(self):
+        self.last_epoch += 1
+        f = self.lr_lambda(self.last_epoch)
+        for g, b in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = b * f
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd["last_epoch"] - 1
+        self.step()

@@ -1,0 +1,90 @@
+"""A ~100-line stand-in for the pl.Trainer loop the reference relies on (MarT/main.py:151-162):
+drives TransformerLitModel's hooks (training_step / validation_step / *_epoch_end / configure_optimizers),
+steps the scheduler every batch (interval 'step'), averages gradients across ranks when launched under torchrun."""
+from __future__ import annotations
+
+import time
+from typing import Dict, Iterable, List, Optional
+
+import torch
+
+from .distributed import GradSync, all_gather_ranks
+
+
+class Trainer:
+    def __init__(self, max_epochs: int = 1, max_steps: Optional[int] = None, accumulate_grad_batches: int = 1, world_size: int = 1,
+                 log_every: int = 0):
+        self.max_epochs, self.max_steps, self.accumulate_grad_batches = max_epochs, max_steps, accumulate_grad_batches
+        self.world_size = world_size
+        self.log_every = log_every
+        self.num_train_batches = 0
+        self.global_step = 0
+        self.history: List[Dict[str, float]] = []
+
+    def _setup(self, lit, train_batches):
+        lit.trainer = self
+        self.num_train_batches = len(train_batches)
+        lit.model.finalize()
+        oc = lit.configure_optimizers()
+        self.optimizer, self.scheduler = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
+        self.sync = GradSync(lit.model)
+        self.optimizer.grad_scale = self.sync.grad_scale / max(1, self.accumulate_grad_batches)
+
+    def train_step(self, lit, batch, batch_idx: int) -> torch.Tensor:
+        lit.model.train()
+        first = batch_idx % self.accumulate_grad_batches == 0
+        last = (batch_idx + 1) % self.accumulate_grad_batches == 0
+        if first:
+            self.optimizer.zero_grad()
+        if last:
+            self.sync.begin()
+        else:
+            lit.model.engine.grad_ready = None
+        loss = lit.training_step(dict(batch), batch_idx)
+        loss.backward()
+        if last:
+            self.sync.finish()
+            self.optimizer.step()
+            self.scheduler.step()
+            self.global_step += 1
+            if self.sync.reducer is not None:
+                lit.model.engine.grad_ready = self.sync.reducer.ready
+        return loss.detach()
+
+    def fit(self, lit, train_batches: Iterable, val_batches: Optional[Iterable] = None):
+        train_batches = list(train_batches) if not hasattr(train_batches, "__len__") else train_batches
+        self._setup(lit, train_batches)
+        for epoch in range(self.max_epochs):
+            t0 = time.time()
+            for i, batch in enumerate(train_batches):
+                loss = self.train_step(lit, batch, i)
+                if self.log_every and (i + 1) % self.log_every == 0:
+                    print(f"epoch {epoch} step {i + 1}: loss {float(loss):.4f} lr {self.optimizer.param_groups[0]['lr']:.3e}")
+                if self.max_steps and self.global_step >= self.max_steps:
+                    break
+            rec = {"epoch": epoch, "train_time_s": time.time() - t0}
+            if val_batches is not None:
+                rec.update(self.validate(lit, val_batches))
+            self.history.append(rec)
+            if self.max_steps and self.global_step >= self.max_steps:
+                break
+        return self.history
+
+    def _run_eval(self, lit, batches, step_fn, end_fn) -> Dict[str, float]:
+        lit.model.eval()
+        outs = [step_fn(dict(b), i) for i, b in enumerate(batches)]
+        merged = {}
+        for key in ("entity_ranks", "relation_ranks"):
+            parts = [o[key] for o in outs if key in o]
+            if parts:
+                import numpy as np
+                merged[key] = all_gather_ranks(np.concatenate(parts))
+        lit.logged = {}
+        end_fn([merged])
+        return dict(lit.logged)
+
+    def validate(self, lit, batches) -> Dict[str, float]:
+        return self._run_eval(lit, batches, lit.validation_step, lit.validation_epoch_end)
+
+    def test(self, lit, batches) -> Dict[str, float]:
+        return self._run_eval(lit, batches, lit.test_step, lit.test_epoch_end)

@@ -1,0 +1,175 @@
+"""End-to-end parity of the HIP MKGformer path (bf16 compute) against the CPU oracle (fp32), real dimensions.
+Tolerances follow BASELINE.json north_star: logits within 1e-2 (bf16); ranks exact where the margin exceeds it."""
+import argparse
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mkgformer_oracle as O  # noqa: E402  (tests may use the oracle; the product never does)
+
+BASE, NE, NR = 30522, 11292, 192
+
+
+def _oracle_sd(vc, seed, analogy_rel):
+    sd = O.init_params(vc, O.TextCfg(vocab_size=BASE + NE + NR), seed=seed)
+    return O.init_relation_word(sd, analogy_rel)
+
+
+def _product(vc_patch, seed):
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.lit_models import TransformerLitModel
+    from mkg_analogy_amd.models import MKGformerKGC, TextConfig, VisionConfig
+    torch.manual_seed(0)
+    model = MKGformerKGC(VisionConfig(patch_size=vc_patch), TextConfig())
+    cfg = D.data_config(seed=1234)
+    args = argparse.Namespace(label_smoothing=0.1, alpha=0.43, pretrain=0, lr=5e-5, weight_decay=0.01, optimizer="AdamW", warm_up_radio=0.1)
+    tok = D.FakeTokenizer()
+    lit = TransformerLitModel(model=model, args=args, tokenizer=tok, data_config=cfg)          # resize -> 42006
+    vc = O.VisionCfg(patch_size=vc_patch)
+    sd0 = O.init_params(vc, O.TextCfg(vocab_size=BASE + NE + NR), seed=seed)
+    missing, unexpected = model.load_state_dict(sd0, strict=False)
+    assert not unexpected and all(("position_ids" in m or "decoder" in m) for m in missing), (missing, unexpected)
+    model.cuda()
+    lit._init_relation_word()                                                                  # -> 42007, [R] = mean of relation rows
+    return model, lit, cfg, vc
+
+
+def _stats(name, got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs().max().item()
+    rel = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    print(f"   {name}: max|err| {err:.3e}  rel-L2 {rel:.3e}  ref max {ref.abs().max().item():.3e}")
+    return err, rel
+
+
+@pytest.mark.parametrize("patch,B", [(32, 4), (16, 2)])
+def test_forward_backward_vs_oracle(patch, B):
+    from mkg_analogy_amd import data_synth as D
+    model, lit, cfg, vc = _product(patch, seed=3)
+    sd = _oracle_sd(vc, 3, cfg["analogy_relation_ids"])
+    tc = O.TextCfg(vocab_size=BASE + NE + NR + 1)
+    # [R] row parity with the reference semantics
+    w = model.get_input_embeddings().weight
+    assert w.shape[0] == D.VOCAB
+    np.testing.assert_allclose(w[-1].detach().cpu().numpy(), sd["unimo.text_embeddings.word_embeddings.weight"][-1].numpy(), atol=1e-6)
+
+    batch = D.make_batch(B, 64, seed=11)
+    ids = torch.tensor(cfg["analogy_entity_ids"])
+    # ---------------- oracle (fp32, CPU)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    _, trans_ref = O.forward(sdg, vc, tc, batch["input_ids"], batch["attention_mask"], batch["token_type_ids"], batch["pixel_values"],
+                             batch["sep_idx"], train=False)
+    loss_ref, ml_ref = O.finetune_loss(sdg, trans_ref, batch["input_ids"], batch["label"], batch["rel_idx"], batch["q_head_idx"],
+                                       batch["a_head_idx"], ids, alpha=0.43)
+    loss_ref.backward()
+    # ---------------- HIP path
+    model.eval()
+    gb = {k: v.cuda() for k, v in batch.items()}
+    st = model.store
+    st.zero_grad()
+    loss = lit.training_step(dict(gb), 1)
+    loss.backward()
+    torch.cuda.synchronize()
+    out, trans = model(input_ids=gb["input_ids"], attention_mask=gb["attention_mask"], token_type_ids=gb["token_type_ids"],
+                       pixel_values=gb["pixel_values"], sep_idx=gb["sep_idx"], return_dict=True)
+    _, mi = (gb["input_ids"] == 103).nonzero(as_tuple=True)
+    ml = out.logits[torch.arange(B, device="cuda"), mi][:, ids.cuda()]
+    print(f"\npatch {patch} B {B}: loss hip {float(loss):.6f} oracle {float(loss_ref):.6f}")
+    e_t, r_t = _stats("trans_hidden", trans, trans_ref)
+    e_l, r_l = _stats("mask logits", ml, ml_ref)
+    assert e_l < 1e-2, "mask logits outside the bf16 tolerance of BASELINE.json"
+    assert r_t < 2e-2
+    assert abs(float(loss) - float(loss_ref)) < 5e-3
+    # ranks: exact wherever the label's margin to every other class exceeds the logit tolerance
+    ranks_ref = O.ranks_double_sort(ml_ref.detach(), batch["label"])
+    ev = lit._eval(dict(gb), 0)
+    amb = ((ml_ref.detach() - ml_ref.detach()[torch.arange(B), batch["label"]][:, None]).abs() < 2 * e_l).sum(1).numpy() - 1
+    print("   ranks hip", ev["entity_ranks"], "oracle", ranks_ref, "ambiguous", amb)
+    assert np.all(np.abs(ev["entity_ranks"] - ranks_ref) <= amb)
+    # gradients
+    worst = 0.0
+    names = ["cls.predictions.transform.dense.weight", "cls.predictions.bias", "unimo.text_embeddings.word_embeddings.weight",
+             "unimo.text_embeddings.position_embeddings.weight", "unimo.text_embeddings.LayerNorm.weight",
+             "unimo.vision_embeddings.patch_embedding.weight", "unimo.vision_embeddings.class_embedding",
+             "unimo.vision_embeddings.position_embedding.weight", "unimo.vision_pre_layrnorm.bias"]
+    for l in (0, 5, 7, 8, 11):
+        t, v = f"unimo.encoder.text_layer.{l}.", f"unimo.encoder.vision_layers.{l}."
+        names += [t + "attention.self.query.weight", t + "attention.self.key.bias", t + "attention.self.value.weight",
+                  t + "attention.self.adaptive_weight.0", t + "attention.self.adaptive_weight.1", t + "attention.output.dense.weight",
+                  t + "attention.output.LayerNorm.weight", t + "intermediate.dense.weight", t + "intermediate.dense.bias",
+                  t + "output.dense.weight", t + "output.LayerNorm.bias",
+                  v + "self_attn.q_proj.weight", v + "self_attn.k_proj.bias", v + "self_attn.v_proj.weight", v + "self_attn.out_proj.weight",
+                  v + "layer_norm1.weight", v + "mlp.fc1.weight", v + "mlp.fc1.bias", v + "mlp.fc2.weight", v + "layer_norm2.bias"]
+        if l >= 8:
+            names += [t + "intermediate.fusion_dense.weight", t + "intermediate.fusion_dense.bias"]
+    for n in names:
+        g, r = st.g(n).detach().float().cpu(), sdg[n].grad
+        rel = ((g - r).norm() / (r.norm() + 1e-20)).item()
+        cos = torch.nn.functional.cosine_similarity(g.flatten(), r.flatten(), dim=0).item()
+        worst = max(worst, rel)
+        flag = "" if rel < 0.08 else "   <-- CHECK"
+        print(f"   grad {n}: rel-L2 {rel:.3e} cos {cos:.5f} |ref| {r.norm().item():.3e}{flag}")
+        assert cos > 0.99 and rel < 0.12, n
+    # tensors that get no gradient in the reference stay at zero
+    for n in ("unimo.text_pooler.dense.weight", "unimo.vision_post_layernorm.weight"):
+        assert float(st.g(n).abs().max()) == 0.0
+    # fusion_dense of layers < 8 is unused -> zero gradient (reference: None)
+    assert float(st.g("unimo.encoder.text_layer.3.intermediate.fusion_dense.weight").abs().max()) == 0.0
+
+
+def test_train_mode_step_and_optimizer():
+    """Dropout on: loss finite and close to eval loss; 3 fused-AdamW steps reduce the loss on a fixed batch;
+    parameter update matches torch.optim.AdamW applied to the same gradients."""
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.trainer import Trainer
+    model, lit, cfg, vc = _product(32, seed=5)
+    gb = D.make_batch(8, 64, seed=21, device="cuda")
+    tr = Trainer(max_epochs=1, max_steps=40)
+    tr._setup(lit, [gb] * 40)
+    st = model.store
+    name = "unimo.encoder.vision_layers.3.mlp.fc1.weight"
+    losses = []
+    for i in range(4):
+        before = st.m(name).clone()
+        lr = tr.optimizer.param_groups[0]["lr"]
+        loss = tr.train_step(lit, gb, i)
+        losses.append(float(loss))
+        g = st.g(name).clone()
+        if i == 1:          # step 2 (lr > 0): check one tensor against torch.optim.AdamW given the same grad history is impractical;
+            # instead verify the closed form for step count i+1 using the optimizer's own moments
+            m, v = tr.optimizer.m[st.slots[name].offset:st.slots[name].offset + g.numel()].view_as(g), \
+                tr.optimizer.v[st.slots[name].offset:st.slots[name].offset + g.numel()].view_as(g)
+            stepn = tr.optimizer.steps
+            ref = before * (1 - lr * 0.01) - (lr / (1 - 0.9 ** stepn)) * m / (v.sqrt() / math.sqrt(1 - 0.999 ** stepn) + 1e-8)
+            assert torch.allclose(st.m(name), ref, atol=1e-7, rtol=1e-5)
+            assert torch.allclose(st.w(name).float(), st.m(name), atol=1e-2, rtol=1e-2)
+            assert torch.equal(st.wt("v3.fc1"), st.w(name).t())
+    print("train-mode losses", losses)
+    assert all(math.isfinite(x) for x in losses)
+    assert losses[-1] < losses[0]
+    m = tr.validate(lit, [gb])
+    assert "Eval_entity/hits1" in m and 0 <= m["Eval_entity/hits1"] <= 1
+
+
+def test_pretrain_branch():
+    from mkg_analogy_amd import data_synth as D
+    model, lit, cfg, vc = _product(32, seed=7)
+    lit.args.pretrain = 1
+    batch = D.make_batch(6, 96, seed=31, pretrain=True)
+    sd = _oracle_sd(vc, 7, cfg["analogy_relation_ids"])
+    tc = O.TextCfg(vocab_size=BASE + NE + NR + 1)
+    _, trans_ref = O.forward(sd, vc, tc, batch["input_ids"], batch["attention_mask"], batch["token_type_ids"], batch["pixel_values"], None, train=False)
+    loss_ref = O.pretrain_loss(sd, trans_ref, batch["input_ids"], batch["label"], batch["pre_type"], (BASE, BASE + NE), (BASE + NE, BASE + NE + NR))
+    model.eval()
+    gb = {k: v.cuda() for k, v in batch.items()}
+    model.store.zero_grad()
+    loss = lit.training_step(dict(gb), 1)
+    loss.backward()
+    print("pretrain loss hip", float(loss), "oracle", float(loss_ref))
+    assert abs(float(loss) - float(loss_ref)) < 1e-2
+    ev = lit._eval(dict(gb), 0)
+    assert "entity_ranks" in ev or "relation_ranks" in ev
