@@ -44,6 +44,7 @@ class UnimoEngine:
         self.fuse_from = 8                     # modeling_unimo.py:616,627
         self.export_from = 7                   # modeling_unimo.py:628
         self.grad_ready: Optional[Callable[[int], None]] = None      # DDP hook: gradients below this flat offset are final
+        self.taps: Optional[dict] = None                              # debugging: per-layer stream snapshots when set to a dict
 
     # ------------------------------------------------------------------ helpers
     def _lin(self, name):
@@ -95,6 +96,9 @@ class UnimoEngine:
                            type_=st.m(u + "token_type_embeddings.weight"), gamma=st.m(u + "LayerNorm.weight"), beta=st.m(u + "LayerNorm.bias"),
                            eps=self.eps_t, p_drop=p_h, seed=seed + 1, B=B, Lq=Lq, H=H, s_out=s_t, mean=tmean, rstd=trstd, out_f32=xt, out_bf16=xtb)
         sv["temb"] = (s_t, tmean, trstd)
+        if self.taps is not None:
+            self.taps["vis_emb"] = xv.view(B, Nv, H).clone()
+            self.taps["txt_emb"] = xt.view(B, Lq, H).clone()
 
         t_qkv_prev = None
         for l in range(self.n_layers):
@@ -177,6 +181,9 @@ class UnimoEngine:
                                s1=s1, m1=am1, r1=ar1, ab=ab, zt=zt, ht=ht, s2=s2, m2=om, r2=orr)
             xt, xtb = xo, xob
             t_qkv_prev = tqkv if l >= self.export_from else None
+            if self.taps is not None:
+                self.taps[f"vis{l}"] = xv.view(B, Nv, H).clone()
+                self.taps[f"txt{l}"] = xt.view(B, Lq, H).clone()
 
         # ---- MLM head transform (BertPredictionHeadTransform.forward, modeling_unimo.py:972-975)
         hp = "cls.predictions.transform."
