@@ -61,11 +61,13 @@ def build(patch: int, seed: int, device):
     return model, lit, cfg
 
 
-def cpu_baseline(patch: int, L: int, iters: int = 2):
+def cpu_baseline(patch: int, L: int, iters: int = 1):
     """The CPU oracle (port of the reference algorithm, fp32, torch CPU ops) on this box's host cores, bounded sample."""
     from mkg_analogy_amd import data_synth as D
     from oracle import mkgformer_oracle as O
-    cores = os.cpu_count() or 1
+    # intra-op threads: torch's CPU GEMMs stop scaling (and collapse under oversubscription) well before a
+    # 2-socket box's full core count at this batch size, so the baseline uses at most 32 threads and says so
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     vc = O.VisionCfg(patch_size=patch)
     tc = O.TextCfg(vocab_size=D.VOCAB)

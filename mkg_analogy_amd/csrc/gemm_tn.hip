@@ -172,7 +172,9 @@ extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
   const int tiles = ((d->NX + BNX - 1) / BNX) * ((d->NY + BNY - 1) / BNY);
   int splits = d->splits;
   const int max_splits = (d->M + 4 * BKM - 1) / (4 * BKM);        // keep >= 256 rows per split
-  if (splits <= 0) splits = (768 + tiles * batch - 1) / (tiles * batch);
+  // one workgroup per CU (256 CUs): measured best on MI355X -- a partial second round of workgroups costs more than
+  // the shorter contraction saves (profiles/: 27x9, 36x7, 9x28 splits win by 20-40 % over 3 rounds)
+  if (splits <= 0) splits = 256 / (tiles * batch);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   int rps = (d->M + splits - 1) / splits;

@@ -1,0 +1,146 @@
+"""Host-side logic that needs no GPU: parameter names / flat layout / optimizer grouping / schedule / metrics / API surface."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mkgformer_oracle as O
+
+
+def _tiny_model():
+    from mkg_analogy_amd.models import MKGformerKGC, TextConfig, VisionConfig
+    tc = TextConfig(vocab_size=100, max_position_embeddings=32)
+    return MKGformerKGC(VisionConfig(patch_size=32), tc), tc
+
+
+@pytest.fixture(scope="module")
+def model():
+    return _tiny_model()[0]
+
+
+def test_parameter_names_match_reference(model):
+    """451 tensors with the reference's names and shapes (the oracle table is pinned to the reference by G1/G4)."""
+    ref = O.param_shapes(O.VisionCfg(patch_size=32), O.TextCfg(vocab_size=100, max_position_embeddings=32))
+    got = {n: tuple(p.shape) for n, p in model.named_parameters()}
+    assert len(got) == 451
+    assert got == ref
+    assert list(got) == list(ref), "named_parameters() order differs from the reference construction order"
+    sd = model.state_dict()
+    assert "cls.predictions.decoder.weight" in sd and "cls.predictions.decoder.bias" in sd
+    assert "unimo.text_embeddings.position_ids" in sd and "unimo.vision_embeddings.position_ids" in sd
+    assert len(sd) == 455
+
+
+def test_tied_embeddings_and_resize(model):
+    m, tc = _tiny_model()
+    assert m.get_input_embeddings().weight is m.get_output_embeddings().weight
+    old = m.get_input_embeddings().weight.detach().clone()
+    b_old = m.cls.predictions.bias.detach().clone()
+    m.resize_token_embeddings(107)
+    w = m.get_input_embeddings().weight
+    assert w.shape == (107, 768) and m.get_output_embeddings().weight is w
+    assert torch.equal(w[:100], old)
+    assert m.cls.predictions.bias.shape == (107,) and torch.equal(m.cls.predictions.bias[:100], b_old)
+    assert float(m.cls.predictions.bias[100:].abs().max()) == 0.0
+    assert m.cls.predictions.decoder.bias is m.cls.predictions.bias
+    assert abs(float(w[100:].std()) - 0.02) < 0.01          # N(0, initializer_range) rows
+
+
+def test_flat_layout_covers_every_parameter_once(model):
+    from mkg_analogy_amd.params import ALIGN, DEAD, NO_DECAY, gemm_weight_names, layout_order
+    names = [n for n, _ in model.named_parameters()]
+    order = layout_order(12)
+    assert sorted(order) == sorted(names) and len(set(order)) == len(order)
+    # backward-completion order: head first, layer 11 before layer 0, tied embedding last
+    assert order[0].startswith("cls.predictions.transform")
+    assert order.index("unimo.encoder.text_layer.11.output.dense.weight") < order.index("unimo.encoder.vision_layers.11.mlp.fc1.weight") \
+        < order.index("unimo.encoder.text_layer.10.output.dense.weight") < order.index("unimo.encoder.vision_layers.0.mlp.fc1.weight")
+    assert order[-1] == "unimo.text_embeddings.word_embeddings.weight" and order[-2] == "cls.predictions.bias"
+    # every GEMM weight group is made of adjacent, alignment-preserving members
+    shapes = {n: tuple(p.shape) for n, p in model.named_parameters()}
+    for key, members in gemm_weight_names(12):
+        idx = [order.index(n) for n in members]
+        assert idx == list(range(idx[0], idx[0] + len(idx))), key
+        for n in members:
+            assert (shapes[n][0] * shapes[n][1]) % ALIGN == 0
+    # optimizer grouping quirk is the reference's substring rule
+    for n in names:
+        assert (0.0 if any(nd in n for nd in NO_DECAY) else 0.01) == O.decay_of(n)
+    assert all(n.startswith(DEAD) for n in ("unimo.text_pooler.dense.weight", "unimo.vision_post_layernorm.bias"))
+
+
+def test_linear_warmup_schedule_matches_reference_golden(golden_dir):
+    from mkg_analogy_amd.optim import LinearWarmupSchedule
+    g = np.load(os.path.join(golden_dir, "g4_adamw.npz"))
+    T = int(g["num_training_steps"])
+
+    class _Opt:
+        param_groups = [{"lr": 5e-5}, {"lr": 5e-5}]
+    opt = _Opt()
+    s = LinearWarmupSchedule(opt, num_warmup_steps=0.1 * T, num_training_steps=T)
+    lrs = []
+    for _ in range(T + 1):
+        lrs.append(opt.param_groups[0]["lr"])
+        s.step()
+    np.testing.assert_allclose(np.array(lrs) / 5e-5, g["sched_curve"], atol=1e-12)
+    np.testing.assert_allclose(lrs[:3], g["lrs"], atol=1e-15)
+    assert opt.param_groups[1]["lr"] == opt.param_groups[0]["lr"]
+
+
+def test_epoch_end_metrics_match_reference_golden(golden_dir):
+    from mkg_analogy_amd.lit_models.transformer import TransformerLitModel
+    g = np.load(os.path.join(golden_dir, "g1_tiny_e2e.npz"))
+    lit = TransformerLitModel.__new__(TransformerLitModel)
+    torch.nn.Module.__init__(lit)
+    lit.logged = {}
+    lit.validation_epoch_end([{"entity_ranks": g["ranks"]}])
+    for name, val in zip(g["metric_names"].tolist(), g["metric_vals"].tolist()):
+        assert abs(lit.logged[name] - val) < 1e-6, name
+    lit.logged = {}
+    lit.test_epoch_end([{"entity_ranks": np.array([1, 4, 11])}, {"entity_ranks": np.array([21, 2])}, {"relation_ranks": np.array([1])}])
+    assert lit.logged["Eval_entity/hits1"] == pytest.approx(0.2) and lit.logged["Eval_entity/hits10"] == pytest.approx(0.6)
+    assert lit.logged["Eval_entity/mrr"] == pytest.approx(np.mean(1.0 / np.array([1, 4, 11, 21, 2])))
+
+
+def test_trainer_surface_constructor_and_argparse():
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.lit_models import TransformerLitModel
+    from mkg_analogy_amd.models import MKGformerKGC
+    p = argparse.ArgumentParser()
+    MKGformerKGC.add_to_argparse(p)
+    TransformerLitModel.add_to_argparse(p)
+    a = p.parse_args([])
+    assert a.pretrain == 0 and a.lr == 5e-5 and a.weight_decay == 0.01 and a.label_smoothing == 0.1 and a.optimizer == "AdamW"
+    m, _ = _tiny_model()
+    tok = D.FakeTokenizer(n=100)
+    a.alpha, a.warm_up_radio = 0.43, 0.1
+    lit = TransformerLitModel(model=m, args=a, tokenizer=tok, data_config=dict(entity_id_st=10, entity_id_ed=60, relation_id_st=60,
+                                                                               relation_id_ed=100, analogy_entity_ids=[11, 12, 13],
+                                                                               analogy_relation_ids=[61, 62, 65]))
+    assert lit.entity_id_ed == 60 and lit.alpha == 0.43
+    lit._init_relation_word()                                       # CPU-side surgery only; no GPU needed until forward
+    w = m.get_input_embeddings().weight
+    assert w.shape[0] == 101
+    np.testing.assert_allclose(w[100].detach().numpy(), w[[61, 62, 65]].mean(0).detach().numpy(), atol=1e-7)
+    assert m.get_input_embeddings().weight is m.get_output_embeddings().weight
+
+
+def test_synthetic_batch_contract():
+    from mkg_analogy_amd import data_synth as D
+    b = D.make_batch(5, 64, seed=3)
+    assert b["pixel_values"].shape == (5, 2, 3, 224, 224) and b["pixel_values"].dtype == torch.float32
+    for i in range(5):
+        ids = b["input_ids"][i]
+        assert ids[0] == D.CLS and (ids == D.MASK).sum() == 1 and (ids == D.SEP).sum() == 6 and (ids == D.R_TOKEN).sum() == 2
+        n = int(b["attention_mask"][i].sum())
+        assert (ids[n:] == 0).all() and 40 <= n <= 64
+        sep = b["sep_idx"][i]
+        assert (ids[sep] == D.SEP).all() and (ids[b["rel_idx"][i]] == D.R_TOKEN).all()
+        assert D.BASE_VOCAB <= ids[b["q_head_idx"][i]] < D.BASE_VOCAB + D.N_ENT
+        assert D.BASE_VOCAB <= ids[b["a_head_idx"][i]] < D.BASE_VOCAB + D.N_ENT
+        assert (b["token_type_ids"][i][: sep[2] + 1] == 0).all() and (b["token_type_ids"][i][sep[2] + 1:n] == 1).all()
+    cfg = D.data_config()
+    assert len(cfg["analogy_entity_ids"]) == 2063 and len(set(cfg["analogy_entity_ids"])) == 2063
+    assert D.VOCAB == 42007 and D.R_TOKEN == 42006
