@@ -92,6 +92,7 @@ typedef struct {
   float* ds_f32; void* ds_bf16;
   float p_drop; uint64_t seed;
   float* dgamma; float* dbeta;
+  int bf16_total;                                                  /* 1: ds_bf16 = bf16(ds + add_f32) (no dropout mask) */
 } mart_ln_bwd_desc;
 int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream);
 
@@ -137,7 +138,7 @@ typedef struct {
   const float* w0; const float* w1;                                 /* device scalars, clamped in-kernel */
   float p_drop; uint64_t seed;
   void* ctx; int ldctx;                                             /* bf16 out [B*Sq, nh*64] */
-  float* lse;                                                       /* [B,nh,Sq] */
+  float* lse;                                                       /* [B,nh,Sq] softmax statistic, LOG2 domain: log2(sum_j 2^(s_ij*log2e)) */
 } mart_attn_fwd_desc;
 int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream);
 

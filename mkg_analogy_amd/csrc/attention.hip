@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int NTH = 256;                 // 4 waves
+constexpr float LOG2E = 1.4426950408889634f;
 constexpr int TILE_BYTES = 64 * 128;     // 64 rows x 64 bf16
 constexpr int STAGE_BYTES = 2 * TILE_BYTES + 512;   // two tiles + 2x64 floats (lse, delta)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
@@ -38,20 +39,36 @@ __device__ __forceinline__ void stage_tile(const Side& s, int b, int h, int r0, 
     glds16(side_row(s, b, h, r0 + row) + lc * 8, lds + (r * NTH + wave * 64) * 16);
   }
 }
+// Per-lane byte offsets of the fragment reads inside a 64x64 tile -- loop invariant, computed once per kernel so the
+// tile loops carry no address arithmetic (the first version spent 36 VALU instructions per MFMA, mostly on this).
+struct LaneOffs {
+  int pf[4];        // plain fragment, k-step ks: row l31 (+32 t), chunk (2ks+hh) ^ key(row); key(32t + l31) == key(l31)
+  int tr1[2], tr2[2];   // transposed fragment, dim tile dt: rows rr and rr+8 (+ base), rr = 4hh + (pp>>2)
+};
+__device__ __forceinline__ LaneOffs make_offs(int lane) {
+  LaneOffs o;
+  const int l31 = lane & 31, hh = lane >> 5, pp = lane & 15, g1 = (lane >> 4) & 1;
+  const int key = (l31 >> 1) & 7;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) o.pf[ks] = l31 * 128 + (((ks * 2 + hh) ^ key) << 4);
+  const int rr = 4 * hh + (pp >> 2), k1 = (rr >> 1) & 7;           // k1 <= 3, key(rr + 8 + 16n) == k1 ^ 4
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int col = dt * 32 + g1 * 16 + (pp & 3) * 4, lc = col >> 3, bo = (col & 7) * 2;
+    o.tr1[dt] = rr * 128 + ((lc ^ k1) << 4) + bo;
+    o.tr2[dt] = (rr + 8) * 128 + ((lc ^ k1 ^ 4) << 4) + bo;
+  }
+  return o;
+}
 // plain fragment: rows t*32 + l31, k-step ks (16 of the 64 head dims)
-__device__ __forceinline__ bf16x8 tile_frag(const char* lds, int t, int ks, int l31, int hh) {
-  const int row = t * 32 + l31, lc = ks * 2 + hh;
-  return *(const bf16x8*)(lds + row * 128 + ((lc ^ ((row >> 1) & 7)) << 4));
+__device__ __forceinline__ bf16x8 tile_frag(const char* lds, int t, int ks, const LaneOffs& o) {
+  return *(const bf16x8*)(lds + t * 4096 + o.pf[ks]);
 }
 // transposed fragment for the second GEMM: A[i = dim dt*32 + l31][k = 8 streamed rows]; k order matches the
-// register order of an MFMA result tile: e<4 -> row base+4hh+e, e>=4 -> row base+8+4hh+(e-4)
-__device__ __forceinline__ bf16x8 tile_frag_tr(const char* lds, int base, int dt, int lane) {
-  const int pp = lane & 15, g1 = (lane >> 4) & 1, hh = lane >> 5;
-  const int col = dt * 32 + g1 * 16 + (pp & 3) * 4;
-  const int r1 = base + 4 * hh + (pp >> 2), r2 = r1 + 8;
-  const int lc = col >> 3, bo = (col & 7) * 2;
-  s16x4 lo = lds_tr_read(lds + r1 * 128 + ((lc ^ ((r1 >> 1) & 7)) << 4) + bo);
-  s16x4 hi = lds_tr_read(lds + r2 * 128 + ((lc ^ ((r2 >> 1) & 7)) << 4) + bo);
+// register order of an MFMA result tile: e<4 -> row base+4hh+e, e>=4 -> row base+8+4hh+(e-4); base multiple of 16
+__device__ __forceinline__ bf16x8 tile_frag_tr(const char* lds, int base, int dt, const LaneOffs& o) {
+  s16x4 lo = lds_tr_read(lds + base * 128 + o.tr1[dt]);
+  s16x4 hi = lds_tr_read(lds + base * 128 + o.tr2[dt]);
   return join_tr(lo, hi);
 }
 __device__ __forceinline__ bf16x8 pack8(const float* v) {
@@ -93,6 +110,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
   const TextCtl ctl = make_ctl(p, b, p.Sk);
   const bool text = ctl.mask_row || ctl.sep >= 0 || ctl.p_drop > 0.f;
+  const LaneOffs lo = make_offs(lane);
 
   const int qi = q0 + l31;
   const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + min(qi, p.Sq - 1)) * p.ldq + h * 64;
@@ -104,6 +122,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
   float m_run = -1.0e30f, l_run = 0.f;
+  const float c2 = p.scale * LOG2E;
 
   const int ntiles = (Stot + 63) / 64;
   stage_tile(K, b, h, 0, smem, tid, wave);
@@ -124,45 +143,67 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st[t] = mfma32(tile_frag(sK, t, ks, l31, hh), qf[ks], st[t]);
+      for (int ks = 0; ks < 4; ++ks) st[t] = mfma32(tile_frag(sK, t, ks, lo), qf[ks], st[t]);
     }
+    // online softmax in the log2 domain: m_run, the saved statistic and every exponent are base-2 (one v_exp_f32 each)
     float pv[2][16];
-    float mx = -1.0e30f;
+    float rs = 0.f, alpha;
+    if (!text && kt * 64 + 64 <= Stot) {              // fast path (vision, full tile): 4 VALU per score
+      float mx = st[0][0];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
-        float s = st[t][r] * p.scale;
-        if (text) {
-          s *= reweight(ctl, qi, kj);
-          if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx * c2);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -m_new));
+          rs += e;
+          pv[t][r] = e;
         }
-        if (kj >= Stot) s = -1.0e30f;
-        pv[t][r] = s;
-        mx = fmaxf(mx, s);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
-    float rs = 0.f;
+      m_run = m_new;
+    } else {
+      float mx = -1.0e30f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __expf(pv[t][r] - m_new);
-        rs += e;
-        float used = e;
-        if (ctl.p_drop > 0.f) {
+        for (int r = 0; r < 16; ++r) {
           const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
-          const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
-          used = dropout_keep(ctl.seed, idx, ctl.p_drop) ? e * ctl.inv_keep : 0.f;
+          float s = st[t][r] * p.scale;
+          if (text) {
+            s *= reweight(ctl, qi, kj);
+            if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+          }
+          s *= LOG2E;
+          if (kj >= Stot) s = -1.0e30f;
+          pv[t][r] = s;
+          mx = fmaxf(mx, s);
         }
-        pv[t][r] = used;
-      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(pv[t][r] - m_new);
+          rs += e;
+          float used = e;
+          if (ctl.p_drop > 0.f) {
+            const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
+            const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
+            used = dropout_keep(ctl.seed, idx, ctl.p_drop) ? e * ctl.inv_keep : 0.f;
+          }
+          pv[t][r] = used;
+        }
+      m_run = m_new;
+    }
     rs += __shfl_xor(rs, 32, 64);
     l_run = l_run * alpha + rs;
-    m_run = m_new;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
     // O^T[d][q] += V^T P^T
@@ -172,7 +213,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
       for (int a = 0; a < 2; ++a) {
         const bf16x8 pf = pack8(&pv[t][8 * a]);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) ot[dt] = mfma32(tile_frag_tr(sV, t * 32 + 16 * a, dt, lane), pf, ot[dt]);
+        for (int dt = 0; dt < 2; ++dt) ot[dt] = mfma32(tile_frag_tr(sV, t * 32 + 16 * a, dt, lo), pf, ot[dt]);
       }
   }
   if (qi < p.Sq) {
@@ -185,7 +226,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
         f32x4 v = {ot[dt][4 * qd] * inv, ot[dt][4 * qd + 1] * inv, ot[dt][4 * qd + 2] * inv, ot[dt][4 * qd + 3] * inv};
         *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
       }
-    if (hh == 0 && p.lse) p.lse[((long long)b * p.nh + h) * p.Sq + qi] = m_run + __logf(l_run);
+    if (hh == 0 && p.lse) p.lse[((long long)b * p.nh + h) * p.Sq + qi] = m_run + __builtin_amdgcn_logf(l_run);   // log2-domain LSE
   }
 }
 
@@ -224,6 +265,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
   const TextCtl ctl = make_ctl(p, b, p.Sk);
   const bool text = ctl.mask_row || ctl.sep >= 0 || ctl.p_drop > 0.f;
+  const LaneOffs lo = make_offs(lane);
 
   const int qi = q0 + l31, qc = min(qi, p.Sq - 1);
   const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + qc) * p.ldq + h * 64;
@@ -235,8 +277,9 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
     gf[ks] = *(const bf16x8*)(gp + ks * 16 + hh * 8);
   }
   const long long li = ((long long)b * p.nh + h) * p.Sq + qc;
-  const float lse = p.lse[li], delta = pb.delta[li];
+  const float lse = p.lse[li], delta = pb.delta[li];   // lse is the log2-domain statistic saved by the forward pass
   const bool qvalid = qi < p.Sq;
+  const float c2 = p.scale * LOG2E;
 
   f32x16 dq[2];
 #pragma unroll
@@ -262,33 +305,43 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
       for (int r = 0; r < 16; ++r) { st[t][r] = 0.f; dp[t][r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        st[t] = mfma32(tile_frag(sK, t, ks, l31, hh), qf[ks], st[t]);
-        dp[t] = mfma32(tile_frag(sV, t, ks, l31, hh), gf[ks], dp[t]);
+        st[t] = mfma32(tile_frag(sK, t, ks, lo), qf[ks], st[t]);
+        dp[t] = mfma32(tile_frag(sV, t, ks, lo), gf[ks], dp[t]);
       }
     }
-    float dsv[2][16];
+    float dsv[2][16];                                    // d/d(raw q.k) / scale  (scale applied once to the accumulators)
+    if (!text && kt * 64 + 64 <= Stot) {              // fast path: fma, exp2, sub, mul per score
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
-        const float spre = st[t][r] * p.scale;
-        float f = 1.f, s = spre;
-        if (text) {
-          f = reweight(ctl, qi, kj);
-          s *= f;
-          if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -lse));
+          dsv[t][r] = pr * (dp[t][r] - delta);
         }
-        float pr = (kj < Stot && qvalid) ? __expf(s - lse) : 0.f;
-        float dpd = dp[t][r];
-        if (ctl.p_drop > 0.f) {
-          const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
-          dpd = dropout_keep(ctl.seed, idx, ctl.p_drop) ? dpd * ctl.inv_keep : 0.f;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
+          const float spre = st[t][r] * p.scale;
+          float f = 1.f, s = spre;
+          if (text) {
+            f = reweight(ctl, qi, kj);
+            s *= f;
+            if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+          }
+          float pr = (kj < Stot && qvalid) ? __builtin_amdgcn_exp2f(s * LOG2E - lse) : 0.f;
+          float dpd = dp[t][r];
+          if (ctl.p_drop > 0.f) {
+            const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
+            dpd = dropout_keep(ctl.seed, idx, ctl.p_drop) ? dpd * ctl.inv_keep : 0.f;
+          }
+          const float ds = pr * (dpd - delta);           // d/d(post-reweight, pre-mask score)
+          if (ctl.sep >= 0 && kj >= ctl.sep) { if (qi < ctl.sep) dc0 += ds * spre; else dc1 += ds * spre; }
+          dsv[t][r] = ds * f;
         }
-        const float ds = pr * (dpd - delta);           // d/d(post-reweight, pre-mask score)
-        if (ctl.sep >= 0 && kj >= ctl.sep) { if (qi < ctl.sep) dc0 += ds * spre; else dc1 += ds * spre; }
-        dsv[t][r] = ds * f * p.scale;                  // d/d(raw q.k)
-      }
+    }
     // dQ^T[d][q] += K^T dS^T
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -296,7 +349,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
       for (int a = 0; a < 2; ++a) {
         const bf16x8 df = pack8(&dsv[t][8 * a]);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tile_frag_tr(sK, t * 32 + 16 * a, dt, lane), df, dq[dt]);
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tile_frag_tr(sK, t * 32 + 16 * a, dt, lo), df, dq[dt]);
       }
   }
   if (qvalid) {
@@ -305,7 +358,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        f32x4 v = {dq[dt][4 * qd], dq[dt][4 * qd + 1], dq[dt][4 * qd + 2], dq[dt][4 * qd + 3]};
+        f32x4 v = {dq[dt][4 * qd] * p.scale, dq[dt][4 * qd + 1] * p.scale, dq[dt][4 * qd + 2] * p.scale, dq[dt][4 * qd + 3] * p.scale};
         *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
       }
   }
@@ -334,6 +387,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
   const Side G{(const bf16*)pb.dctx, pb.lddctx, p.Sq, nullptr, 0, 0};
   const TextCtl ctl = make_ctl(p, b, p.Sk);
   const bool text = ctl.mask_row || ctl.sep >= 0 || ctl.p_drop > 0.f;
+  const LaneOffs lo = make_offs(lane);
 
   const int kj = k0 + l31;
   const bool kvalid = kj < Stot;
@@ -346,6 +400,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
     vf[ks] = *(const bf16x8*)(vp + ks * 16 + hh * 8);
   }
   const float maskadd = (ctl.mask_row && kvalid) ? (1.0f - (float)ctl.mask_row[kj]) * -10000.0f : 0.f;
+  const float c2 = p.scale * LOG2E;
 
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -384,28 +439,45 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
       for (int r = 0; r < 16; ++r) { st[t][r] = 0.f; dp[t][r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        st[t] = mfma32(tile_frag(sQ, t, ks, l31, hh), kf[ks], st[t]);
-        dp[t] = mfma32(tile_frag(sG, t, ks, l31, hh), vf[ks], dp[t]);
+        st[t] = mfma32(tile_frag(sQ, t, ks, lo), kf[ks], st[t]);
+        dp[t] = mfma32(tile_frag(sG, t, ks, lo), vf[ks], dp[t]);
       }
     }
-    float pd[2][16], dsv[2][16];
+    float pd[2][16], dsv[2][16];                         // dsv = dS / scale (scale applied once to dK at the end)
+    if (!text && qt * 64 + 64 <= p.Sq) {              // fast path: whole q tile valid, vision mode
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ql = t * 32 + mfma_row(r, hh);
-        const int qi = qt * 64 + ql;
-        float f = 1.f, s = st[t][r] * p.scale;
-        if (text) { f = reweight(ctl, qi, kj); s = s * f + maskadd; }
-        const float pr = (kvalid && qi < p.Sq) ? __expf(s - sLse[ql]) : 0.f;
-        float keep = 1.f;
-        if (ctl.p_drop > 0.f) {
-          const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
-          keep = dropout_keep(ctl.seed, idx, ctl.p_drop) ? ctl.inv_keep : 0.f;
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x4 l4 = *(const f32x4*)(sLse + t * 32 + 8 * qd + 4 * hh);   // rows 4qd..4qd+3 of this lane-half
+          const f32x4 d4 = *(const f32x4*)(sDel + t * 32 + 8 * qd + 4 * hh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qd + e;
+            const float pr = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -l4[e]));
+            pd[t][r] = pr;
+            dsv[t][r] = pr * (dp[t][r] - d4[e]);
+          }
         }
-        pd[t][r] = pr * keep;
-        dsv[t][r] = pr * (dp[t][r] * keep - sDel[ql]) * f * p.scale;
-      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ql = t * 32 + mfma_row(r, hh);
+          const int qi = qt * 64 + ql;
+          float f = 1.f, s = st[t][r] * p.scale;
+          if (text) { f = reweight(ctl, qi, kj); s = s * f + maskadd; }
+          const float pr = (kvalid && qi < p.Sq) ? __builtin_amdgcn_exp2f(s * LOG2E - sLse[ql]) : 0.f;
+          float keep = 1.f;
+          if (ctl.p_drop > 0.f) {
+            const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
+            keep = dropout_keep(ctl.seed, idx, ctl.p_drop) ? ctl.inv_keep : 0.f;
+          }
+          pd[t][r] = pr * keep;
+          dsv[t][r] = pr * (dp[t][r] * keep - sDel[ql]) * f;
+        }
+    }
     // dV^T[d][key] += dO^T Pd ; dK^T[d][key] += Q^T dS
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -415,8 +487,8 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
         const bf16x8 df = pack8(&dsv[t][8 * a]);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = mfma32(tile_frag_tr(sG, t * 32 + 16 * a, dt, lane), pf, dv[dt]);
-          dk[dt] = mfma32(tile_frag_tr(sQ, t * 32 + 16 * a, dt, lane), df, dk[dt]);
+          dv[dt] = mfma32(tile_frag_tr(sG, t * 32 + 16 * a, dt, lo), pf, dv[dt]);
+          dk[dt] = mfma32(tile_frag_tr(sQ, t * 32 + 16 * a, dt, lo), df, dk[dt]);
         }
       }
   }
@@ -435,7 +507,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const int off = dt * 32 + 8 * qd + 4 * hh;
-      f32x4 a = {dk[dt][4 * qd], dk[dt][4 * qd + 1], dk[dt][4 * qd + 2], dk[dt][4 * qd + 3]};
+      f32x4 a = {dk[dt][4 * qd] * p.scale, dk[dt][4 * qd + 1] * p.scale, dk[dt][4 * qd + 2] * p.scale, dk[dt][4 * qd + 3] * p.scale};
       f32x4 c = {dv[dt][4 * qd], dv[dt][4 * qd + 1], dv[dt][4 * qd + 2], dv[dt][4 * qd + 3]};
       if (acc) { a += bf4_to_f4(*(const bf16x4*)(okp + off)); c += bf4_to_f4(*(const bf16x4*)(ovp + off)); }
       *(bf16x4*)(okp + off) = f4_to_bf4(a);

@@ -30,6 +30,7 @@ struct Args {
   float alpha;
   void* C; int ldc; int c_f32;
   bf16* C2; int ldc2;
+  int dbg;                           // 1: skip the LDS-DMA after the first tile (timing experiment only)
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -105,6 +106,64 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
   for (int j = 0; j < TN; ++j) rowB[j] = wn0 + j * 32 + l31;
 
+  if constexpr (WAVES_M == 2 && WAVES_N == 4) {
+    // ---- ping-pong main loop (8 waves).  The two wave-rows of the tile (waves 0-3 / 4-7; waves w and w+4 share a
+    // SIMD) run the same 4-phase K-tile sequence  R0 | M0 | R1 | M1  (R = fragment reads of two k-steps (+ LDS-DMA
+    // of the next tile in R0), M = 32 MFMAs), every phase ending in s_barrier -- but the lower wave-row executes ONE
+    // extra barrier up front, so it always runs one phase behind: while one wave of a SIMD issues MFMAs the other
+    // one reads LDS / issues DMA, and the matrix pipe never waits for fragment reads.
+    //   RAW: a wave waits vmcnt(0) for its own DMA at the end of R1(t); every wave passes >= 1 further barrier
+    //        before anyone reads tile t+1.
+    //   WAR: DMA for tile t+1 (buffer of tile t-1) is issued in R0(t), after a barrier that every wave passed with
+    //        lgkmcnt(0) behind its last read of tile t-1.
+    const int grp = wave >> 2;
+    bf16x8 af[2][TM], bfr[2][TN];
+    auto read2 = [&](const char* sA_, const char* sB_, int ks0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int lc = (ks0 + u) * 2 + h;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[u][i] = *(const bf16x8*)(sA_ + rowA[i] * 128 + ((lc ^ ((rowA[i] >> 1) & 7)) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[u][j] = *(const bf16x8*)(sB_ + rowB[j] * 128 + ((lc ^ ((rowB[j] >> 1) & 7)) << 4));
+      }
+    };
+    auto mma2 = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[u][j], af[u][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto phase_end = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // one-phase lag of the lower wave-row
+    for (int t = 0; t < nk; ++t) {
+      const char* sA = smem + (t & 1) * STAGE;
+      const char* sB = sA + A_BYTES;
+      read2(sA, sB, 0);                                   // R0
+      if (t + 1 < nk && !p.dbg) stage(t + 1, (t + 1) & 1);
+      phase_end();
+      mma2();                                             // M0
+      phase_end();
+      read2(sA, sB, 2);                                   // R1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      phase_end();
+      mma2();                                             // M1
+      phase_end();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // balance the barrier count
+  } else {
   stage(0, 0);
   for (int t = 0; t < nk; ++t) {
     __syncthreads();                    // tile t landed (vmcnt(0) per wave, then barrier); buffer (t+1)&1 is free
@@ -126,6 +185,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[j], af[i], acc[i][j]);   // D[n][m]: lane = row m
     }
+  }
   }
 
   // ---------------- epilogue: lane owns row m, 4 consecutive n per register quad
@@ -297,6 +357,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
   int cfg = d->tile_cfg;
+  a.dbg = 0;
+  if (cfg == 999) { a.dbg = 1; cfg = 256; }
   if (cfg == 0) cfg = (t256 >= 224) ? 256 : 128;
   if (cfg == 256) return launch<256, 256, 2, 4>(a, batch, st);
   return launch<128, 128, 2, 2>(a, batch, st);

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
         f32x4 ds;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ds[e] = rstd * (dy[v][e] * gam[v][e] - c1 - xh[v][e] * c2);
-        if (p.ds_bf16) {
+        if (p.ds_bf16 && !p.bf16_total) {
           f32x4 dd = ds;
           if (p.p_drop > 0.f) {
 #pragma unroll
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
         }
         if (p.add_f32) ds += *(const f32x4*)(p.add_f32 + o);
         if (p.ds_f32) *(f32x4*)(p.ds_f32 + o) = ds;
+        if (p.ds_bf16 && p.bf16_total) *(bf16x4*)((bf16*)p.ds_bf16 + o) = f4_to_bf4(ds);
       }
   }
   if (!p.dgamma && !p.dbeta) return;

@@ -279,7 +279,8 @@ class UnimoEngine:
             # ================= vision layer l
             v = f"unimo.encoder.vision_layers.{l}."
             s = sv[f"v{l}"]
-            ops.add_f32_bf16(dxv, None, None, dxvb)                    # bf16 copy of the (possibly fusion-updated) stream gradient
+            if l >= self.fuse_from or l == self.n_layers - 1:          # fusion of text layer l just added d(vis) into dxv
+                ops.add_f32_bf16(dxv, None, None, dxvb)                # -> refresh the bf16 copy (otherwise ln1 bwd wrote it)
             self._wgrad(dxvb, s["f"], v + "mlp.fc2.weight", v + "mlp.fc2.bias")
             dz = _e((Mv, I), BF, dev)
             ops.gemm_nt(dxvb, st.wt(f"v{l}.fc2"), dz, mulz=s["z"], mul_act=ops.ACT_QGELU)
@@ -289,8 +290,7 @@ class UnimoEngine:
             del dz
             dx1, dx1b = _e((Mv, H), F32, dev), _e((Mv, H), BF, dev)
             ops.ln_bwd(dy_bf16=dh2, s=s["x1"], mean=s["m2"], rstd=s["r2"], gamma=st.m(v + "layer_norm2.weight"), M=Mv, H=H, add_f32=dxv,
-                       ds_f32=dx1, dgamma=st.g(v + "layer_norm2.weight"), dbeta=st.g(v + "layer_norm2.bias"))
-            ops.add_f32_bf16(dx1, None, None, dx1b)
+                       ds_f32=dx1, ds_bf16=dx1b, bf16_total=True, dgamma=st.g(v + "layer_norm2.weight"), dbeta=st.g(v + "layer_norm2.bias"))
             self._wgrad(dx1b, s["ctx"], v + "self_attn.out_proj.weight", v + "self_attn.out_proj.bias")
             dctx = dh2                                                 # reuse
             ops.gemm_nt(dx1b, st.wt(f"v{l}.o"), dctx)
@@ -313,7 +313,7 @@ class UnimoEngine:
             ops.gemm_nt(dqkv, st.wt(f"v{l}.qkv"), dh1)
             del dqkv
             ops.ln_bwd(dy_bf16=dh1, s=s["x"], mean=s["m1"], rstd=s["r1"], gamma=st.m(v + "layer_norm1.weight"), M=Mv, H=H, add_f32=dx1,
-                       ds_f32=dxv, dgamma=st.g(v + "layer_norm1.weight"), dbeta=st.g(v + "layer_norm1.bias"))
+                       ds_f32=dxv, ds_bf16=dxvb, bf16_total=True, dgamma=st.g(v + "layer_norm1.weight"), dbeta=st.g(v + "layer_norm1.bias"))
             sv[f"v{l}"] = None
             sv[f"t{l}"] = None
             if l > 0:
