@@ -13,6 +13,9 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmart_hip.so")
 SOURCES = ["util.hip", "gemm_nt.hip", "gemm_tn.hip", "norm_embed.hip", "attention.hip", "head_optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# per-file extras: attention keeps MFMA results in arch VGPRs (the softmax consumes them with VALU right away; the
+# default AGPR form cost ~150 v_accvgpr moves per 16 MFMAs)
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result", "-Wno-pass-failed"]
 
@@ -38,7 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

@@ -154,9 +154,15 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx * c2);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
+      // deferred rescale: while no row's maximum grew by more than 2^8 keep the old reference maximum (probabilities then
+      // reach at most 256, harmless in bf16/f32) and skip the O-wide rescale; decided per wave, before any P is formed
+      float m_new = m_run;
+      alpha = 1.f;
+      if (!__all(mx - m_run <= 8.0f)) {
+        m_new = fmaxf(m_run, mx);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -204,8 +210,10 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
     }
     rs += __shfl_xor(rs, 32, 64);
     l_run = l_run * alpha + rs;
+    if (!__all(alpha == 1.f)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+      for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+    }
     // O^T[d][q] += V^T P^T
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
 }
 
 // =========================================================================== backward, dK/dV pass (owner = keys)
-__global__ __launch_bounds__(NTH) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
+__global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mart_attn_fwd_desc& p = pb.f;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -443,48 +451,48 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
         dp[t] = mfma32(tile_frag(sG, t, ks, lo), vf[ks], dp[t]);
       }
     }
-    float pd[2][16], dsv[2][16];                         // dsv = dS / scale (scale applied once to dK at the end)
-    if (!text && qt * 64 + 64 <= p.Sq) {              // fast path: whole q tile valid, vision mode
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const f32x4 l4 = *(const f32x4*)(sLse + t * 32 + 8 * qd + 4 * hh);   // rows 4qd..4qd+3 of this lane-half
-          const f32x4 d4 = *(const f32x4*)(sDel + t * 32 + 8 * qd + 4 * hh);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * qd + e;
-            const float pr = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -l4[e]));
-            pd[t][r] = pr;
-            dsv[t][r] = pr * (dp[t][r] - d4[e]);
-          }
-        }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ql = t * 32 + mfma_row(r, hh);
-          const int qi = qt * 64 + ql;
-          float f = 1.f, s = st[t][r] * p.scale;
-          if (text) { f = reweight(ctl, qi, kj); s = s * f + maskadd; }
-          const float pr = (kvalid && qi < p.Sq) ? __builtin_amdgcn_exp2f(s * LOG2E - sLse[ql]) : 0.f;
-          float keep = 1.f;
-          if (ctl.p_drop > 0.f) {
-            const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
-            keep = dropout_keep(ctl.seed, idx, ctl.p_drop) ? ctl.inv_keep : 0.f;
-          }
-          pd[t][r] = pr * keep;
-          dsv[t][r] = pr * (dp[t][r] * keep - sDel[ql]) * f;
-        }
-    }
-    // dV^T[d][key] += dO^T Pd ; dK^T[d][key] += Q^T dS
+    // dV^T[d][key] += dO^T Pd ; dK^T[d][key] += Q^T dS, eight q rows (one MFMA k-slice) at a time so the probabilities
+    // live only as packed bf16 (dS carries no `scale`: it is applied once to dK at the end)
+    const bool fast = !text && qt * 64 + 64 <= p.Sq;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const bf16x8 pf = pack8(&pd[t][8 * a]);
-        const bf16x8 df = pack8(&dsv[t][8 * a]);
+        float pd8[8], ds8[8];
+        if (fast) {
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) {
+            const int qd = 2 * a + q2;
+            const f32x4 l4 = *(const f32x4*)(sLse + t * 32 + 8 * qd + 4 * hh);   // rows 4qd..4qd+3 of this lane-half
+            const f32x4 d4 = *(const f32x4*)(sDel + t * 32 + 8 * qd + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * qd + e;
+              const float pr = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -l4[e]));
+              pd8[4 * q2 + e] = pr;
+              ds8[4 * q2 + e] = pr * (dp[t][r] - d4[e]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int r = 8 * a + i;
+            const int ql = t * 32 + mfma_row(r, hh);
+            const int qi = qt * 64 + ql;
+            float f = 1.f, sc = st[t][r] * p.scale;
+            if (text) { f = reweight(ctl, qi, kj); sc = sc * f + maskadd; }
+            const float pr = (kvalid && qi < p.Sq) ? __builtin_amdgcn_exp2f(sc * LOG2E - sLse[ql]) : 0.f;
+            float keep = 1.f;
+            if (ctl.p_drop > 0.f) {
+              const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
+              keep = dropout_keep(ctl.seed, idx, ctl.p_drop) ? ctl.inv_keep : 0.f;
+            }
+            pd8[i] = pr * keep;
+            ds8[i] = pr * (dp[t][r] * keep - sDel[ql]) * f;
+          }
+        }
+        const bf16x8 pf = pack8(pd8);
+        const bf16x8 df = pack8(ds8);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           dv[dt] = mfma32(tile_frag_tr(sG, t * 32 + 16 * a, dt, lo), pf, dv[dt]);

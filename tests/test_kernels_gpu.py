@@ -264,6 +264,39 @@ def test_attention_vision(ops, B, nh, S, Lp):
         close(dt[:, 2 * H:], pvr.grad, 2e-2 * max(float(pvr.grad.abs().max()), 1), 3e-2, "dpv")
 
 
+def test_attention_rescale_branch(ops):
+    """Online softmax with a deferred rescale: spike some keys in LATE tiles so the running maximum jumps by far more
+    than the 2^8 threshold after probabilities were already accumulated (the branch is rare on random data)."""
+    B, nh, S, H = 2, 4, 393, 256
+    qkv = rnd(B * S, 3 * H, seed=1, scale=1.0)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    kk = k.clone().view(B, S, H)
+    qq = q.view(B, S, H)
+    kk[0, 300] = (qq[0, 5].float() * 3.0).to(BF)         # row 5 of batch 0: score ~ 3|q|^2/8 at key 300 (tile 4)
+    kk[1, 200] = (qq[1, 100].float() * 2.0).to(BF)       # another wave / tile
+    kk[1, 390] = (qq[1, 101].float() * 4.0).to(BF)       # last (partial) tile
+    k = kk.view(B * S, H)
+    ctx = torch.zeros(B * S, H, device=DEV, dtype=BF)
+    lse = torch.empty(B, nh, S, device=DEV)
+    kw = dict(q=q, k=k, v=v, ctx=ctx, lse=lse, B=B, nh=nh, Sq=S, Sk=S, scale=0.125)
+    ops.attn_fwd(**kw)
+    qr, kr, vr = [t.float().clone().requires_grad_(True) for t in (q, k, v)]
+    o = _attn_ref(_heads(qr, B, S, nh), _heads(kr, B, S, nh), _heads(vr, B, S, nh), 0.125)
+    oref = o.permute(0, 2, 1, 3).reshape(B * S, H)
+    close(ctx, oref, 2e-2, 2e-2, "attn fwd with forced rescale")
+    s = torch.einsum("bhqd,bhkd->bhqk", _heads(qr, B, S, nh), _heads(kr, B, S, nh)) * 0.125
+    assert float(s.max()) > 20.0
+    close(lse * math.log(2.0), torch.logsumexp(s, -1), 2e-3, 1e-3, "lse with forced rescale")
+    dctx = rnd(B * S, H, seed=3)
+    oref.backward(dctx.float())
+    dqkv = torch.zeros(B * S, 3 * H, device=DEV, dtype=BF)
+    delta = torch.empty(B, nh, S, device=DEV)
+    ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:], **kw)
+    close(dqkv[:, :H], qr.grad, 2e-2 * max(float(qr.grad.abs().max()), 1), 3e-2, "dq (spiked)")
+    close(dqkv[:, H:2 * H], kr.grad, 2e-2 * max(float(kr.grad.abs().max()), 1), 3e-2, "dk (spiked)")
+    close(dqkv[:, 2 * H:], vr.grad, 2e-2 * max(float(vr.grad.abs().max()), 1), 3e-2, "dv (spiked)")
+
+
 @pytest.mark.parametrize("B,nh,L,p", [(3, 12, 64, 0.0), (2, 12, 64, 0.1), (2, 4, 24, 0.0), (2, 2, 96, 0.1)])
 def test_attention_text(ops, B, nh, L, p):
     H = nh * 64
