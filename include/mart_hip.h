@@ -100,6 +100,12 @@ int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream);
  * pixels f32 [B,2,3,S,S] -> bf16 patch matrix [B*2*P, 3*p*p] (k = c*p*p + ky*p + kx): the im2col-free
  * operand of the bias-free patch conv, modeling_unimo.py:110-112,123-124. */
 int mart_patchify(const float* pixels, void* out_bf16, int B, int S, int p, void* stream);
+/* Device-side batch assembly (DataCollatorForSeq2Seq.__call__, MarT/data/data_module.py:126-142,161): the per-entity
+ * image table [N_img,3,S,S] stays resident in HBM; index[b*2+slot] picks the row, < 0 = the all-zero image of a missing
+ * slot.  Produces the same patch matrix as mart_patchify on the stacked pixel_values, without materialising them. */
+int mart_patchify_gather(const float* table, const int32_t* index, void* out_bf16, int B, int S, int p, void* stream);
+/* the stacked tensor itself, for callers that want pixel_values [B,2,3,S,S] */
+int mart_gather_images(const float* table, const int32_t* index, float* out, int B, int S, void* stream);
 /* s[b,t,:] = [cls | patch(b,0,:) | patch(b,1,:)] + pos[0,1..P,1..P]   (modeling_unimo.py:127-130) */
 int mart_vision_assemble(const void* patch_bf16, const float* cls, const float* pos, float* s, int B, int P, int H, void* stream);
 /* backward of the assemble: dpatch (bf16) and atomically accumulated dcls, dpos */

@@ -79,6 +79,8 @@ _SIGS = {
     "mart_ln_fwd": (i32, [C.POINTER(LnFwd), vp]),
     "mart_ln_bwd": (i32, [C.POINTER(LnBwd), vp]),
     "mart_patchify": (i32, [vp, vp, i32, i32, i32, vp]),
+    "mart_patchify_gather": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "mart_gather_images": (i32, [vp, vp, vp, i32, i32, vp]),
     "mart_vision_assemble": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "mart_vision_assemble_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
     "mart_text_embed_fwd": (i32, [C.POINTER(TextEmbed), vp]),

@@ -6,7 +6,7 @@
 namespace {
 constexpr int WPB = 4;            // waves (rows in flight) per workgroup
 constexpr int TPB = 64 * WPB;
-constexpr int VMAX = 4;           // float4 per lane cached in registers -> H <= 1024
+constexpr int VMAX_ALL = 4;       // float4 per lane cached in registers -> H <= 1024 (kernels are instantiated for 3 = H 768, and 4)
 
 inline int row_grid(int M) {
   int g = (M + WPB - 1) / WPB;
@@ -14,11 +14,12 @@ inline int row_grid(int M) {
 }
 
 // ------------------------------------------------------------------ LayerNorm forward
+template <int VMAX>
 __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * WPB + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * WPB;
-  const int nv = p.H / 256;                       // float4 per lane (H multiple of 256)
+  const int nv = p.H / 256;                       // float4 per lane (H multiple of 256), nv <= VMAX
   const float inv_keep = 1.f / (1.f - p.p_drop);
   const bf16* yb = (const bf16*)p.y_bf16;
   for (int m = wave_g; m < p.M; m += nwaves) {
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
+template <int VMAX>
 __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
   __shared__ float red[WPB][2][VMAX * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
 
 // ------------------------------------------------------------------ text embeddings (gather + LN + dropout)
 __global__ __launch_bounds__(TPB) void text_embed_k(mart_text_embed_desc p) {
+  constexpr int VMAX = VMAX_ALL;
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * WPB + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * WPB;
@@ -222,6 +225,35 @@ __global__ void patchify_k(const float* __restrict__ pix, bf16* __restrict__ out
     const int c = k4 / (p * p), rem = k4 % (p * p), ky = rem / p, kx = rem % p;   // p multiple of 4 -> 4 kx contiguous
     f32x4 v = *(const f32x4*)(src + ((long long)c * S + py * p + ky) * S + px * p + kx);
     *(bf16x4*)(out + row * K + k4) = f4_to_bf4(v);
+  }
+}
+
+__global__ void patchify_gather_k(const float* __restrict__ table, const int32_t* __restrict__ index, bf16* __restrict__ out, int B, int S, int p) {
+  const int g = S / p, P = g * g, K = 3 * p * p;
+  const long long row = blockIdx.x;                  // (b*2+slot)*P + py*g + px
+  const int patch = (int)(row % P);
+  const long long bi = row / P;
+  const int py = patch / g, px = patch % g;
+  const int src_row = index[bi];
+  const float* src = table + (long long)src_row * 3LL * S * S;
+  for (int k4 = threadIdx.x * 4; k4 < K; k4 += blockDim.x * 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (src_row >= 0) {
+      const int c = k4 / (p * p), rem = k4 % (p * p), ky = rem / p, kx = rem % p;
+      v = *(const f32x4*)(src + ((long long)c * S + py * p + ky) * S + px * p + kx);
+    }
+    *(bf16x4*)(out + row * K + k4) = f4_to_bf4(v);
+  }
+}
+__global__ void gather_images_k(const float* __restrict__ table, const int32_t* __restrict__ index, float* __restrict__ out, long long per) {
+  const long long slot = blockIdx.y;
+  const int src_row = index[slot];
+  const float* src = table + (long long)src_row * per;
+  float* dst = out + slot * per;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < per; i += (long long)gridDim.x * blockDim.x * 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (src_row >= 0) v = *(const f32x4*)(src + i);
+    *(f32x4*)(dst + i) = v;
   }
 }
 
@@ -336,26 +368,28 @@ __global__ void transpose_table_k(const bf16* __restrict__ src, bf16* __restrict
 
 extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
   MART_CHECK(d && (d->x_f32 || d->y_bf16), "ln_fwd: need x_f32 or y_bf16");
-  MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX, "ln_fwd: H must be a multiple of 256 and <= 1024");
+  MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_fwd: H must be a multiple of 256 and <= 1024");
   MART_CHECK(d->gamma && d->beta && d->mean && d->rstd && (d->out_f32 || d->out_bf16), "ln_fwd: null pointer");
   MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "ln_fwd: bad dropout p");
-  hipLaunchKernelGGL(ln_fwd_k, dim3(row_grid(d->M)), dim3(TPB), 0, (hipStream_t)stream, *d);
+  if (d->H <= 768) hipLaunchKernelGGL(ln_fwd_k<3>, dim3(row_grid(d->M)), dim3(TPB), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(ln_fwd_k<4>, dim3(row_grid(d->M)), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   MART_CHECK(d && (d->dy_f32 || d->dy_bf16), "ln_bwd: need dy_f32 or dy_bf16");
-  MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX, "ln_bwd: H must be a multiple of 256 and <= 1024");
+  MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_bwd: H must be a multiple of 256 and <= 1024");
   MART_CHECK(d->s && d->mean && d->rstd && d->gamma && (d->ds_f32 || d->ds_bf16), "ln_bwd: null pointer");
   int g = row_grid(d->M);
-  if (g > 1024) g = 1024;
-  hipLaunchKernelGGL(ln_bwd_k, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
+  if (g > 2048) g = 2048;
+  if (d->H <= 768) hipLaunchKernelGGL(ln_bwd_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(ln_bwd_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int mart_text_embed_fwd(const mart_text_embed_desc* d, void* stream) {
   MART_CHECK(d && d->ids && d->tt && d->word && d->pos && d->type && d->gamma && d->beta, "text_embed: null pointer");
-  MART_CHECK(d->B > 0 && d->L > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX, "text_embed: bad shape");
+  MART_CHECK(d->B > 0 && d->L > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "text_embed: bad shape");
   MART_CHECK(d->mean && d->rstd && (d->out_f32 || d->out_bf16), "text_embed: null output");
   hipLaunchKernelGGL(text_embed_k, dim3(row_grid(d->B * d->L)), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
@@ -372,6 +406,19 @@ extern "C" int mart_patchify(const float* pixels, void* out_bf16, int B, int S, 
   MART_CHECK(pixels && out_bf16 && B > 0 && S > 0 && p > 0 && S % p == 0 && p % 4 == 0, "patchify: bad args");
   const int g = S / p;
   hipLaunchKernelGGL(patchify_k, dim3(B * 2 * g * g), dim3(192), 0, (hipStream_t)stream, pixels, (bf16*)out_bf16, B, S, p);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_patchify_gather(const float* table, const int32_t* index, void* out_bf16, int B, int S, int p, void* stream) {
+  MART_CHECK(table && index && out_bf16 && B > 0 && S > 0 && p > 0 && S % p == 0 && p % 4 == 0, "patchify_gather: bad args");
+  const int g = S / p;
+  hipLaunchKernelGGL(patchify_gather_k, dim3(B * 2 * g * g), dim3(192), 0, (hipStream_t)stream, table, index, (bf16*)out_bf16, B, S, p);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_gather_images(const float* table, const int32_t* index, float* out, int B, int S, void* stream) {
+  MART_CHECK(table && index && out && B > 0 && S > 0 && (S * S * 3) % 4 == 0, "gather_images: bad args");
+  hipLaunchKernelGGL(gather_images_k, dim3(64, B * 2), dim3(256), 0, (hipStream_t)stream, table, index, out, 3LL * S * S);
   MART_LAUNCH_CHECK();
   return 0;
 }

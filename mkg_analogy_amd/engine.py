@@ -57,7 +57,8 @@ class UnimoEngine:
         ops.gemm_tn(X, Y, g.view(g.shape[0], -1), NX=NX, colsum=self.st.g(bname) if bname else None)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train: bool, seed: int):
+    def forward(self, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train: bool, seed: int,
+                image_table=None, image_index=None):
         st, H, nh, I = self.st, self.H, self.nh, self.I
         dev = input_ids.device
         B, Lq = input_ids.shape
@@ -72,11 +73,16 @@ class UnimoEngine:
         p_a = self.p_attn if train else 0.0
 
         # ---- vision embeddings: patchify -> GEMM -> assemble(+cls,+pos) -> pre-LN    (modeling_unimo.py:119-132,711)
-        pix = pixel_values.contiguous()
-        assert pix.dtype == F32 and tuple(pix.shape) == (B, 2, 3, S, S), "pixel_values must be f32 [B,2,3,S,S]"
         Kp = 3 * p * p
         patches = _e((B * 2 * P, Kp), BF, dev)
-        ops.patchify(pix, patches, B, S, p)
+        if image_index is not None:                   # device-side batch assembly: gather straight from the resident image table
+            assert image_table is not None and image_table.dtype == F32 and tuple(image_table.shape[1:]) == (3, S, S)
+            assert image_index.dtype == torch.int32 and tuple(image_index.shape) == (B, 2)
+            ops.patchify_gather(image_table, image_index.contiguous(), patches, B, S, p)
+        else:
+            pix = pixel_values.contiguous()
+            assert pix.dtype == F32 and tuple(pix.shape) == (B, 2, 3, S, S), "pixel_values must be f32 [B,2,3,S,S]"
+            ops.patchify(pix, patches, B, S, p)
         pe = _e((B * 2 * P, H), BF, dev)
         ops.gemm_nt(patches, st.w("unimo.vision_embeddings.patch_embedding.weight").view(H, Kp), pe)
         s_v = _e((Mv, H), F32, dev)

@@ -19,8 +19,10 @@ class _MKGformerFn(torch.autograd.Function):
     """trans_hidden_states = head_transform(encoder(...)).  UnimoForMaskedLM.forward, modeling_unimo.py:848-893."""
 
     @staticmethod
-    def forward(ctx, anchor, engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder):
-        trans, transb, sv = engine.forward(input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed)
+    def forward(ctx, anchor, engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
+                image_table=None, image_index=None):
+        trans, transb, sv = engine.forward(input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed,
+                                           image_table=image_table, image_index=image_index)
         ctx.engine, ctx.sv = engine, sv
         holder["trans_bf16"] = transb
         return trans
@@ -31,7 +33,7 @@ class _MKGformerFn(torch.autograd.Function):
         if sv is None:
             raise RuntimeError("MKGformer backward called twice (activations are freed after the first pass)")
         ctx.engine.backward(sv, dtrans)
-        return (None,) * 10
+        return (None,) * 12
 
 
 class _ScoreFn(torch.autograd.Function):

@@ -186,6 +186,7 @@ class UnimoForMaskedLM(nn.Module):
         self._store: Optional[FlatStore] = None
         self._engine: Optional[UnimoEngine] = None
         self._step = 0
+        self.image_table = None                     # optional resident [N_img,3,S,S] f32 table for device-side batch assembly
         self.base_seed = 0x5EED
         self.tie_weights()
 
@@ -262,13 +263,19 @@ class UnimoForMaskedLM(nn.Module):
             self._store.refresh_shadows()
         return r
 
+    def set_image_table(self, table: torch.Tensor):
+        """Keep the per-entity pixel tensor (MarT/tools/encode_images_data.py output, data_module.py:209) resident in HBM so
+        that batches carry [B,2] row indices instead of 1.2 MB of pixels per example."""
+        st = self.finalize()
+        self.image_table = table.to(st.device, torch.float32).contiguous()
+
     def sync_shadows(self):
         """Call after editing parameters in place (e.g. _init_relation_word) so the bf16 GEMM operands follow."""
         self.finalize().refresh_shadows()
 
     # ------------------------------------------------------------------ forward (modeling_unimo.py:848-893)
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None, sep_idx=None,
-                pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None, labels=None):
+                pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None, labels=None, image_index=None):
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention maps / per-layer hidden states are not materialised by the fused HIP path")
         if position_ids is not None or head_mask is not None:
@@ -281,12 +288,20 @@ class UnimoForMaskedLM(nn.Module):
         token_type_ids = torch.zeros((B, L), device=dev, dtype=torch.int64) if token_type_ids is None else token_type_ids.to(dev, torch.int64).contiguous()
         if sep_idx is not None:
             sep_idx = sep_idx.to(dev, torch.int64).contiguous()
-        pixel_values = pixel_values.to(dev, torch.float32)
+        image_table = None
+        if image_index is not None:                 # device-side batch assembly (mkg_analogy_amd.batching.DeviceImageTable)
+            if self.image_table is None:
+                raise ValueError("image_index given but no image table attached: call model.set_image_table(table) first")
+            image_table = self.image_table
+            image_index = image_index.to(dev, torch.int32).contiguous()
+        else:
+            pixel_values = pixel_values.to(dev, torch.float32)
         train = bool(self.training)
         self._step += 1
         seed = (self.base_seed * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFF
         holder: Dict[str, torch.Tensor] = {}
-        trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder)
+        trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
+                                      image_table, image_index)
         logits = Fn.LazyLogits(trans, holder["trans_bf16"], st)
         loss = None
         if labels is not None:                      # CrossEntropyLoss over the full vocabulary (:880-882); not used by MarT

@@ -103,6 +103,14 @@ def patchify(pixels, out, B, S, p):
     L.check(L.lib().mart_patchify(_p(pixels), _p(out), B, S, p, _stream()), "mart_patchify")
 
 
+def patchify_gather(table, index, out, B, S, p):
+    L.check(L.lib().mart_patchify_gather(_p(table), _p(index), _p(out), B, S, p, _stream()), "mart_patchify_gather")
+
+
+def gather_images(table, index, out, B, S):
+    L.check(L.lib().mart_gather_images(_p(table), _p(index), _p(out), B, S, _stream()), "mart_gather_images")
+
+
 def vision_assemble(patch, cls, pos, s, B, P, H):
     L.check(L.lib().mart_vision_assemble(_p(patch), _p(cls), _p(pos), _p(s), B, P, H, _stream()), "mart_vision_assemble")
 

@@ -144,3 +144,21 @@ def test_synthetic_batch_contract():
     cfg = D.data_config()
     assert len(cfg["analogy_entity_ids"]) == 2063 and len(set(cfg["analogy_entity_ids"])) == 2063
     assert D.VOCAB == 42007 and D.R_TOKEN == 42006
+
+
+def test_device_image_table_slot_rules():
+    """Same slot selection as the reference collator (MarT/data/data_module.py:126-142), restated with explicit branches."""
+    from mkg_analogy_amd.batching import DeviceImageTable
+    ents = ["Q1", "Q2", "Q3", "Q2"]
+    t = DeviceImageTable(ents)
+    head = ["Q1", "Q3", None, None, "Q2", ""]
+    tail = ["Q2", None, "Q3", None, "", "Q1"]
+    got = t.slots(head, tail).tolist()
+    exp = []
+    for h, tl in zip(head, tail):
+        if h and tl:
+            exp.append([ents.index(h), ents.index(tl)])
+        else:
+            e = h if h is not None else tl
+            exp.append([ents.index(e) if e else -1, -1])
+    assert got == exp == [[0, 1], [2, -1], [2, -1], [-1, -1], [1, -1], [-1, -1]]

@@ -488,3 +488,23 @@ def test_adamw_and_misc(ops):
     pos, row = torch.empty(4, dtype=torch.int32, device=DEV), torch.empty(4, dtype=torch.int32, device=DEV)
     ops.find_token(ids.to(DEV), 103, pos, row)
     assert pos.tolist() == [3, 15, 0, 9] and row.tolist() == [3, 31, 32, 57]
+
+
+def test_device_side_batch_assembly(ops):
+    """patchify_gather / gather_images == stacking rows of the image table on the host (zeros for missing slots)."""
+    N, B, S, p = 7, 5, 224, 16
+    table = rnd(N, 3, S, S, seed=1, dtype=F32)
+    idx = torch.tensor([[0, 3], [6, -1], [-1, -1], [2, 2], [5, 1]], dtype=torch.int32, device=DEV)
+    pix = torch.zeros(B, 2, 3, S, S, device=DEV)
+    for b in range(B):
+        for s_ in range(2):
+            if idx[b, s_] >= 0:
+                pix[b, s_] = table[idx[b, s_]]
+    out = torch.empty_like(pix)
+    ops.gather_images(table, idx, out, B, S)
+    assert torch.equal(out, pix)
+    P = (S // p) ** 2
+    a, b_ = torch.empty(B * 2 * P, 3 * p * p, device=DEV, dtype=BF), torch.empty(B * 2 * P, 3 * p * p, device=DEV, dtype=BF)
+    ops.patchify(pix, a, B, S, p)
+    ops.patchify_gather(table, idx, b_, B, S, p)
+    assert torch.equal(a, b_)

@@ -215,3 +215,32 @@ def test_pretrain_branch():
     assert abs(float(loss) - float(loss_ref)) < 1e-2
     ev = lit._eval(dict(gb), 0)
     assert "entity_ranks" in ev or "relation_ranks" in ev
+
+
+def test_image_index_path_equals_pixel_values_path():
+    """Device-side batch assembly: indices into the resident image table give bit-identical outputs
+    to the stacked pixel_values the reference collator would have built."""
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.batching import DeviceImageTable
+    model, lit, cfg, vc = _product(32, seed=9, conditioned=True)
+    model.eval()
+    B = 4
+    batch = D.make_batch(B, 64, seed=41, device="cuda")
+    names = [f"Q{i}" for i in range(6)]
+    table = torch.randn(6, 3, 224, 224)
+    tab = DeviceImageTable(names)
+    head = ["Q1", "Q3", None, "Q5"]
+    tail = ["Q2", None, None, "Q0"]
+    idx = tab.slots(head, tail)
+    pix = torch.zeros(B, 2, 3, 224, 224)
+    for b in range(B):
+        for s in range(2):
+            if idx[b, s] >= 0:
+                pix[b, s] = table[idx[b, s]]
+    model.set_image_table(table)
+    kw = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], token_type_ids=batch["token_type_ids"],
+              sep_idx=batch["sep_idx"], return_dict=True)
+    with torch.no_grad():
+        _, t1 = model(pixel_values=pix.cuda(), **kw)
+        _, t2 = model(image_index=idx, **kw)
+    assert torch.equal(t1, t2)
