@@ -111,7 +111,12 @@ class GemmTimer:
             s.record()
             r = self.orig(A, B, out, **kw)
             e.record()
-            self.rec.append((2.0 * M * N * K * bz, s, e, M * N * bz >= 224 * 65536))
+            mn = float(M) * N * bz
+            byt = 2.0 * M * K * bz + 2.0 * N * K * (bz if kw.get("stride_b", 0) else 1) + mn * (4 if out.dtype == torch.float32 else 2)
+            for key, sz in (("preact", 2), ("mulz", 2), ("res_f32", 4), ("res_bf16", 2), ("C2", 2)):
+                if kw.get(key) is not None:
+                    byt += mn * sz
+            self.rec.append((2.0 * M * N * K * bz, s, e, M * N * bz >= 224 * 65536, byt))
             return r
         self.ops.gemm_nt = timed
         return self
@@ -121,9 +126,9 @@ class GemmTimer:
 
     def summary(self):
         torch.cuda.synchronize()
-        big = [(f, s.elapsed_time(e)) for f, s, e, isbig in self.rec if isbig]
-        fl, ms = sum(f for f, _ in big), sum(t for _, t in big)
-        return len(big), fl, ms
+        big = [(f, s.elapsed_time(e), b) for f, s, e, isbig, b in self.rec if isbig]
+        fl, ms, by = sum(x[0] for x in big), sum(x[1] for x in big), sum(x[2] for x in big)
+        return len(big), fl, ms, by
 
 
 def main():
@@ -182,10 +187,15 @@ def main():
     if not a.no_kernel_timing:
         with GemmTimer(ops) as gt:
             tr.train_step(lit, batch, a.warmup + a.steps)
-        n, fl, kms = gt.summary()
+        n, fl, kms, by = gt.summary()
         ach = fl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_nt.json")
+        if os.path.exists(pmc) and a.batch == 256 and a.patch == 16 and a.seq_len == 64:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")     # rocprofv3 --pmc passes of this same command
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,256,2,4> (bf16 MFMA 32x32x16 NT GEMM, fused epilogues)", "achieved": round(ach, 1),
-                "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None, "launches_per_step": n,
+                "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                "algorithmic_bytes_per_launch": round(by / max(n, 1)), "launches_per_step": n,
                 "avg_launch_ms": round(kms / max(n, 1), 4), "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 1),
                 "step_frac_of_mfma_peak": round(value / world * train_gflop / 2.5e6, 4)}
     # Hits@1 of the (untrained, random-init) model on the same batch -- reported to exercise the ranking eval path
