@@ -99,6 +99,7 @@ __device__ __forceinline__ float reweight(const TextCtl& c, int qi, int kj) {
 }
 
 // =========================================================================== forward
+template <bool TEXT>
 __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -109,10 +110,11 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
   const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
   const TextCtl ctl = make_ctl(p, b, p.Sk);
-  const bool text = ctl.mask_row || ctl.sep >= 0 || ctl.p_drop > 0.f;
+  constexpr bool text = TEXT;          // vision instantiation: no mask / reweight / dropout code at all
   const LaneOffs lo = make_offs(lane);
 
   const int qi = q0 + l31;
+  const bool active = q0 < p.Sq;                      // wave-uniform
   const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + min(qi, p.Sq - 1)) * p.ldq + h * 64;
   bf16x8 qf[4];
 #pragma unroll
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
     }
     const char* sK = smem + (kt & 1) * STAGE_BYTES;
     const char* sV = sK + TILE_BYTES;
+    if (!active) continue;                            // wave past the last query row: only stages tiles and keeps the barriers
     // S^T[key][q] = K q^T
     f32x16 st[2];
 #pragma unroll
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
           const float e = __builtin_amdgcn_exp2f(pv[t][r] - m_new);
           rs += e;
           float used = e;
-          if (ctl.p_drop > 0.f) {
+          if (TEXT && ctl.p_drop > 0.f) {
             const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
             const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
             used = dropout_keep(ctl.seed, idx, ctl.p_drop) ? e * ctl.inv_keep : 0.f;
@@ -261,6 +264,7 @@ __global__ void attn_delta_k(const bf16* __restrict__ o, int ldo, const bf16* __
 }
 
 // =========================================================================== backward, dQ pass (owner = queries)
+template <bool TEXT>
 __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mart_attn_fwd_desc& p = pb.f;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
   const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
   const TextCtl ctl = make_ctl(p, b, p.Sk);
-  const bool text = ctl.mask_row || ctl.sep >= 0 || ctl.p_drop > 0.f;
+  constexpr bool text = TEXT;          // vision instantiation: no mask / reweight / dropout code at all
   const LaneOffs lo = make_offs(lane);
 
   const int qi = q0 + l31, qc = min(qi, p.Sq - 1);
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
     }
     const char* sK = smem + (kt & 1) * STAGE_BYTES;
     const char* sV = sK + TILE_BYTES;
+    if (q0 >= p.Sq) continue;                         // idle wave (rows past Sq): staging + barriers only
     f32x16 st[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -341,12 +346,12 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
           }
           float pr = (kj < Stot && qvalid) ? __builtin_amdgcn_exp2f(s * LOG2E - lse) : 0.f;
           float dpd = dp[t][r];
-          if (ctl.p_drop > 0.f) {
+          if (TEXT && ctl.p_drop > 0.f) {
             const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
             dpd = dropout_keep(ctl.seed, idx, ctl.p_drop) ? dpd * ctl.inv_keep : 0.f;
           }
           const float ds = pr * (dpd - delta);           // d/d(post-reweight, pre-mask score)
-          if (ctl.sep >= 0 && kj >= ctl.sep) { if (qi < ctl.sep) dc0 += ds * spre; else dc1 += ds * spre; }
+          if (TEXT && ctl.sep >= 0 && kj >= ctl.sep) { if (qi < ctl.sep) dc0 += ds * spre; else dc1 += ds * spre; }
           dsv[t][r] = ds * f;
         }
     }
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
         *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
       }
   }
-  if (pb.dw && ctl.sep >= 0) {
+  if (TEXT && pb.dw && ctl.sep >= 0) {
     dc0 = wave_sum(dc0); dc1 = wave_sum(dc1);
     if (lane == 0) {
       const float w0 = p.w0[0], w1 = p.w1[0];
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
 }
 
 // =========================================================================== backward, dK/dV pass (owner = keys)
+template <bool TEXT>
 __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mart_attn_fwd_desc& p = pb.f;
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
   const Side Q{(const bf16*)p.q, p.ldq, p.Sq, nullptr, 0, 0};
   const Side G{(const bf16*)pb.dctx, pb.lddctx, p.Sq, nullptr, 0, 0};
   const TextCtl ctl = make_ctl(p, b, p.Sk);
-  const bool text = ctl.mask_row || ctl.sep >= 0 || ctl.p_drop > 0.f;
+  constexpr bool text = TEXT;          // vision instantiation: no mask / reweight / dropout code at all
   const LaneOffs lo = make_offs(lane);
 
   const int kj = k0 + l31;
@@ -439,6 +445,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
     const char* sG = sQ + TILE_BYTES;
     const float* sLse = (const float*)(sQ + 2 * TILE_BYTES);
     const float* sDel = sLse + 64;
+    if (k0 >= Stot) continue;                         // idle wave (keys past the end): staging + barriers only
     // S[q][key] = Q k^T ; dP[q][key] = dO v^T      (lane = key)
     f32x16 st[2], dp[2];
 #pragma unroll
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
             if (text) { f = reweight(ctl, qi, kj); sc = sc * f + maskadd; }
             const float pr = (kvalid && qi < p.Sq) ? __builtin_amdgcn_exp2f(sc * LOG2E - sLse[ql]) : 0.f;
             float keep = 1.f;
-            if (ctl.p_drop > 0.f) {
+            if (TEXT && ctl.p_drop > 0.f) {
               const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
               keep = dropout_keep(ctl.seed, idx, ctl.p_drop) ? ctl.inv_keep : 0.f;
             }
@@ -537,9 +544,11 @@ int check_fwd(const mart_attn_fwd_desc* d) {
 bool g_attr_set = false;
 int set_attrs() {
   if (g_attr_set) return 0;
-  if (hipFuncSetAttribute((const void*)attn_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-      hipFuncSetAttribute((const void*)attn_bwd_dq_k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-      hipFuncSetAttribute((const void*)attn_bwd_dkv_k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+  const void* ks[6] = {(const void*)attn_fwd_k<false>, (const void*)attn_fwd_k<true>, (const void*)attn_bwd_dq_k<false>,
+                       (const void*)attn_bwd_dq_k<true>, (const void*)attn_bwd_dkv_k<false>, (const void*)attn_bwd_dkv_k<true>};
+  bool ok = true;
+  for (int i = 0; i < 6; ++i) ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+  if (!ok) {
     mart_set_error("attn: hipFuncSetAttribute failed");
     return -2;
   }
@@ -551,7 +560,9 @@ int set_attrs() {
 extern "C" int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream) {
   if (int rc = check_fwd(d)) return rc;
   if (int rc = set_attrs()) return rc;
-  hipLaunchKernelGGL(attn_fwd_k, dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
+  const bool text = d->attn_mask || d->sep || d->p_drop > 0.f;
+  if (text) hipLaunchKernelGGL(attn_fwd_k<true>, dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(attn_fwd_k<false>, dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
   return 0;
 }
@@ -569,9 +580,12 @@ extern "C" int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream) {
   hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16*)f.ctx, f.ldctx, (const bf16*)d->dctx,
                      d->lddctx, d->delta, f.B, f.nh, f.Sq);
   MART_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dq_k, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
+  const bool text = f.attn_mask || f.sep || f.p_drop > 0.f;
+  if (text) hipLaunchKernelGGL(attn_bwd_dq_k<true>, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
+  else hipLaunchKernelGGL(attn_bwd_dq_k<false>, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   MART_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dkv_k, dim3((f.Lp + f.Sk + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
+  if (text) hipLaunchKernelGGL(attn_bwd_dkv_k<true>, dim3((f.Lp + f.Sk + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
+  else hipLaunchKernelGGL(attn_bwd_dkv_k<false>, dim3((f.Lp + f.Sk + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   MART_LAUNCH_CHECK();
   return 0;
 }
