@@ -33,7 +33,7 @@ struct Args {
   int dbg;                           // 1: skip the LDS-DMA after the first tile (timing experiment only)
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int BK = 64;
@@ -106,7 +106,75 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
   for (int j = 0; j < TN; ++j) rowB[j] = wn0 + j * 32 + l31;
 
-  if constexpr (WAVES_M == 2 && WAVES_N == 4) {
+  if constexpr (PIPE == 1) {
+    // ---- 4-slot ring of 32-deep K-steps (32 KB per slot), LDS-DMA three steps ahead behind COUNTED vmcnt waits: the
+    // memory pipe always has 2-3 steps (64-96 KB per CU) in flight instead of one 64 KB burst per barrier.
+    //   slot image: 64-byte rows, 16-byte chunk c' = c ^ ((row>>2)&3)  (conflict-free for the b128 service groups)
+    constexpr int SA = BM * 64, SB = BN * 64, SLOT = SA + SB;          // bytes
+    constexpr int QA = (BM * 4) / NT, QB = (BN * 4) / NT;              // chunks per thread per step
+    static_assert(QA >= 1 && QB >= 1, "tile too small for the ring");
+    unsigned oA[QA], oB[QB];
+#pragma unroll
+    for (int r = 0; r < QA; ++r) {
+      int c = r * NT + tid, row = c >> 2, pc = c & 3, lc = pc ^ ((row >> 2) & 3);
+      int gm = min(m0 + row, p.M - 1);
+      if (p.a_rows) gm = p.a_rows[gm];
+      oA[r] = (unsigned)gm * (unsigned)p.lda + lc * 8;
+    }
+#pragma unroll
+    for (int r = 0; r < QB; ++r) {
+      int c = r * NT + tid, row = c >> 2, pc = c & 3, lc = pc ^ ((row >> 2) & 3);
+      int gn = min(n0 + row, p.N - 1);
+      if (p.b_rows) gn = p.b_rows[gn];
+      oB[r] = (unsigned)gn * (unsigned)p.ldb + lc * 8;
+    }
+    const int ns1 = p.K / 32, ns = ns1 + p.K2 / 32;
+    auto issue = [&](int t) {
+      const bf16* Ap = A; const bf16* Bp = B; int k0 = t * 32;
+      if (t >= ns1) { Ap = A2; Bp = B2; k0 = (t - ns1) * 32; }
+      char* sA = smem + (t & 3) * SLOT;
+      char* sB = sA + SA;
+#pragma unroll
+      for (int r = 0; r < QA; ++r) glds16(Ap + oA[r] + k0, sA + (r * NT + wave * 64) * 16);
+#pragma unroll
+      for (int r = 0; r < QB; ++r) glds16(Bp + oB[r] + k0, sB + (r * NT + wave * 64) * 16);
+    };
+    int keyA[TM], keyB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) keyA[i] = (rowA[i] >> 2) & 3;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) keyB[j] = (rowB[j] >> 2) & 3;
+    issue(0);
+    if (ns > 1) issue(1);
+    if (ns > 2) issue(2);
+    for (int t = 0; t < ns; ++t) {
+      const int ahead = min(ns - 1 - t, 2);                 // newer steps that may stay in flight
+      if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (QA + QB)) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA + QB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                          // step t visible to all; slot of step t-1 free
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 3 < ns) issue(t + 3);
+      const char* sA = smem + (t & 3) * SLOT;
+      const char* sB = sA + SA;
+      bf16x8 af[2][TM], bfr[2][TN];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int lc = u * 2 + h;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[u][i] = *(const bf16x8*)(sA + rowA[i] * 64 + ((lc ^ keyA[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[u][j] = *(const bf16x8*)(sB + rowB[j] * 64 + ((lc ^ keyB[j]) << 4));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[u][j], af[u][i], acc[i][j]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all fragment reads of this slot retired before the next barrier
+    }
+  } else if constexpr (WAVES_M == 2 && WAVES_N == 4) {
     // ---- ping-pong main loop (8 waves).  The two wave-rows of the tile (waves 0-3 / 4-7; waves w and w+4 share a
     // SIMD) run the same 4-phase K-tile sequence  R0 | M0 | R1 | M1  (R = fragment reads of two k-steps (+ LDS-DMA
     // of the next tile in R0), M = 32 MFMAs), every phase ending in s_barrier -- but the lower wave-row executes ONE
@@ -310,13 +378,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0>
 int launch(const Args& a, int batch, hipStream_t st) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2, LDS_EPI = (BM / WAVES_M) * (BN + 4) * 4;
   constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N>;
+  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       mart_set_error("gemm_nt: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -360,6 +428,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   a.dbg = 0;
   if (cfg == 999) { a.dbg = 1; cfg = 256; }
   if (cfg == 0) cfg = (t256 >= 224) ? 256 : 128;
+  if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
   if (cfg == 256) return launch<256, 256, 2, 4>(a, batch, st);
   return launch<128, 128, 2, 2>(a, batch, st);
 }
