@@ -335,6 +335,76 @@ def g3(lit, out_dir):
     print("G3 ok", float(loss), ranks, (t2 + 1).numpy())
 
 
+def g5_flava(out_dir):
+    """G5: tiny FLAVA end-to-end (FlavaForMaskedLM as MarT runs it): trans_hidden, mask-row logits, fine-tune loss, gradients.
+    Extra shims: prune helpers stubbed into transformers.modeling_utils; get_head_mask / get_extended_attention_mask
+    of FlavaPreTrainedModel overridden with the transformers==4.19.0 semantics the reference was written against."""
+    import transformers.modeling_utils as mu
+    if not hasattr(mu, "find_pruneable_heads_and_indices"):
+        mu.find_pruneable_heads_and_indices = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    if not hasattr(mu, "prune_linear_layer"):
+        mu.prune_linear_layer = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+    from oracle import flava_oracle as FO
+    spec = importlib.util.spec_from_file_location("ref_flava", os.path.join(REF, "models/modeling_flava.py"))
+    fl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fl)
+    fl.FlavaPreTrainedModel.get_head_mask = lambda self, head_mask, n, *a, **k: [None] * n
+    fl.FlavaPreTrainedModel.get_extended_attention_mask = \
+        lambda self, mask, shape=None, device=None, *a, **k: (1.0 - mask[:, None, None, :].to(torch.float32)) * -10000.0
+    from transformers import FlavaConfig
+    V = TINY_BASE + TINY_E + TINY_R + 1
+    c = FO.FlavaCfg(vocab_size=V, hidden_size=64, text_layers=3, image_layers=3, mm_layers=2, num_attention_heads=4,
+                    intermediate_size=128, max_position_embeddings=64, image_size=64, patch_size=32)
+    common = dict(hidden_size=64, num_attention_heads=4, intermediate_size=128)
+    cfg = FlavaConfig(text_config=dict(vocab_size=V, num_hidden_layers=3, max_position_embeddings=64, **common),
+                      image_config=dict(num_hidden_layers=3, image_size=64, patch_size=32, **common),
+                      multimodal_config=dict(num_hidden_layers=2, **common), hidden_size=64, projection_dim=64)
+    torch.manual_seed(0)
+    model = fl.FlavaForMaskedLM(cfg)
+    model.cls.decoder.weight = model.flava.text_model.embeddings.word_embeddings.weight      # tie manually (no resize under 5.x)
+    # MarT always resizes the embedding (lit_models/transformer.py:33); transformers==4.19.0's _get_resized_embeddings builds a
+    # plain nn.Embedding(new_num_tokens, dim) WITHOUT padding_idx, so the [PAD] row does receive gradient in real use
+    model.flava.text_model.embeddings.word_embeddings.padding_idx = None
+    sd = FO.init_params(c, seed=31)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("position_ids" in m or "decoder" in m or "token_type_ids" in m) for m in missing), missing
+    named = dict(model.named_parameters())
+    assert set(named) == set(sd), (set(named) ^ set(sd))
+    assert [n for n in named] == [n for n in sd], "parameter order differs"
+    model.eval()
+    batch = tiny_batch(B=3, L=24, seed=9)
+    ids = batch["analogy_entity_ids"]
+    out, trans = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], token_type_ids=batch["token_type_ids"],
+                       pixel_values=batch["pixel_values"], sep_idx=batch["sep_idx"], return_dict=True)
+    B = trans.shape[0]
+    _, mask_idx = (batch["input_ids"] == 103).nonzero(as_tuple=True)
+    mask_logits = out.logits[torch.arange(B), mask_idx][:, ids]
+    loss = O.label_smooth_ce(mask_logits, batch["label"], 0.1) + 0.45 * O.relaxation_loss(trans, batch["rel_idx"], batch["q_head_idx"],
+                                                                                          batch["a_head_idx"])
+    loss.backward()
+    none_grad = sorted(n for n, p in named.items() if p.grad is None)
+    zero_grad = sorted(n for n, p in named.items() if p.grad is not None and float(p.grad.abs().max()) == 0.0)
+    gnames = ["flava.text_model.encoder.layer.1.attention.attention.adaptive_weight.0",
+              "flava.text_model.encoder.layer.1.attention.attention.adaptive_weight.1",
+              "flava.text_model.encoder.layer.0.attention.attention.query.weight",
+              "flava.text_model.embeddings.word_embeddings.weight", "flava.image_model.embeddings.position_embeddings",
+              "flava.image_model.embeddings.cls_token", "flava.image_model.embeddings.patch_embeddings.projection.weight",
+              "flava.image_model.embeddings.patch_embeddings.projection.bias",
+              "flava.image_model.encoder.layer.2.output.dense.weight", "flava.multimodal_model.cls_token",
+              "flava.multimodal_model.encoder.layer.1.attention.attention.key.bias", "flava.image_to_mm_projection.weight",
+              "flava.text_to_mm_projection.bias", "flava.multimodal_model.layernorm.weight", "cls.transform.dense.weight", "cls.bias"]
+    grads = {"grad::" + n: named[n].grad.detach().numpy().copy() for n in gnames}
+    norms = {n: float(p.grad.norm()) for n, p in named.items() if p.grad is not None}
+    np.savez_compressed(
+        os.path.join(out_dir, "g5_flava_tiny.npz"),
+        **{"in::" + k: v.numpy() for k, v in batch.items()}, weight_seed=np.int64(31),
+        trans=trans.detach().numpy(), mask_logits=mask_logits.detach().numpy(), loss=np.float64(float(loss)),
+        none_grad=np.array(none_grad), zero_grad=np.array(zero_grad),
+        grad_norm_names=np.array(sorted(norms)), grad_norm_vals=np.array([norms[k] for k in sorted(norms)]), **grads)
+    print("G5 flava loss", float(loss), "none-grad", len(none_grad), "zero-grad", len(zero_grad))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -345,6 +415,7 @@ def main():
     g3(lit, a.out)
     g2(unimo, a.out)
     g1_g4(lit, unimo, a.out)
+    g5_flava(a.out)
 
 
 if __name__ == "__main__":

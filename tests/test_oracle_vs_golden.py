@@ -164,3 +164,33 @@ def test_g4_adamw_groups_schedule_and_steps(golden_dir):
     for k in g.files:
         if k.startswith("after::"):
             np.testing.assert_allclose(sd[k[7:]].detach().numpy(), g[k], atol=2e-6, rtol=1e-5, err_msg=k)
+
+
+def test_g5_flava_oracle_matches_reference(golden_dir):
+    """oracle/flava_oracle.py against the FLAVA golden captured from the unmodified reference (forward, loss, gradients,
+    and which tensors never receive a gradient)."""
+    from oracle import flava_oracle as FO
+    g = np.load(os.path.join(golden_dir, "g5_flava_tiny.npz"))
+    b = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in::")}
+    V = int(b["input_ids"].max()) + 1
+    c = FO.FlavaCfg(vocab_size=361, hidden_size=64, text_layers=3, image_layers=3, mm_layers=2, num_attention_heads=4,
+                    intermediate_size=128, max_position_embeddings=64, image_size=64, patch_size=32)
+    assert V <= c.vocab_size
+    sd = {k: v.clone().requires_grad_(True) for k, v in FO.init_params(c, seed=int(g["weight_seed"])).items()}
+    trans = FO.forward(sd, c, b["input_ids"], b["attention_mask"], b["token_type_ids"], b["pixel_values"], b["sep_idx"])
+    np.testing.assert_allclose(trans.detach().numpy(), g["trans"], atol=2e-5, rtol=1e-5)
+    B = trans.shape[0]
+    _, mi = (b["input_ids"] == 103).nonzero(as_tuple=True)
+    ml = FO.score(sd, trans[torch.arange(B), mi], b["analogy_entity_ids"])
+    np.testing.assert_allclose(ml.detach().numpy(), g["mask_logits"], atol=2e-5, rtol=1e-5)
+    loss = O.label_smooth_ce(ml, b["label"], 0.1) + 0.45 * O.relaxation_loss(trans, b["rel_idx"], b["q_head_idx"], b["a_head_idx"])
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    none_ref = set(g["none_grad"].tolist())
+    none_got = {k for k, v in sd.items() if v.grad is None}
+    assert none_ref == none_got, none_ref ^ none_got
+    for k in g.files:
+        if k.startswith("grad::"):
+            np.testing.assert_allclose(sd[k[6:]].grad.numpy(), g[k], atol=3e-6, rtol=3e-4, err_msg=k)
+    for k, v in zip(g["grad_norm_names"].tolist(), g["grad_norm_vals"].tolist()):
+        assert abs(float(sd[k].grad.norm()) - v) <= 1e-6 + 3e-4 * v, k
