@@ -107,9 +107,11 @@ int mart_patchify_gather(const float* table, const int32_t* index, void* out_bf1
 /* the stacked tensor itself, for callers that want pixel_values [B,2,3,S,S] */
 int mart_gather_images(const float* table, const int32_t* index, float* out, int B, int S, void* stream);
 /* s[b,t,:] = [cls | patch(b,0,:) | patch(b,1,:)] + pos[0,1..P,1..P]   (modeling_unimo.py:127-130) */
-int mart_vision_assemble(const void* patch_bf16, const float* cls, const float* pos, float* s, int B, int P, int H, void* stream);
+/* tail_shift: position row of the second image's patch t is t - tail_shift (MKGformer 0: pos[1..P]; FLAVA 1: pos[0..P-1],
+ * the reference's FlavaImageEmbeddings quirk, modeling_flava.py:338) */
+int mart_vision_assemble(const void* patch_bf16, const float* cls, const float* pos, float* s, int B, int P, int H, int tail_shift, void* stream);
 /* backward of the assemble: dpatch (bf16) and atomically accumulated dcls, dpos */
-int mart_vision_assemble_bwd(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, void* stream);
+int mart_vision_assemble_bwd(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, int tail_shift, void* stream);
 /* BertEmbeddings.forward (modeling_unimo.py:152-186): word[ids]+type[tt]+pos[:L] -> LN(eps) -> dropout */
 typedef struct {
   const int64_t* ids; const int64_t* tt;
@@ -145,6 +147,7 @@ typedef struct {
   float p_drop; uint64_t seed;
   void* ctx; int ldctx;                                             /* bf16 out [B*Sq, nh*64] */
   float* lse;                                                       /* [B,nh,Sq] softmax statistic, LOG2 domain: log2(sum_j 2^(s_ij*log2e)) */
+  int rw_skip_row0;                                                 /* FLAVA reweight variant: query row 0 ([CLS]) is not scaled (modeling_flava.py:494) */
 } mart_attn_fwd_desc;
 int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream);
 

@@ -55,7 +55,7 @@ class AttnFwd(C.Structure):
                 ("pk", vp), ("pv", vp), ("ldp", i32), ("Lp", i32),
                 ("B", i32), ("nh", i32), ("Sq", i32), ("Sk", i32), ("scale", f32),
                 ("attn_mask", vp), ("sep", vp), ("sep_stride", i32), ("w0", vp), ("w1", vp),
-                ("p_drop", f32), ("seed", u64), ("ctx", vp), ("ldctx", i32), ("lse", vp)]
+                ("p_drop", f32), ("seed", u64), ("ctx", vp), ("ldctx", i32), ("lse", vp), ("rw_skip_row0", i32)]
 
 
 class AttnBwd(C.Structure):
@@ -81,8 +81,8 @@ _SIGS = {
     "mart_patchify": (i32, [vp, vp, i32, i32, i32, vp]),
     "mart_patchify_gather": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "mart_gather_images": (i32, [vp, vp, vp, i32, i32, vp]),
-    "mart_vision_assemble": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
-    "mart_vision_assemble_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mart_vision_assemble": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mart_vision_assemble_bwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mart_text_embed_fwd": (i32, [C.POINTER(TextEmbed), vp]),
     "mart_dropout_bwd_f32": (i32, [vp, vp, vp, i64, f32, u64, vp]),
     "mart_text_embed_scatter": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

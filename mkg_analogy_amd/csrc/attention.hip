@@ -81,6 +81,7 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
 struct TextCtl {                          // per-(b) text controls, all optional
   const int64_t* mask_row;                // attention_mask row of this batch element or NULL
   int sep;                                // reweight split, <0 = off
+  int skip0;                              // FLAVA: query row 0 keeps factor 1
   float c0, c1;
   float p_drop, inv_keep; uint64_t seed;
 };
@@ -88,6 +89,7 @@ __device__ __forceinline__ TextCtl make_ctl(const mart_attn_fwd_desc& p, int b, 
   TextCtl c;
   c.mask_row = p.attn_mask ? p.attn_mask + (long long)b * Sk : nullptr;
   c.sep = p.sep ? (int)p.sep[(long long)b * p.sep_stride] : -1;
+  c.skip0 = p.rw_skip_row0;
   c.c0 = p.w0 ? fminf(fmaxf(p.w0[0], 0.f), 0.5f) : 1.f;
   c.c1 = p.w1 ? fminf(fmaxf(p.w1[0], 0.5f), 1.f) : 1.f;
   c.p_drop = p.p_drop; c.inv_keep = 1.f / (1.f - p.p_drop); c.seed = p.seed;
@@ -95,7 +97,8 @@ __device__ __forceinline__ TextCtl make_ctl(const mart_attn_fwd_desc& p, int b, 
 }
 __device__ __forceinline__ float reweight(const TextCtl& c, int qi, int kj) {
   if (c.sep < 0 || kj < c.sep) return 1.f;
-  return qi < c.sep ? c.c0 : c.c1;
+  if (qi >= c.sep) return c.c1;
+  return (c.skip0 && qi == 0) ? 1.f : c.c0;
 }
 
 // =========================================================================== forward
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
             dpd = dropout_keep(ctl.seed, idx, ctl.p_drop) ? dpd * ctl.inv_keep : 0.f;
           }
           const float ds = pr * (dpd - delta);           // d/d(post-reweight, pre-mask score)
-          if (TEXT && ctl.sep >= 0 && kj >= ctl.sep) { if (qi < ctl.sep) dc0 += ds * spre; else dc1 += ds * spre; }
+          if (TEXT && ctl.sep >= 0 && kj >= ctl.sep) { if (qi >= ctl.sep) dc1 += ds * spre; else if (!(ctl.skip0 && qi == 0)) dc0 += ds * spre; }
           dsv[t][r] = ds * f;
         }
     }

@@ -258,12 +258,12 @@ __global__ void gather_images_k(const float* __restrict__ table, const int32_t* 
 }
 
 __global__ void vision_assemble_k(const bf16* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
-                                  float* __restrict__ s, int B, int P, int H) {
+                                  float* __restrict__ s, int B, int P, int H, int tail_shift) {
   const int Nv = 1 + 2 * P;
   const long long row = blockIdx.x;                  // b*Nv + t
   const int t = (int)(row % Nv);
   const long long b = row / Nv;
-  const int pidx = t == 0 ? 0 : (t <= P ? t : t - P);
+  const int pidx = t == 0 ? 0 : (t <= P ? t : t - P - tail_shift);
   for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
     f32x4 v;
     if (t == 0) v = *(const f32x4*)(cls + c);
@@ -274,22 +274,24 @@ __global__ void vision_assemble_k(const bf16* __restrict__ patch, const float* _
 }
 
 // dpatch = bf16(ds rows 1..2P); dcls += sum_b ds[b,0]; dpos[t] += sum_b (ds[b,t] + ds[b,t+P])
-__global__ void vision_assemble_bwd_k(const float* __restrict__ ds, bf16* __restrict__ dpatch, float* dcls, float* dpos, int B, int P, int H) {
+__global__ void vision_assemble_bwd_k(const float* __restrict__ ds, bf16* __restrict__ dpatch, float* dcls, float* dpos, int B, int P, int H, int tail_shift) {
   const int Nv = 1 + 2 * P;
-  const int t = blockIdx.x;                          // 0..P : position row
+  const int t = blockIdx.x;                          // 0..P : row of the first image (and of the class token)
   for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    float acc = 0.f, acc_cls = 0.f;
+    float acc = 0.f, acc_cls = 0.f, acc_tail = 0.f;
     for (int b = 0; b < B; ++b) {
       const float* base = ds + (long long)b * Nv * H;
       if (t == 0) { float g = base[c]; acc += g; acc_cls += g; }
       else {
         float g0 = base[(long long)t * H + c], g1 = base[(long long)(t + P) * H + c];
-        acc += g0 + g1;
+        acc += g0 + g1; acc_tail += g1;
         dpatch[((long long)b * 2 * P + (t - 1)) * H + c] = f2bf(g0);
         dpatch[((long long)b * 2 * P + (t - 1 + P)) * H + c] = f2bf(g1);
       }
     }
-    atomicAdd(dpos + (long long)t * H + c, acc);
+    // acc holds the first image's row t (+ the second image's row t, whose position row is t - tail_shift)
+    atomicAdd(dpos + (long long)t * H + c, acc - acc_tail);
+    if (t > 0) atomicAdd(dpos + (long long)(t - tail_shift) * H + c, acc_tail);
     if (t == 0) atomicAdd(dcls + c, acc_cls);
   }
 }
@@ -422,15 +424,15 @@ extern "C" int mart_gather_images(const float* table, const int32_t* index, floa
   MART_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int mart_vision_assemble(const void* patch_bf16, const float* cls, const float* pos, float* s, int B, int P, int H, void* stream) {
-  MART_CHECK(patch_bf16 && cls && pos && s && B > 0 && P > 0 && H % 4 == 0, "vision_assemble: bad args");
-  hipLaunchKernelGGL(vision_assemble_k, dim3(B * (1 + 2 * P)), dim3(192), 0, (hipStream_t)stream, (const bf16*)patch_bf16, cls, pos, s, B, P, H);
+extern "C" int mart_vision_assemble(const void* patch_bf16, const float* cls, const float* pos, float* s, int B, int P, int H, int tail_shift, void* stream) {
+  MART_CHECK(patch_bf16 && cls && pos && s && B > 0 && P > 0 && H % 4 == 0 && (tail_shift == 0 || tail_shift == 1), "vision_assemble: bad args");
+  hipLaunchKernelGGL(vision_assemble_k, dim3(B * (1 + 2 * P)), dim3(192), 0, (hipStream_t)stream, (const bf16*)patch_bf16, cls, pos, s, B, P, H, tail_shift);
   MART_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int mart_vision_assemble_bwd(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, void* stream) {
-  MART_CHECK(ds && dpatch_bf16 && dcls && dpos && B > 0 && P > 0 && H > 0, "vision_assemble_bwd: bad args");
-  hipLaunchKernelGGL(vision_assemble_bwd_k, dim3(P + 1), dim3(256), 0, (hipStream_t)stream, ds, (bf16*)dpatch_bf16, dcls, dpos, B, P, H);
+extern "C" int mart_vision_assemble_bwd(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, int tail_shift, void* stream) {
+  MART_CHECK(ds && dpatch_bf16 && dcls && dpos && B > 0 && P > 0 && H > 0 && (tail_shift == 0 || tail_shift == 1), "vision_assemble_bwd: bad args");
+  hipLaunchKernelGGL(vision_assemble_bwd_k, dim3(P + 1), dim3(256), 0, (hipStream_t)stream, ds, (bf16*)dpatch_bf16, dcls, dpos, B, P, H, tail_shift);
   MART_LAUNCH_CHECK();
   return 0;
 }

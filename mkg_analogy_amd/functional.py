@@ -13,6 +13,7 @@ import torch
 from . import ops
 
 BF, F32 = torch.bfloat16, torch.float32
+WORD, BIAS = "unimo.text_embeddings.word_embeddings.weight", "cls.predictions.bias"
 
 
 class _MKGformerFn(torch.autograd.Function):
@@ -41,24 +42,26 @@ class _ScoreFn(torch.autograd.Function):
     (modeling_unimo.py:958 restricted to what lit_models/transformer.py:75-95,131-160 actually read)."""
 
     @staticmethod
-    def forward(ctx, trans, transb, rows, ids, store):
+    def forward(ctx, trans, transb, rows, ids, store, word_name=WORD, bias_name=BIAS):
         R, A = rows.numel(), ids.numel()
-        W = store.w("unimo.text_embeddings.word_embeddings.weight")
+        W = store.w(word_name)
         out = torch.empty((R, A), device=trans.device, dtype=F32)
-        ops.gemm_nt(transb, W, out, a_rows=rows, b_rows=ids, bias=store.m("cls.predictions.bias"), bias_by_brow=True)
+        ops.gemm_nt(transb, W, out, a_rows=rows, b_rows=ids, bias=store.m(bias_name), bias_by_brow=True)
         ctx.store, ctx.rows, ctx.ids, ctx.transb, ctx.shape = store, rows, ids, transb, trans.shape
+        ctx.names = (word_name, bias_name)
         return out
 
     @staticmethod
     def backward(ctx, dlogits):
         store, rows, ids, transb = ctx.store, ctx.rows, ctx.ids, ctx.transb
+        word_name, bias_name = ctx.names
         dev = dlogits.device
         R, A = dlogits.shape
         H = transb.shape[1]
         Ap = ((A + 63) // 64) * 64
         dl = torch.empty((R, Ap), device=dev, dtype=BF)
         ops.cast_pad_f32_bf16(dlogits.contiguous(), dl, R, A)
-        W = store.w("unimo.text_embeddings.word_embeddings.weight")
+        W = store.w(word_name)
         Wg = torch.empty((A, H), device=dev, dtype=BF)
         ops.gather_rows_bf16(W, ids, Wg)
         WgT = torch.empty((H, Ap), device=dev, dtype=BF)
@@ -69,9 +72,8 @@ class _ScoreFn(torch.autograd.Function):
         ops.scatter_add_rows_f32(drows, rows, dtrans.view(-1, H))
         trows = torch.empty((R, H), device=dev, dtype=BF)
         ops.gather_rows_bf16(transb, rows, trows)
-        ops.gemm_tn(dl, trows, store.g("unimo.text_embeddings.word_embeddings.weight"), NX=A, out_rows=ids,
-                    colsum=store.g("cls.predictions.bias"), colsum_by_row=True)
-        return dtrans, None, None, None, None
+        ops.gemm_tn(dl, trows, store.g(word_name), NX=A, out_rows=ids, colsum=store.g(bias_name), colsum_by_row=True)
+        return dtrans, None, None, None, None, None, None
 
 
 class _LSCEFn(torch.autograd.Function):
@@ -158,16 +160,17 @@ class LazyRows:
         if not (isinstance(rsel, slice) and rsel == slice(None)):
             rows = rows[rsel].contiguous()
         o = self.owner
-        return _ScoreFn.apply(o.trans, o.trans_bf16, rows, self._ids(csel), o.store)
+        return _ScoreFn.apply(o.trans, o.trans_bf16, rows, self._ids(csel), o.store, o.word_name, o.bias_name)
 
 
 class LazyLogits:
     """Stand-in for ``MaskedLMOutput.logits`` [B,L,V] (2.75 GB fp32 at B=256 in the reference, modeling_unimo.py:958).
     Indexing patterns used by the trainer surface are scored on demand; ``materialize()`` builds the full tensor."""
 
-    def __init__(self, trans: torch.Tensor, trans_bf16: torch.Tensor, store):
+    def __init__(self, trans: torch.Tensor, trans_bf16: torch.Tensor, store, word_name: str = WORD, bias_name: str = BIAS):
         self.trans, self.trans_bf16, self.store = trans, trans_bf16, store
-        self.vocab = store.slots["unimo.text_embeddings.word_embeddings.weight"].shape[0]
+        self.word_name, self.bias_name = word_name, bias_name
+        self.vocab = store.slots[word_name].shape[0]
 
     @property
     def shape(self):
@@ -192,4 +195,4 @@ class LazyLogits:
         B, L, _ = self.trans.shape
         rows = torch.arange(B * L, device=self.trans.device, dtype=torch.int32)
         ids = torch.arange(self.vocab, device=self.trans.device, dtype=torch.int32)
-        return _ScoreFn.apply(self.trans, self.trans_bf16, rows, ids, self.store).view(B, L, self.vocab)
+        return _ScoreFn.apply(self.trans, self.trans_bf16, rows, ids, self.store, self.word_name, self.bias_name).view(B, L, self.vocab)

@@ -155,6 +155,9 @@ class TransformerLitModel(BaseLitModel):
     def configure_optimizers(self):
         if self.optimizer_name != "AdamW":
             raise NotImplementedError("the HIP path implements AdamW (the only optimizer MarT's scripts use)")
+        if self.args.pretrain:          # no sep_idx => the adaptive weights get grad None in the reference => torch never touches them
+            st = self.model.store
+            st.rebuild_chunks(extra_dead=[n for n in st.slots if "adaptive_weight" in n])
         optimizer = FusedAdamW(self.model, lr=self.lr, eps=1e-8, weight_decay=self.args.weight_decay)
         steps = self.num_training_steps
         scheduler = LinearWarmupSchedule(optimizer, num_warmup_steps=steps * self.args.warm_up_radio, num_training_steps=steps)

@@ -1,5 +1,6 @@
-from .model import MKGformerKGC
+from .model import FlavaKGC, MKGformerKGC
 from .modeling_unimo import UnimoForMaskedLM
+from .modeling_flava import FlavaForMaskedLM, flava_config
 from .configs import TextConfig, VisionConfig
 
-__all__ = ["MKGformerKGC", "UnimoForMaskedLM", "TextConfig", "VisionConfig"]
+__all__ = ["MKGformerKGC", "FlavaKGC", "UnimoForMaskedLM", "FlavaForMaskedLM", "flava_config", "TextConfig", "VisionConfig"]

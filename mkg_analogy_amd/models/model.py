@@ -7,3 +7,12 @@ class MKGformerKGC(UnimoForMaskedLM):
     def add_to_argparse(parser):
         parser.add_argument("--pretrain", type=int, default=0, help="")
         return parser
+
+
+class FlavaKGC(__import__("mkg_analogy_amd.models.modeling_flava", fromlist=["FlavaForMaskedLM"]).FlavaForMaskedLM):
+    """MarT/models/model.py:31."""
+
+    @staticmethod
+    def add_to_argparse(parser):
+        parser.add_argument("--pretrain", type=int, default=0, help="")
+        return parser

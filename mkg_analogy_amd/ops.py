@@ -111,12 +111,12 @@ def gather_images(table, index, out, B, S):
     L.check(L.lib().mart_gather_images(_p(table), _p(index), _p(out), B, S, _stream()), "mart_gather_images")
 
 
-def vision_assemble(patch, cls, pos, s, B, P, H):
-    L.check(L.lib().mart_vision_assemble(_p(patch), _p(cls), _p(pos), _p(s), B, P, H, _stream()), "mart_vision_assemble")
+def vision_assemble(patch, cls, pos, s, B, P, H, tail_shift=0):
+    L.check(L.lib().mart_vision_assemble(_p(patch), _p(cls), _p(pos), _p(s), B, P, H, tail_shift, _stream()), "mart_vision_assemble")
 
 
-def vision_assemble_bwd(ds, dpatch, dcls, dpos, B, P, H):
-    L.check(L.lib().mart_vision_assemble_bwd(_p(ds), _p(dpatch), _p(dcls), _p(dpos), B, P, H, _stream()), "mart_vision_assemble_bwd")
+def vision_assemble_bwd(ds, dpatch, dcls, dpos, B, P, H, tail_shift=0):
+    L.check(L.lib().mart_vision_assemble_bwd(_p(ds), _p(dpatch), _p(dcls), _p(dpos), B, P, H, tail_shift, _stream()), "mart_vision_assemble_bwd")
 
 
 def text_embed_fwd(*, ids, tt, word, pos, type_, gamma, beta, eps, p_drop, seed, B, Lq, H, s_out, mean, rstd, out_f32, out_bf16):
@@ -138,7 +138,7 @@ def text_embed_scatter(ds, ids, tt, dword, dpos, dtype, B, Lq, H):
 
 
 def _attn_desc(d, *, q, k, v, ctx, lse, B, nh, Sq, Sk, scale, pk=None, pv=None, Lp=0, attn_mask=None, sep=None,
-               sep_stride=0, w0=None, w1=None, p_drop=0.0, seed=0):
+               sep_stride=0, w0=None, w1=None, p_drop=0.0, seed=0, rw_skip_row0=False):
     d.q, d.k, d.v = _p(q), _p(k), _p(v)
     d.ldq, d.ldk, d.ldv = _rows2d(q), _rows2d(k), _rows2d(v)
     d.pk, d.pv, d.ldp, d.Lp = _p(pk), _p(pv), (_rows2d(pk) if pk is not None else 0), Lp
@@ -146,6 +146,7 @@ def _attn_desc(d, *, q, k, v, ctx, lse, B, nh, Sq, Sk, scale, pk=None, pv=None, 
     d.attn_mask, d.sep, d.sep_stride, d.w0, d.w1 = _p(attn_mask), _p(sep), sep_stride, _p(w0), _p(w1)
     d.p_drop, d.seed = p_drop, seed
     d.ctx, d.ldctx, d.lse = _p(ctx), _rows2d(ctx), _p(lse)
+    d.rw_skip_row0 = int(rw_skip_row0)
 
 
 def attn_fwd(**kw):

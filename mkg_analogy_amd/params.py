@@ -85,8 +85,12 @@ def gemm_weight_names(n_layers: int) -> List[Tuple[str, Tuple[str, ...]]]:
 
 
 class FlatStore:
-    def __init__(self, named_params: Dict[str, torch.nn.Parameter], n_layers: int, device: torch.device):
-        order = layout_order(n_layers)
+    def __init__(self, named_params: Dict[str, torch.nn.Parameter], n_layers: int, device: torch.device,
+                 order: Optional[List[str]] = None, gemm_groups=None, dead: Sequence[str] = DEAD):
+        """``order`` / ``gemm_groups`` / ``dead`` default to the MKGformer layout; other backbones (FLAVA) pass their own."""
+        order = layout_order(n_layers) if order is None else order
+        gemm_groups = gemm_weight_names(n_layers) if gemm_groups is None else gemm_groups
+        self.dead = tuple(dead)
         missing = set(named_params) - set(order)
         extra = set(order) - set(named_params)
         assert not missing and not extra, f"parameter set mismatch: missing {sorted(missing)[:4]} extra {sorted(extra)[:4]}"
@@ -117,7 +121,7 @@ class FlatStore:
         self.tslots: Dict[str, Tuple[int, int, int]] = {}        # key -> (offset, rows(out), cols(in))
         toff = 0
         table = []
-        for key, names in gemm_weight_names(n_layers):
+        for key, names in gemm_groups:
             first = self.slots[names[0]]
             rows = sum(self.slots[n].shape[0] for n in names)
             cols = first.shape[1]
@@ -132,10 +136,22 @@ class FlatStore:
         self.shadow_t = torch.zeros(toff, device=device, dtype=torch.bfloat16)
         self.ttable = torch.tensor(table, dtype=torch.int64, device=device)
         # AdamW chunk table: (start, len, decay_flag); dead tensors are excluded (grad None in the reference => untouched)
+        self.order = order
+        self.rebuild_chunks()
+        self.refresh_shadows()
+
+    def rebuild_chunks(self, extra_dead: Sequence[str] = ()) -> None:
+        """AdamW chunk table.  Tensors that never receive a gradient in the reference (grad None => torch.optim skips them:
+        no update, no weight decay) are left out; ``extra_dead`` adds run-mode specific ones (e.g. adaptive weights when
+        pre-training without sep_idx)."""
+        device = self.device
         chunks = []
         CH = 1 << 16
-        for name in order:
-            if name.startswith(DEAD) or name.endswith(PACK_WITH_PREV):
+        dead = tuple(self.dead) + tuple(extra_dead)
+        for name in self.order:
+            if name.endswith(PACK_WITH_PREV):
+                continue
+            if dead and name.startswith(dead):
                 continue
             s = self.slots[name]
             n = s.numel + (1 if name.endswith("adaptive_weight.0") else 0)
@@ -144,9 +160,6 @@ class FlatStore:
                 chunks.append([s.offset + c0, min(CH, n - c0), decay])
         self.chunks = torch.tensor(chunks, dtype=torch.int32, device=device)
         self.n_chunks = len(chunks)
-        self.live_end = self.slots["unimo.vision_post_layernorm.weight"].offset
-        self.tail_start = self.slots["cls.predictions.bias"].offset
-        self.refresh_shadows()
 
     # ------------------------------------------------------------------ views
     def m(self, name: str) -> torch.Tensor:

@@ -1,0 +1,88 @@
+"""FLAVA backbone (SURVEY 8(a) row 19 / BASELINE config 4) on the HIP path vs the CPU oracle, real dimensions (768 wide,
+12 + 12 + 6 layers, 393 image tokens, L = 64, vocabulary 42007)."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import flava_oracle as FO  # noqa: E402
+from oracle import mkgformer_oracle as O  # noqa: E402
+
+
+def test_flava_forward_backward_vs_oracle():
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.lit_models import TransformerLitModel
+    from mkg_analogy_amd.models import FlavaKGC, flava_config
+    c = FO.FlavaCfg(vocab_size=D.VOCAB - 1)
+    torch.manual_seed(0)
+    model = FlavaKGC(flava_config(vocab_size=30522))
+    cfg = D.data_config(seed=1234)
+    args = argparse.Namespace(label_smoothing=0.1, alpha=0.45, pretrain=0, lr=5e-5, weight_decay=0.01, optimizer="AdamW", warm_up_radio=0.1)
+    lit = TransformerLitModel(model=model, args=args, tokenizer=D.FakeTokenizer(), data_config=cfg)      # resize -> 42006
+    sd0 = FO.init_params(c, seed=13)
+    missing, unexpected = model.load_state_dict(sd0, strict=False)
+    assert not unexpected and all(("position_ids" in m or "decoder" in m) for m in missing), (missing, unexpected)
+    model.cuda()
+    lit._init_relation_word()                                                                            # -> 42007
+    W = sd0["flava.text_model.embeddings.word_embeddings.weight"]
+    sd = dict(sd0)
+    sd["flava.text_model.embeddings.word_embeddings.weight"] = torch.cat([W, W[torch.tensor(cfg["analogy_relation_ids"])].mean(0, keepdim=True)], 0)
+    sd["cls.bias"] = torch.cat([sd0["cls.bias"], torch.zeros(1)])
+    c = FO.FlavaCfg(vocab_size=D.VOCAB)
+    B = 2
+    batch = D.make_batch(B, 64, seed=17)
+    ids = torch.tensor(cfg["analogy_entity_ids"])
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    trans_ref = FO.forward(sdg, c, batch["input_ids"], batch["attention_mask"], batch["token_type_ids"], batch["pixel_values"], batch["sep_idx"])
+    _, mi = (batch["input_ids"] == 103).nonzero(as_tuple=True)
+    ml_ref = FO.score(sdg, trans_ref[torch.arange(B), mi], ids)
+    loss_ref = O.label_smooth_ce(ml_ref, batch["label"], 0.1) + 0.45 * O.relaxation_loss(trans_ref, batch["rel_idx"], batch["q_head_idx"],
+                                                                                         batch["a_head_idx"])
+    loss_ref.backward()
+    model.eval()
+    gb = {k: v.cuda() for k, v in batch.items()}
+    st = model.store
+    st.zero_grad()
+    loss = lit.training_step(dict(gb), 1)
+    loss.backward()
+    torch.cuda.synchronize()
+    out, trans = model(input_ids=gb["input_ids"], attention_mask=gb["attention_mask"], token_type_ids=gb["token_type_ids"],
+                       pixel_values=gb["pixel_values"], sep_idx=gb["sep_idx"], return_dict=True)
+    ml = out.logits[torch.arange(B, device="cuda"), mi.cuda()][:, ids.cuda()]
+    rel_t = float((trans.detach().float().cpu() - trans_ref.detach()).norm() / trans_ref.detach().norm())
+    e_l = float((ml.detach().float().cpu() - ml_ref.detach()).abs().max())
+    scale = max(1.0, float(ml_ref.detach().abs().max()))
+    print(f"\nflava: loss hip {float(loss.detach()):.5f} oracle {float(loss_ref.detach()):.5f}; trans rel-L2 {rel_t:.3e}; logits max|err| {e_l:.3e} (scale {scale:.2f})")
+    assert rel_t < 2e-2 and e_l < 1e-2 * scale * 1.5 and abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-2
+    ev = lit._eval(dict(gb), 0)
+    ranks_ref = O.ranks_double_sort(ml_ref.detach(), batch["label"])
+    amb = ((ml_ref.detach() - ml_ref.detach()[torch.arange(B), batch["label"]][:, None]).abs() < 2 * e_l).sum(1).numpy() - 1
+    assert np.all(np.abs(ev["entity_ranks"] - ranks_ref) <= amb)
+    names = ["cls.transform.dense.weight", "cls.bias", "flava.text_model.embeddings.word_embeddings.weight",
+             "flava.image_model.embeddings.position_embeddings", "flava.image_model.embeddings.cls_token",
+             "flava.image_model.embeddings.patch_embeddings.projection.weight", "flava.image_model.embeddings.patch_embeddings.projection.bias",
+             "flava.multimodal_model.cls_token", "flava.image_to_mm_projection.weight", "flava.text_to_mm_projection.bias",
+             "flava.multimodal_model.layernorm.weight", "flava.text_model.embeddings.LayerNorm.bias"]
+    for mod, ls in (("text_model", (0, 6, 11)), ("image_model", (0, 11)), ("multimodal_model", (0, 5))):
+        for l in ls:
+            p = f"flava.{mod}.encoder.layer.{l}."
+            names += [p + "attention.attention.query.weight", p + "attention.attention.key.bias", p + "attention.attention.value.weight",
+                      p + "attention.output.dense.weight", p + "layernorm_before.weight", p + "intermediate.dense.weight",
+                      p + "output.dense.bias", p + "layernorm_after.bias"]
+            if mod == "text_model":
+                names += [p + "attention.attention.adaptive_weight.0", p + "attention.attention.adaptive_weight.1"]
+    for n in names:
+        g, r = st.g(n).detach().float().cpu().reshape(-1), sdg[n].grad.reshape(-1)
+        if r.norm().item() < 1e-7:
+            assert g.norm().item() < 1e-3, n
+            continue
+        rel = ((g - r).norm() / r.norm()).item()
+        cos = torch.nn.functional.cosine_similarity(g, r, dim=0).item()
+        print(f"   grad {n}: rel-L2 {rel:.3e} cos {cos:.5f}")
+        assert cos > 0.99 and rel < 0.12, n
+    for n in ("flava.logit_scale", "flava.image_model.pooler.dense.weight", "flava.text_model.layernorm.weight",
+              "flava.image_model.encoder.layer.3.attention.attention.adaptive_weight.0"):
+        assert float(st.g(n).abs().max()) == 0.0

@@ -162,3 +162,25 @@ def test_device_image_table_slot_rules():
             e = h if h is not None else tl
             exp.append([ents.index(e) if e else -1, -1])
     assert got == exp == [[0, 1], [2, -1], [2, -1], [-1, -1], [1, -1], [-1, -1]]
+
+
+def test_flava_parameter_names_and_layout():
+    """FlavaKGC container tree == the reference's named_parameters (order included; the oracle table is pinned by golden G5)."""
+    from oracle import flava_oracle as FO
+    from mkg_analogy_amd.flava_engine import FLAVA_DEAD, flava_gemm_groups, flava_layout_order
+    from mkg_analogy_amd.models import FlavaKGC, flava_config
+    c = FO.FlavaCfg(vocab_size=120, text_layers=2, image_layers=2, mm_layers=1, max_position_embeddings=32)
+    m = FlavaKGC(flava_config(vocab_size=120, text_layers=2, image_layers=2, mm_layers=1, max_position_embeddings=32))
+    ref = FO.param_shapes(c)
+    got = {n: tuple(p.shape) for n, p in m.named_parameters()}
+    assert got == ref and list(got) == list(ref)
+    order = flava_layout_order(2, 2, 1)
+    assert sorted(order) == sorted(ref) and len(set(order)) == len(order)
+    for key, members in flava_gemm_groups(2, 2, 1):
+        idx = [order.index(n) for n in members]
+        assert idx == list(range(idx[0], idx[0] + len(idx))), key
+    dead = FLAVA_DEAD((2, 2, 1))
+    assert sum(1 for n in ref if n.startswith(dead)) == 1 + 1 + 4 + 6 + 4 + 2 * (2 + 1)      # == reference None-grad set rule (golden g5: 26 at 3/3/2)
+    assert m.get_input_embeddings().weight is m.get_output_embeddings().weight
+    m.resize_token_embeddings(125)
+    assert m.cls.bias.shape == (125,) and m.get_output_embeddings().weight.shape == (125, 768)
