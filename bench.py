@@ -39,13 +39,21 @@ def fwd_gflop_per_example(P: int, L: int = 64, A: int = 2063) -> float:
     return (patch + vis_lin + vis_att + txt_lin + txt_att + fus + head) / 1e9
 
 
-def build(patch: int, seed: int, device):
+def flava_fwd_gflop_per_example(P: int, L: int = 64, A: int = 2063) -> float:
+    Nv, lin = 1 + 2 * P, 8 * H * H + 4 * H * I
+    Sm = 1 + Nv + L
+    f = 2 * (2 * P) * H * (3 * (224 * 224 // P)) + Nv * lin * 12 + 12 * 4 * Nv * Nv * H + L * lin * 12 + 12 * 4 * L * L * H
+    f += 2 * (Nv + L) * H * H + Sm * lin * 6 + 6 * 4 * Sm * Sm * H + 2 * L * H * H + 2 * A * H
+    return f / 1e9
+
+
+def build(patch: int, seed: int, device, backbone: str = "mkgformer"):
     from mkg_analogy_amd import data_synth as D
     from mkg_analogy_amd.lit_models import TransformerLitModel
-    from mkg_analogy_amd.models import MKGformerKGC, TextConfig, VisionConfig
+    from mkg_analogy_amd.models import FlavaKGC, MKGformerKGC, TextConfig, VisionConfig, flava_config
     torch.manual_seed(seed)
     tcfg = TextConfig()
-    model = MKGformerKGC(VisionConfig(patch_size=patch), tcfg)
+    model = MKGformerKGC(VisionConfig(patch_size=patch), tcfg) if backbone == "mkgformer" else FlavaKGC(flava_config(patch_size=patch))
     # random-init weights of the named architecture (no checkpoints offline): N(0, 0.02) matrices / embeddings
     with torch.no_grad():
         for n, p in model.named_parameters():
@@ -54,7 +62,8 @@ def build(patch: int, seed: int, device):
             if "adaptive_weight.0" in n:
                 p.fill_(0.25)
     cfg = D.data_config()
-    args = argparse.Namespace(label_smoothing=0.1, alpha=0.43, pretrain=0, lr=5e-5, weight_decay=0.01, optimizer="AdamW", warm_up_radio=0.1)
+    args = argparse.Namespace(label_smoothing=0.1, alpha=0.43 if backbone == "mkgformer" else 0.45, pretrain=0, lr=5e-5, weight_decay=0.01,
+                              optimizer="AdamW", warm_up_radio=0.1)
     lit = TransformerLitModel(model=model, args=args, tokenizer=D.FakeTokenizer(), data_config=cfg)
     model.to(device)
     lit._init_relation_word()
@@ -139,6 +148,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="examples per GPU")
     ap.add_argument("--seq-len", type=int, default=64)
     ap.add_argument("--patch", type=int, default=16, help="16 -> 196 patches/image (BASELINE), 32 -> 49 (reference default CLIP-B/32)")
+    ap.add_argument("--model", default="mkgformer", choices=["mkgformer", "flava"], help="flava = BASELINE configs[3] (parity case; not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -153,7 +163,7 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     ops.require_gpu()
     dev = torch.device("cuda", local)
-    model, lit, cfg = build(a.patch, seed=0, device=dev)
+    model, lit, cfg = build(a.patch, seed=0, device=dev, backbone=a.model)
     batch = D.make_batch(a.batch, a.seq_len, seed=1234 + rank, device=dev)
     total = a.steps + a.warmup + 4
     tr = Trainer(max_epochs=1, max_steps=10 * total, world_size=world)
@@ -181,7 +191,7 @@ def main():
     ms = 1000.0 * dt / a.steps
     P = (224 // a.patch) ** 2
     value = a.batch * world * a.steps / dt
-    train_gflop = 3.0 * fwd_gflop_per_example(P, a.seq_len)
+    train_gflop = 3.0 * (fwd_gflop_per_example(P, a.seq_len) if a.model == "mkgformer" else flava_fwd_gflop_per_example(P, a.seq_len))
 
     roof = None
     if not a.no_kernel_timing:
@@ -191,7 +201,7 @@ def main():
         ach = fl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_nt.json")
-        if os.path.exists(pmc) and a.batch == 256 and a.patch == 16 and a.seq_len == 64:
+        if os.path.exists(pmc) and a.batch == 256 and a.patch == 16 and a.seq_len == 64 and a.model == "mkgformer":
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")     # rocprofv3 --pmc passes of this same command
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,256,2,4> (bf16 MFMA 32x32x16 NT GEMM, fused epilogues)", "achieved": round(ach, 1),
                 "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
@@ -205,14 +215,15 @@ def main():
         out = {"metric": "analogy examples/sec (fine-tune step)", "value": round(value, 2), "unit": "examples/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"MKGformer (BERT-base + ViT-B/{a.patch} patches) fine-tune step, MARS-shaped batch", "batch_per_gpu": a.batch,
+               "config": {"workload": (f"MKGformer (BERT-base + ViT-B/{a.patch} patches)" if a.model == "mkgformer" else "FLAVA-base (12+12+6 layers)") +
+                          " fine-tune step, MARS-shaped batch", "batch_per_gpu": a.batch,
                           "global_batch": a.batch * world, "seq_len": a.seq_len, "patches_per_image": P, "vision_tokens": 1 + 2 * P,
                           "entity_head": 2063, "vocab": D.VOCAB, "parallelism": f"dp{world}", "weights": "random-init N(0,0.02)"},
                "loss": round(float(loss), 4), "hits1": metrics.get("Eval_entity/hits1"),
                "train_gflop_per_example": round(train_gflop, 1)}
         if roof is not None:
             out["roofline"] = roof
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and a.model == "mkgformer":
             out["cpu_baseline"] = cpu_baseline(a.patch, a.seq_len)
         print(json.dumps(out), flush=True)
     if world > 1:
