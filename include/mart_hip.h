@@ -50,6 +50,8 @@ typedef struct {
   void* C; int ldc; int c_f32;
   void* C2; int ldc2;                                             /* optional bf16 copy; 0 -> ldc */
   int tile_cfg;                                                   /* 0 auto, 128, 256 */
+  int b_blocked;                                                  /* B (and B2) stored tile-blocked [N/256][K/64][256][64] (mart_block_table): every LDS-DMA stage of the weight
+                                                                     operand is one contiguous 32 KB run instead of 256 strided 128-B rows; needs N % 256 == 0, no b_rows */
 } mart_gemm_nt_desc;
 int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream);
 
@@ -214,6 +216,8 @@ typedef struct {
 int mart_adamw(const mart_adamw_desc* d, void* stream);
 /* batched bf16 transposes described by int64 quadruples (src_off, dst_off, rows, cols) into the W^T shadow */
 int mart_transpose_table(const void* src_bf16, void* dst_bf16, const int64_t* table, int n, void* stream);
+/* row-major [rows, cols] -> tile-blocked [rows/256][cols/64][256][64] per table entry (src_off, dst_off, rows, cols); rows % 256 == 0, cols % 64 == 0 */
+int mart_block_table(const void* src_bf16, void* dst_bf16, const int64_t* table, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ class GemmNT(C.Structure):
                 ("batch", i32), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64), ("stride_aux", i64),
                 ("bias", vp), ("bias2", vp), ("bias_by_brow", i32), ("act", i32), ("preact", vp),
                 ("mulz", vp), ("mul_act", i32), ("res_f32", vp), ("res_bf16", vp), ("ldres", i32),
-                ("alpha", f32), ("C", vp), ("ldc", i32), ("c_f32", i32), ("C2", vp), ("ldc2", i32), ("tile_cfg", i32)]
+                ("alpha", f32), ("C", vp), ("ldc", i32), ("c_f32", i32), ("C2", vp), ("ldc2", i32), ("tile_cfg", i32), ("b_blocked", i32)]
 
 
 class GemmTN(C.Structure):
@@ -108,6 +108,7 @@ _SIGS = {
     "mart_dropout_mask": (i32, [vp, i64, f32, u64, vp]),
     "mart_adamw": (i32, [C.POINTER(AdamW), vp]),
     "mart_transpose_table": (i32, [vp, vp, vp, i32, vp]),
+    "mart_block_table": (i32, [vp, vp, vp, i32, vp]),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -30,6 +30,7 @@ struct Args {
   float alpha;
   void* C; int ldc; int c_f32;
   bf16* C2; int ldc2;
+  int b_blocked;
   int dbg;                           // 1: skip the LDS-DMA after the first tile (timing experiment only)
 };
 
@@ -75,19 +76,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     int gn = min(n0 + row, p.N - 1);
     if (p.b_rows) gn = p.b_rows[gn];
     offB[r] = (unsigned)gn * (unsigned)p.ldb + lc * 8;
+    if (p.b_blocked) offB[r] = (unsigned)(row & 255) * 64 + lc * 8 + (unsigned)(row >> 8) * 0;   // inside the 256x64 block
   }
+  // tile-blocked weights: block (n0/256, kt) of operand with K' columns starts at ((n0/256)*(K'/64) + kt) * 16384 elements
+  const long long blkB1 = p.b_blocked ? (long long)(n0 >> 8) * (p.K >> 6) * 16384 : 0;
+  const long long blkB2 = p.b_blocked ? (long long)(n0 >> 8) * (p.K2 >> 6) * 16384 : 0;
 
   const int nk1 = p.K / BK, nk = nk1 + p.K2 / BK;
 
   auto stage = [&](int t, int buf) {
-    const bf16* Ap = A; const bf16* Bp = B; int k0 = t * BK;
-    if (t >= nk1) { Ap = A2; Bp = B2; k0 = (t - nk1) * BK; }
+    const bf16* Ap = A; const bf16* Bp = B + blkB1; int k0 = t * BK;
+    if (t >= nk1) { Ap = A2; Bp = B2 + blkB2; k0 = (t - nk1) * BK; }
+    const long long kb = p.b_blocked ? (long long)(k0 >> 6) * 16384 : k0;      // blocked: whole 256x64 blocks per K-tile
     char* sA = smem + buf * STAGE;
     char* sB = sA + A_BYTES;
 #pragma unroll
     for (int r = 0; r < RA; ++r) glds16(Ap + offA[r] + k0, sA + (r * NT + wave * 64) * 16);
 #pragma unroll
-    for (int r = 0; r < RB; ++r) glds16(Bp + offB[r] + k0, sB + (r * NT + wave * 64) * 16);
+    for (int r = 0; r < RB; ++r) glds16(Bp + offB[r] + kb, sB + (r * NT + wave * 64) * 16);
   };
 
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
@@ -409,6 +415,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   MART_CHECK((d->K2 == 0) == (d->A2 == nullptr) && (d->K2 == 0) == (d->B2 == nullptr), "gemm_nt: A2/B2/K2 inconsistent");
   MART_CHECK(d->C != nullptr && d->ldc >= d->N, "gemm_nt: bad C/ldc");
   MART_CHECK(!d->bias_by_brow || d->b_rows, "gemm_nt: bias_by_brow needs b_rows");
+  MART_CHECK(!d->b_blocked || (d->N % 256 == 0 && !d->b_rows && (d->batch <= 1 || d->stride_b == 0)), "gemm_nt: b_blocked needs N % 256 == 0, no b_rows, shared B");
   MART_CHECK((long long)d->M * d->lda < (1LL << 32) && (long long)d->N * d->ldb < (1LL << 32) || d->a_rows || d->b_rows,
              "gemm_nt: operand too large for 32-bit element offsets");
   Args a;
@@ -426,8 +433,10 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
   int cfg = d->tile_cfg;
   a.dbg = 0;
+  a.b_blocked = d->b_blocked;
   if (cfg == 999) { a.dbg = 1; cfg = 256; }
-  if (cfg == 0) cfg = (t256 >= 224) ? 256 : 128;
+  if (cfg == 0) cfg = (t256 >= 224 || d->b_blocked) ? 256 : 128;
+  MART_CHECK(!d->b_blocked || cfg == 256 || cfg == 999, "gemm_nt: b_blocked requires the 256x256 tile");
   if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
   if (cfg == 256) return launch<256, 256, 2, 4>(a, batch, st);
   return launch<128, 128, 2, 2>(a, batch, st);

@@ -366,6 +366,19 @@ __global__ void transpose_table_k(const bf16* __restrict__ src, bf16* __restrict
     __syncthreads();
   }
 }
+__global__ void block_table_k(const bf16* __restrict__ src, bf16* __restrict__ dst, const int64_t* __restrict__ table, int n) {
+  const int64_t* e = table + 4LL * blockIdx.y;
+  const bf16* s = src + e[0];
+  bf16* d = dst + e[1];
+  const int R = (int)e[2], C = (int)e[3];
+  const long long chunks = (long long)R * C / 8;                 // 16-byte chunks, destination order
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (long long)gridDim.x * blockDim.x) {
+    const long long blk = i >> 11;                               // 2048 chunks per 256x64 block
+    const int within = (int)(i & 2047), row = within >> 3, ch = within & 7;
+    const int kb = (int)(blk % (C >> 6)), nb = (int)(blk / (C >> 6));
+    *(bf16x8*)(d + i * 8) = *(const bf16x8*)(s + ((long long)nb * 256 + row) * C + kb * 64 + ch * 8);
+  }
+}
 }  // namespace
 
 extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
@@ -459,6 +472,13 @@ extern "C" int mart_transpose_bf16(const void* in, int ldi, long long stride_i, 
 extern "C" int mart_transpose_table(const void* src_bf16, void* dst_bf16, const int64_t* table, int n, void* stream) {
   MART_CHECK(src_bf16 && dst_bf16 && table && n > 0, "transpose_table: bad args");
   hipLaunchKernelGGL(transpose_table_k, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_bf16, (bf16*)dst_bf16, table, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mart_block_table(const void* src_bf16, void* dst_bf16, const int64_t* table, int n, void* stream) {
+  MART_CHECK(src_bf16 && dst_bf16 && table && n > 0, "block_table: bad args");
+  hipLaunchKernelGGL(block_table_k, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const bf16*)src_bf16, (bf16*)dst_bf16, table, n);
   MART_LAUNCH_CHECK();
   return 0;
 }
