@@ -31,6 +31,7 @@ struct Args {
   void* C; int ldc; int c_f32;
   bf16* C2; int ldc2;
   int b_blocked;
+  int stagger_ticks;                 // >0: first-wave workgroups start g*ticks (100 MHz) late, g = 0..7
   int dbg;                           // 1: skip the LDS-DMA after the first tile (timing experiment only)
 };
 
@@ -50,6 +51,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
 
+  if (p.stagger_ticks > 0 && blockIdx.x < 256 && blockIdx.y == 0) {
+    // De-phase the CUs: all first-wave workgroups start together, run the same K loop and would all reach their
+    // epilogue at the same instant -- a 33 MB write burst that the memory side absorbs at ~4.4 TB/s while every
+    // matrix core idles.  Starting eighths of the CUs an eighth of a tile period apart spreads the bursts.
+    const long long t0 = wall_clock64();
+    const long long d = (long long)((blockIdx.x >> 3) & 7) * p.stagger_ticks;
+    while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(32);
+  }
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -179,6 +188,51 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[u][j], af[u][i], acc[i][j]);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all fragment reads of this slot retired before the next barrier
+    }
+  } else if constexpr (PIPE == 2) {
+    // ---- 4 waves, 128x128 per wave (one wave per SIMD, 256 accumulator registers): fragment reads per K-tile drop from
+    // 192 KB to 128 KB, ONE barrier per K-tile, and each wave software-pipelines its own LDS reads under its own MFMAs
+    // (fragments of k-step s+1 -- or of step 0 of the next tile -- are fetched while the 16 MFMAs of step s execute).
+    static_assert(TM == 4 && TN == 4, "PIPE 2 is the 2x2-wave 256x256 configuration");
+    const int key = (l31 >> 1) & 7;                      // same swizzle key for every fragment row of this lane
+    const char* baseA = smem + (wm0 + l31) * 128;
+    const char* baseB = smem + A_BYTES + (wn0 + l31) * 128;
+    bf16x8 fa[2][TM], fb[2][TN];
+    auto rd = [&](int buf, int ks, int slot) {
+      const int co = (((ks * 2 + h) ^ key) << 4) + buf * STAGE;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[slot][i] = *(const bf16x8*)(baseA + co + i * 4096);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[slot][j] = *(const bf16x8*)(baseB + co + j * 4096);
+    };
+    auto mma_half = [&](int slot, int i0) {
+#pragma unroll
+      for (int i = i0; i < i0 + 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(fb[slot][j], fa[slot][i], acc[i][j]);
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    rd(0, 0, 0);
+    for (int t = 0; t < nk; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < nk && !p.dbg) stage(t + 1, buf ^ 1);
+      rd(buf, 1, 1);
+      mma_half(0, 0); mma_half(0, 2);
+      rd(buf, 2, 0);
+      mma_half(1, 0); mma_half(1, 2);
+      rd(buf, 3, 1);
+      mma_half(0, 0); mma_half(0, 2);
+      // tile t+1 landed (own DMA retired, then everybody's); all reads of tile t are retired as well (lgkmcnt(0) is
+      // implied by the MFMAs above having consumed them, the explicit wait covers the step-3 fragments)
+      mma_half(1, 0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nk) rd(buf ^ 1, 0, 0);
+      mma_half(1, 2);
     }
   } else if constexpr (WAVES_M == 2 && WAVES_N == 4) {
     // ---- ping-pong main loop (8 waves).  The two wave-rows of the tile (waves 0-3 / 4-7; waves w and w+4 share a
@@ -351,43 +405,44 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       }
     }
   };
-  // Accumulators -> LDS (f32, one wave-row of the tile at a time, row stride BN+4 floats: conflict-free 16-byte
-  // writes) -> every thread picks 4 consecutive columns of a row so that ALL global epilogue traffic (bias,
-  // residual, pre-activation, output) is coalesced: 64 lanes cover 256 consecutive columns of one row.
-  constexpr int EP_LD = BN + 4;
-  float* ep = (float*)smem;
-  const int wave_m = wave / WAVES_N;
-#pragma unroll 1
-  for (int pass = 0; pass < WAVES_M; ++pass) {
-    __syncthreads();
-    if (wave_m == pass) {
+  // Accumulators -> LDS -> registers, WAVE-PRIVATE: each wave transposes its own WM x WN sub-tile through a private
+  // [32][WN+4] f32 region, one 32-row block at a time (16-byte writes in MFMA layout: conflict-free with the +4 pad;
+  // 16-byte reads with WN/4 lanes covering one row), so that ALL global epilogue traffic (bias, residual,
+  // pre-activation, output) is coalesced: a row segment of WN columns = 128 B of bf16 / 256 B of f32 per request.
+  // No block-level barrier after the first one, and all waves (both SIMD halves of the LDS store path) stay busy.
+  if (p.dbg == 2) return;                                        // timing experiment: no epilogue
+  constexpr int EP_LD = WN + 4;
+  constexpr int LPR = WN / 4, RPI = 64 / LPR;                    // lanes per row, rows per wave-instruction
+  __syncthreads();                                               // every wave is done with the K-loop buffers
+  float* ep = (float*)smem + wave * (32 * EP_LD);
+  const int er = lane / LPR, ec = (lane % LPR) * 4;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *(f32x4*)(ep + (i * 32 + l31) * EP_LD + wn0 + j * 32 + 8 * q + 4 * h) =
-                f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(ep + l31 * EP_LD + j * 32 + 8 * q + 4 * h) =
+            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int row = it * RPI + er;
+      const int m = m0 + wm0 + i * 32 + row, n = n0 + wn0 + ec;
+      const f32x4 a = *(const f32x4*)(ep + row * EP_LD + ec);
+      if (p.dbg == 3) { if (a[0] == 1.2345f) *(float*)p.C = a[1]; }             // timing experiment: LDS staging only
+      else if (m < p.M && n < p.N) emit(m, n, a[0], a[1], a[2], a[3]);
     }
-    __syncthreads();
-    constexpr int QUADS = WM * (BN / 4);
-#pragma unroll 4
-    for (int idx = tid; idx < QUADS; idx += NT) {
-      const int row = idx / (BN / 4), cg = idx % (BN / 4);
-      const int m = m0 + pass * WM + row, n = n0 + cg * 4;
-      if (m < p.M && n < p.N) {
-        const f32x4 a = *(const f32x4*)(ep + row * EP_LD + cg * 4);
-        emit(m, n, a[0], a[1], a[2], a[3]);
-      }
-    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0>
 int launch(const Args& a, int batch, hipStream_t st) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
-  constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2, LDS_EPI = (BM / WAVES_M) * (BN + 4) * 4;
+  constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2, LDS_EPI = WAVES_M * WAVES_N * 32 * (BN / WAVES_N + 4) * 4;
   constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
   static bool attr_set = false;
   auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE>;
@@ -433,11 +488,15 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
   int cfg = d->tile_cfg;
   a.dbg = 0;
+  a.stagger_ticks = 0;
   a.b_blocked = d->b_blocked;
   if (cfg == 999) { a.dbg = 1; cfg = 256; }
+  if (cfg >= 70000 && cfg < 80000) { a.stagger_ticks = cfg - 70000; cfg = 256; }
+  if (cfg == 9992 || cfg == 9993) { a.dbg = cfg - 9990; cfg = 256; }
   if (cfg == 0) cfg = (t256 >= 224 || d->b_blocked) ? 256 : 128;
-  MART_CHECK(!d->b_blocked || cfg == 256 || cfg == 999, "gemm_nt: b_blocked requires the 256x256 tile");
+  MART_CHECK(!d->b_blocked || cfg == 256 || cfg == 999 || cfg == 2564, "gemm_nt: b_blocked requires the 256x256 tile");
   if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
+  if (cfg == 2564 || cfg == 9994) { a.dbg = cfg == 9994; return launch<256, 256, 2, 2, 2>(a, batch, st); }
   if (cfg == 256) return launch<256, 256, 2, 4>(a, batch, st);
   return launch<128, 128, 2, 2>(a, batch, st);
 }

@@ -90,3 +90,42 @@ def make_batch(B: int, L: int, image_size: int = 224, seed: int = 1234, device="
         out["pre_type"] = torch.from_numpy(pt)
         out["label"] = torch.from_numpy(np.where(pt == 2, rng.integers(0, N_REL, size=B), rng.integers(0, N_ENT, size=B)))
     return {k: v.to(device) for k, v in out.items()}
+
+
+def synthetic_wordpiece_vocab(texts, size: int = 30522):
+    """A deterministic stand-in for bert-base-uncased's vocab.txt (not downloadable here): same size and the same ids for
+    the specials ([PAD]=0, [UNK]=100, [CLS]=101, [SEP]=102, [MASK]=103), body built from ``texts`` -- every character and
+    ``##``character (so nothing degenerates to [UNK]), words seen >= 3 times whole, rarer words as a 3-4 letter stem plus
+    ``##`` suffix pieces -- so that WordPiece really splits.  Only used by tests / fixture generation."""
+    from collections import Counter
+    from .data.tokenization import BertWordPieceTokenizer
+    base = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + \
+           [f"[unused{i}]" for i in range(99, 994)]
+    probe = BertWordPieceTokenizer(base)
+    words = Counter()
+    for t in texts:
+        words.update(probe._pre_tokenize(probe._normalize(t)))
+    chars = sorted({c for w in words for c in w})
+    vocab = list(base)
+    seen = set(vocab)
+
+    def add(tok):
+        if tok not in seen and len(vocab) < size:
+            seen.add(tok); vocab.append(tok)
+    for c in chars:
+        add(c)
+    for c in chars:
+        add("##" + c)
+    for w, n in sorted(words.items(), key=lambda kv: (-kv[1], kv[0])):
+        if n >= 3:
+            add(w)
+    for w, n in sorted(words.items(), key=lambda kv: (-kv[1], kv[0])):
+        if n < 3 and len(w) > 4:
+            k = 3 + (len(w) & 1)
+            add(w[:k]); add("##" + w[k:k + 3])
+            if len(w) > k + 3:
+                add("##" + w[k + 3:])
+    i = 994
+    while len(vocab) < size:
+        vocab.append(f"[unused{i}]"); i += 1
+    return vocab
