@@ -260,7 +260,16 @@ class BertWordPieceTokenizer:
     def __call__(self, text: str, text_pair: Optional[str] = None, truncation: Union[bool, str] = False,
                  max_length: Optional[int] = None, padding: Union[bool, str] = False, add_special_tokens: bool = True,
                  **kw) -> Dict[str, List[int]]:
-        """One example (the reference never batches at this level).  ``padding="longest"`` on one example is a no-op."""
+        """One example (processor.py:736-770; ``padding="longest"`` on one example is a no-op) or a list of texts
+        (lit_models/transformer.py:46 ``tokenizer(['[R]'], add_special_tokens=False)``) -> lists of lists, padded to the
+        longest when ``padding`` asks for it."""
+        if isinstance(text, (list, tuple)):
+            pairs = text_pair if text_pair is not None else [None] * len(text)
+            encs = [self(t, p, truncation=truncation, max_length=max_length, padding=False if padding in (True, "longest") else padding,
+                         add_special_tokens=add_special_tokens) for t, p in zip(text, pairs)]
+            if padding in (True, "longest"):
+                return self.pad(encs, padding="longest")
+            return {k: [e[k] for e in encs] for k in encs[0]} if encs else {k: [] for k in self.model_input_names}
         a = self.convert_tokens_to_ids(self.tokenize(text))
         b = self.convert_tokens_to_ids(self.tokenize(text_pair)) if text_pair is not None else None
         n_special = (3 if b is not None else 2) if add_special_tokens else 0

@@ -78,6 +78,7 @@ def test_tokenizer_interface():
     assert tok.add_special_tokens({"additional_special_tokens": ["[ENTITY_0]", "[ENTITY_1]"]}) == 2
     assert tok.get_added_vocab() == {"[ENTITY_0]": 30522, "[ENTITY_1]": 30523} and len(tok) == 30524
     assert tok("x [ENTITY_1] y")["input_ids"][2] == 30523
+    assert tok(["[ENTITY_1]", "[ENTITY_0] [ENTITY_1]"], add_special_tokens=False)["input_ids"] == [[30523], [30522, 30523]]
     # slow-tokenizer longest_first: one token at a time from the longer input, from the pair on a tie
     e = tok("a b c d e f", "a b c d e f", truncation="longest_first", max_length=10)
     assert e["token_type_ids"] == [0] * 6 + [1] * 4                      # 7 of 12 tokens survive: 4 of A, 3 of B

@@ -49,7 +49,7 @@ def world(tmp_path_factory):
     model = MKGformerKGC(VisionConfig(image_size=IMG, patch_size=PATCH), TextConfig())
     lit = TransformerLitModel(model=model, args=args, tokenizer=dm.tokenizer, data_config=dm.get_config())
     vc = O.VisionCfg(image_size=IMG, patch_size=PATCH)
-    sd = O.init_params(vc, O.TextCfg(vocab_size=len(dm.tokenizer) - 1), seed=21)
+    sd = O.init_params(vc, O.TextCfg(vocab_size=len(dm.tokenizer)), seed=21)
     for l in range(8, 12):                     # conditioned weights, see tests/test_model_gpu.py::_condition
         for k in ("weight", "bias"):
             n = f"unimo.encoder.text_layer.{l}.attention.self.value.{k}"
