@@ -54,9 +54,12 @@ class GradSync:
 
     def __init__(self, model, bucket_elems: int = 32 << 20, group=None):
         self.model = model
+        import os
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         st = model.store
-        self.reducer = BucketedAllReduce(st.grad, st.buckets(bucket_elems), group) if self.world > 1 else None
+        # MART_FORCE_PG=1: run the bucketed collectives even in a 1-rank group (exercises the RCCL path on a 1-GPU box)
+        on = self.world > 1 or (dist.is_initialized() and os.environ.get("MART_FORCE_PG") == "1")
+        self.reducer = BucketedAllReduce(st.grad, st.buckets(bucket_elems), group) if on else None
         if self.reducer is not None:
             model.engine.grad_ready = self.reducer.ready
 
@@ -77,7 +80,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, local_rank, world) from torchrun's environment; initialises the default process group when world > 1."""
     import os
     rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("MART_FORCE_PG") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
