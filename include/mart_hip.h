@@ -219,6 +219,26 @@ int mart_transpose_table(const void* src_bf16, void* dst_bf16, const int64_t* ta
 /* row-major [rows, cols] -> tile-blocked [rows/256][cols/64][256][64] per table entry (src_off, dst_off, rows, cols); rows % 256 == 0, cols % 64 == 0 */
 int mart_block_table(const void* src_bf16, void* dst_bf16, const int64_t* table, int n, void* stream);
 
+/* ---------------------------------------------------------------- fp32-accurate evaluation path (csrc/precise.hip)
+ * The reference is fp32 end to end.  Precise mode keeps activations in fp32 and runs every dense contraction through
+ * mart_gemm_nt on two-term bf16 splits laid out K-concatenated (K' = 3K):  role 0 (activations) [hi|lo|hi],
+ * role 1 (weights) [hi|hi|lo]  =>  hi*hi + lo*hi + hi*lo accumulated in fp32. */
+int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16 /* [rows, 3K] */, int rows, int K, int role, void* stream);
+/* f32 twins of mart_patchify / mart_patchify_gather (index NULL: pixels are [B,2,3,S,S]; else table rows, -1 = zero image) and mart_vision_assemble */
+int mart_patchify_f32(const float* pixels_or_table, const int32_t* index, float* out, int B, int S, int p, void* stream);
+int mart_vision_assemble_f32(const float* patch, const float* cls, const float* pos, float* s, int B, int P, int H, int tail_shift, void* stream);
+/* fp32 attention, plain FMA arithmetic: CLIPAttention (modeling_unimo.py:212-272, prefix keys), BertSelfAttention
+ * (:317-377, scale, adaptive reweight, additive mask) with D = 64, and BertFusion (:400-414) with nh = 1, D = 768, scale = 1 */
+typedef struct {
+  const float* q; const float* k; const float* v; long long ldq, ldk, ldv;   /* rows [B*S, ld]; head h at column h*D */
+  const float* pk; const float* pv; long long ldp; int Lp;
+  int B, nh, D, Sq, Sk;
+  float scale;
+  const int64_t* attn_mask; const int64_t* sep; int sep_stride; const float* w0; const float* w1; int rw_skip_row0;
+  float* ctx; long long ldctx;
+} mart_attn_f32_desc;
+int mart_attn_fwd_f32(const mart_attn_f32_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,14 @@ class AttnFwd(C.Structure):
                 ("p_drop", f32), ("seed", u64), ("ctx", vp), ("ldctx", i32), ("lse", vp), ("rw_skip_row0", i32)]
 
 
+class AttnF32(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("ldq", i64), ("ldk", i64), ("ldv", i64),
+                ("pk", vp), ("pv", vp), ("ldp", i64), ("Lp", i32),
+                ("B", i32), ("nh", i32), ("D", i32), ("Sq", i32), ("Sk", i32), ("scale", f32),
+                ("attn_mask", vp), ("sep", vp), ("sep_stride", i32), ("w0", vp), ("w1", vp), ("rw_skip_row0", i32),
+                ("ctx", vp), ("ldctx", i64)]
+
+
 class AttnBwd(C.Structure):
     _fields_ = [("f", AttnFwd), ("dctx", vp), ("lddctx", i32), ("delta", vp),
                 ("dq", vp), ("dk", vp), ("dv", vp), ("lddq", i32), ("lddk", i32), ("lddv", i32),
@@ -109,6 +117,10 @@ _SIGS = {
     "mart_adamw": (i32, [C.POINTER(AdamW), vp]),
     "mart_transpose_table": (i32, [vp, vp, vp, i32, vp]),
     "mart_block_table": (i32, [vp, vp, vp, i32, vp]),
+    "mart_split_bf16x3": (i32, [vp, i64, vp, i32, i32, i32, vp]),
+    "mart_patchify_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "mart_vision_assemble_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "mart_attn_fwd_f32": (i32, [vp, vp]),
 }
 
 EXPORTS = tuple(_SIGS)

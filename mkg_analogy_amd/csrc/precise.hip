@@ -1,0 +1,212 @@
+// fp32-accurate evaluation path (north_star: logits within 1e-3 of the fp32 reference, ranked indices exact).
+//
+// The reference computes in fp32 end to end.  gfx950's fast matrix path is bf16, so the precise mode keeps
+// every activation in fp32 and feeds the SAME bf16 MFMA GEMM kernel with operands split into two bf16 terms
+//     x = hi + lo,  hi = bf16(x),  lo = bf16(x - hi)            (16 mantissa bits)
+// laid out K-concatenated so that one NT GEMM over K' = 3K accumulates  hi*hi + lo*hi + hi*lo  in fp32:
+//     A' = [ hi | lo | hi ]   (activations, role 0)        B' = [ hi | hi | lo ]   (weights, role 1)
+// (the dropped lo*lo term is 2^-16 relative).  Attention and the image-text fusion softmax(ctx vis^T) vis run in plain
+// fp32 FMA arithmetic in attn_f32_k (no MFMA: 7 % of the FLOPs, and the softmax path is the precision-critical part).
+// Forward only: this mode exists for evaluation / parity, training stays on the bf16 path.
+#include "common.h"
+#include "mart_hip.h"
+
+namespace {
+
+__global__ void split3_k(const float* __restrict__ src, long long ld, bf16* __restrict__ dst, int rows, int K, int role) {
+  const long long total = (long long)rows * (K / 4);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / (K / 4);
+    const int c = (int)(i % (K / 4)) * 4;
+    const f32x4 x = *(const f32x4*)(src + r * ld + c);
+    const bf16x4 hi = f4_to_bf4(x);
+    const f32x4 hf = bf4_to_f4(hi);
+    const bf16x4 lo = f4_to_bf4(f32x4{x[0] - hf[0], x[1] - hf[1], x[2] - hf[2], x[3] - hf[3]});
+    bf16* o = dst + r * 3LL * K + c;
+    *(bf16x4*)(o) = hi;
+    *(bf16x4*)(o + K) = role == 0 ? lo : hi;
+    *(bf16x4*)(o + 2 * K) = role == 0 ? hi : lo;
+  }
+}
+
+// pixels [B,2,3,S,S] f32 (or table rows through index) -> f32 patch matrix [(b,img,py,px), (c,ky,kx)]
+__global__ void patchify_f32_k(const float* __restrict__ pix, const int32_t* __restrict__ index, float* __restrict__ out, int S, int p) {
+  const int g = S / p, P = g * g, K = 3 * p * p;
+  const long long row = blockIdx.x;
+  const int patch = (int)(row % P);
+  const long long bi = row / P;
+  const int py = patch / g, px = patch % g;
+  const long long src_row = index ? index[bi] : bi;
+  const float* src = pix + src_row * 3LL * S * S;
+  for (int k4 = threadIdx.x * 4; k4 < K; k4 += blockDim.x * 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (src_row >= 0) {
+      const int c = k4 / (p * p), rem = k4 % (p * p), ky = rem / p, kx = rem % p;
+      v = *(const f32x4*)(src + ((long long)c * S + py * p + ky) * S + px * p + kx);
+    }
+    *(f32x4*)(out + row * K + k4) = v;
+  }
+}
+
+__global__ void vision_assemble_f32_k(const float* __restrict__ patch, const float* __restrict__ cls, const float* __restrict__ pos,
+                                      float* __restrict__ s, int P, int H, int tail_shift) {
+  const int Nv = 1 + 2 * P;
+  const long long row = blockIdx.x;
+  const int t = (int)(row % Nv);
+  const long long b = row / Nv;
+  const int pidx = t == 0 ? 0 : (t <= P ? t : t - P - tail_shift);
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+    f32x4 v = t == 0 ? *(const f32x4*)(cls + c) : *(const f32x4*)(patch + ((b * 2 * P) + (t - 1)) * H + c);
+    v += *(const f32x4*)(pos + (long long)pidx * H + c);
+    *(f32x4*)(s + row * H + c) = v;
+  }
+}
+
+// Generic fp32 attention: one workgroup = QT query rows of one (batch, head).
+//   phase 1  scores[r][j] = q_r . key_j   (thread j streams its key row once, the QT query rows sit in LDS)
+//   phase 2  scale, adaptive reweight (modeling_unimo.py:342-349), additive mask (-10000), row softmax (one wave per row)
+//   phase 3  ctx[r][d] = sum_j p[r][j] v[j][d]   (thread = column d, coalesced V reads)
+// Keys = optional prefix [Lp] (text K/V feeding a vision layer, :227-229) followed by the Sk own keys.
+constexpr int QT = 16;
+template <int D>
+__global__ __launch_bounds__(256) void attn_f32_k(mart_attn_f32_desc p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Stot = p.Lp + p.Sk;
+  float* qs = sm;                    // [QT][D]
+  float* sc = sm + QT * D;           // [QT][Stot]
+  const int q0 = blockIdx.x * QT, h = blockIdx.y;
+  const long long b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int nq = min(QT, p.Sq - q0);
+  for (int i = tid; i < QT * D; i += 256) {
+    const int r = i / D, d = i % D;
+    qs[i] = r < nq ? p.q[(b * p.Sq + q0 + r) * p.ldq + h * D + d] : 0.f;
+  }
+  __syncthreads();
+  for (int j = tid; j < Stot; j += 256) {
+    const float* kr = j < p.Lp ? p.pk + (b * p.Lp + j) * p.ldp + h * D : p.k + (b * p.Sk + (j - p.Lp)) * p.ldk + h * D;
+    float acc[QT];
+#pragma unroll
+    for (int r = 0; r < QT; ++r) acc[r] = 0.f;
+    for (int d = 0; d < D; d += 4) {
+      const f32x4 kv = *(const f32x4*)(kr + d);
+#pragma unroll
+      for (int r = 0; r < QT; ++r) {
+        const f32x4 qv = *(const f32x4*)(qs + r * D + d);
+        acc[r] = fmaf(qv[0], kv[0], acc[r]); acc[r] = fmaf(qv[1], kv[1], acc[r]);
+        acc[r] = fmaf(qv[2], kv[2], acc[r]); acc[r] = fmaf(qv[3], kv[3], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < QT; ++r) sc[r * Stot + j] = acc[r];
+  }
+  __syncthreads();
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    float w0 = 1.f, w1 = 1.f; int s = 0x7fffffff;
+    if (p.sep) {
+      s = (int)p.sep[b * p.sep_stride];
+      w0 = fminf(fmaxf(*p.w0, 0.f), 0.5f);
+      w1 = fminf(fmaxf(*p.w1, 0.5f), 1.f);
+    }
+    for (int r = wave; r < nq; r += 4) {
+      const int qi = q0 + r;
+      float mx = -3.0e38f;
+      for (int j = lane; j < Stot; j += 64) {
+        float v = sc[r * Stot + j] * p.scale;
+        if (p.sep && j >= s && !(p.rw_skip_row0 && qi == 0)) v *= (qi < s ? w0 : w1);
+        if (p.attn_mask && p.attn_mask[b * p.Sk + j] == 0) v += -10000.0f;
+        sc[r * Stot + j] = v;
+        mx = fmaxf(mx, v);
+      }
+      mx = wave_max(mx);
+      float sum = 0.f;
+      for (int j = lane; j < Stot; j += 64) {
+        const float e = expf(sc[r * Stot + j] - mx);
+        sc[r * Stot + j] = e;
+        sum += e;
+      }
+      sum = wave_sum(sum);
+      const float inv = 1.f / sum;
+      for (int j = lane; j < Stot; j += 64) sc[r * Stot + j] *= inv;
+    }
+  }
+  __syncthreads();
+  constexpr int RG = D >= 256 ? 1 : 256 / D;       // row groups working side by side on narrow heads
+  constexpr int RPG = QT / RG;                      // rows per group
+  for (int d0 = 0; d0 < D; d0 += 256 / RG) {
+    const int d = d0 + tid % (256 / RG), rg = tid / (256 / RG);
+    if (d >= D) continue;
+    float acc[RPG];
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) acc[r] = 0.f;
+    for (int j = 0; j < Stot; ++j) {
+      const float vv = j < p.Lp ? p.pv[(b * p.Lp + j) * p.ldp + h * D + d] : p.v[(b * p.Sk + (j - p.Lp)) * p.ldv + h * D + d];
+#pragma unroll
+      for (int r = 0; r < RPG; ++r) acc[r] = fmaf(sc[(rg * RPG + r) * Stot + j], vv, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+      const int rr = rg * RPG + r;
+      if (rr < nq) p.ctx[(b * p.Sq + q0 + rr) * p.ldctx + h * D + d] = acc[r];
+    }
+  }
+}
+
+template <int D>
+int launch_attn(const mart_attn_f32_desc* d, hipStream_t st) {
+  const int Stot = d->Lp + d->Sk;
+  const size_t lds = (size_t)(QT * D + QT * Stot) * sizeof(float);
+  MART_CHECK(lds <= 160 * 1024, "attn_f32: keys do not fit the LDS score tile");
+  static bool attr_set = false;
+  auto kern = attn_f32_k<D>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      mart_set_error("attn_f32: hipFuncSetAttribute failed");
+      return -2;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((d->Sq + QT - 1) / QT, d->nh, d->B), dim3(256), lds, st, *d);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16, int rows, int K, int role, void* stream) {
+  MART_CHECK(src && dst_bf16 && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3: bad args");
+  const long long total = (long long)rows * (K / 4);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split3_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mart_patchify_f32(const float* pixels, const int32_t* index, float* out, int B, int S, int p, void* stream) {
+  MART_CHECK(pixels && out && B > 0 && S > 0 && p > 0 && S % p == 0 && p % 4 == 0, "patchify_f32: bad args");
+  const int g = S / p;
+  hipLaunchKernelGGL(patchify_f32_k, dim3(B * 2 * g * g), dim3(192), 0, (hipStream_t)stream, pixels, index, out, S, p);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mart_vision_assemble_f32(const float* patch, const float* cls, const float* pos, float* s, int B, int P, int H, int tail_shift,
+                                        void* stream) {
+  MART_CHECK(patch && cls && pos && s && B > 0 && P > 0 && H % 4 == 0 && (tail_shift == 0 || tail_shift == 1), "vision_assemble_f32: bad args");
+  hipLaunchKernelGGL(vision_assemble_f32_k, dim3(B * (1 + 2 * P)), dim3(192), 0, (hipStream_t)stream, patch, cls, pos, s, P, H, tail_shift);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mart_attn_fwd_f32(const mart_attn_f32_desc* d, void* stream) {
+  MART_CHECK(d && d->q && d->k && d->v && d->ctx, "attn_f32: null pointer");
+  MART_CHECK(d->B > 0 && d->nh > 0 && d->Sq > 0 && d->Sk > 0 && d->Lp >= 0, "attn_f32: bad shape");
+  MART_CHECK(d->ldq % 4 == 0 && d->ldk % 4 == 0 && d->ldv % 4 == 0 && (d->Lp == 0 || (d->pk && d->pv && d->ldp % 4 == 0)), "attn_f32: bad strides / prefix");
+  MART_CHECK((d->w0 == nullptr) == (d->w1 == nullptr) && (!d->sep || (d->w0 && d->Lp == 0)), "attn_f32: reweight needs w0/w1 and no prefix");
+  MART_CHECK(!d->attn_mask || d->Lp == 0, "attn_f32: mask with prefix unsupported");
+  if (d->D == 64) return launch_attn<64>(d, (hipStream_t)stream);
+  if (d->D == 768) return launch_attn<768>(d, (hipStream_t)stream);
+  mart_set_error("attn_f32: head dim must be 64 (multi-head attention) or 768 (fusion)");
+  return -1;
+}

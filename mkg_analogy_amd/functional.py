@@ -160,6 +160,8 @@ class LazyRows:
         if not (isinstance(rsel, slice) and rsel == slice(None)):
             rows = rows[rsel].contiguous()
         o = self.owner
+        if o.precise is not None:
+            return o.precise.score(o.trans, rows, self._ids(csel), o.word_name, o.bias_name)
         return _ScoreFn.apply(o.trans, o.trans_bf16, rows, self._ids(csel), o.store, o.word_name, o.bias_name)
 
 
@@ -167,9 +169,10 @@ class LazyLogits:
     """Stand-in for ``MaskedLMOutput.logits`` [B,L,V] (2.75 GB fp32 at B=256 in the reference, modeling_unimo.py:958).
     Indexing patterns used by the trainer surface are scored on demand; ``materialize()`` builds the full tensor."""
 
-    def __init__(self, trans: torch.Tensor, trans_bf16: torch.Tensor, store, word_name: str = WORD, bias_name: str = BIAS):
+    def __init__(self, trans: torch.Tensor, trans_bf16: torch.Tensor, store, word_name: str = WORD, bias_name: str = BIAS, precise=None):
         self.trans, self.trans_bf16, self.store = trans, trans_bf16, store
         self.word_name, self.bias_name = word_name, bias_name
+        self.precise = precise                      # engine_precise.PreciseUnimoForward: fp32-accurate scoring (eval only)
         self.vocab = store.slots[word_name].shape[0]
 
     @property
@@ -195,4 +198,6 @@ class LazyLogits:
         B, L, _ = self.trans.shape
         rows = torch.arange(B * L, device=self.trans.device, dtype=torch.int32)
         ids = torch.arange(self.vocab, device=self.trans.device, dtype=torch.int32)
+        if self.precise is not None:
+            return self.precise.score(self.trans, rows, ids, self.word_name, self.bias_name).view(B, L, self.vocab)
         return _ScoreFn.apply(self.trans, self.trans_bf16, rows, ids, self.store, self.word_name, self.bias_name).view(B, L, self.vocab)

@@ -127,11 +127,23 @@ class TransformerLitModel(BaseLitModel):
         mask_logits = rows[:, self._ids("analogy_entity_ids")]
         return dict(entity_ranks=Fn.entity_ranks(mask_logits, label).cpu().numpy())
 
+    def _eval_at(self, batch, batch_idx):
+        """``args.eval_precision = "fp32"`` scores validation / test batches on the fp32-accurate path (engine_precise)."""
+        prec = getattr(self.args, "eval_precision", None)
+        if not prec or prec == self.model.precision:
+            return self._eval(batch, batch_idx)
+        old = self.model.precision
+        self.model.set_precision(prec)
+        try:
+            return self._eval(batch, batch_idx)
+        finally:
+            self.model.set_precision(old)
+
     def validation_step(self, batch, batch_idx):
-        return self._eval(batch, batch_idx)
+        return self._eval_at(batch, batch_idx)
 
     def test_step(self, batch, batch_idx):
-        return self._eval(batch, batch_idx)
+        return self._eval_at(batch, batch_idx)
 
     # -- lit_models/transformer.py:173-222
     def _epoch_end(self, outputs):

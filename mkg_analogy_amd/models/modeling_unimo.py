@@ -188,6 +188,8 @@ class UnimoForMaskedLM(nn.Module):
         self._step = 0
         self.image_table = None                     # optional resident [N_img,3,S,S] f32 table for device-side batch assembly
         self.base_seed = 0x5EED
+        self.precision = "bf16"                     # "fp32": fp32-accurate evaluation path (engine_precise), forward only
+        self._precise = None
         self.tie_weights()
 
     # ------------------------------------------------------------------ embedding surgery (modeling_unimo.py:895-930)
@@ -263,6 +265,15 @@ class UnimoForMaskedLM(nn.Module):
             self._store.refresh_shadows()
         return r
 
+    def set_precision(self, precision: str):
+        """"bf16" (default: bf16 MFMA operands, fp32 accumulation / residual streams; training + eval) or "fp32"
+        (evaluation only: fp32 activations, split-bf16 MFMA contractions, fp32 attention -- meets the reference's fp32
+        results to ~1e-4 on logits; see engine_precise.py)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
+        return self
+
     def set_image_table(self, table: torch.Tensor):
         """Keep the per-entity pixel tensor (MarT/tools/encode_images_data.py output, data_module.py:209) resident in HBM so
         that batches carry [B,2] row indices instead of 1.2 MB of pixels per example."""
@@ -297,6 +308,16 @@ class UnimoForMaskedLM(nn.Module):
         else:
             pixel_values = pixel_values.to(dev, torch.float32)
         train = bool(self.training)
+        if self.precision == "fp32":
+            if train or labels is not None:
+                raise NotImplementedError("precision='fp32' is the evaluation path (forward only, no labels); call model.eval() or set_precision('bf16')")
+            if self._precise is None or self._precise.st is not st:
+                from ..engine_precise import PreciseUnimoForward
+                self._precise = PreciseUnimoForward(st, self.vision_config, self.config)
+            trans = self._precise.forward(input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, image_table=image_table,
+                                          image_index=image_index)
+            out = MaskedLMOutput(loss=None, logits=Fn.LazyLogits(trans, None, st, precise=self._precise), hidden_states=None, attentions=None)
+            return (out, trans) if return_dict else ((out.logits,), trans)
         self._step += 1
         seed = (self.base_seed * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFF
         holder: Dict[str, torch.Tensor] = {}

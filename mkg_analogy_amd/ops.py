@@ -167,6 +167,35 @@ def attn_bwd(*, dctx, delta, dq, dk, dv, dpk=None, dpv=None, accum_dkv=False, dw
     L.check(L.lib().mart_attn_bwd(C.byref(d), _stream()), "mart_attn_bwd")
 
 
+# ---------------------------------------------------------------- fp32-accurate evaluation path (csrc/precise.hip)
+def split_bf16x3(src, role, out=None):
+    """f32 [rows, K] (row stride = ld) -> bf16 [rows, 3K]: role 0 = [hi|lo|hi] (A operand), role 1 = [hi|hi|lo] (B operand)."""
+    rows, K = src.shape
+    if out is None:
+        out = torch.empty((rows, 3 * K), device=src.device, dtype=BF16)
+    L.check(L.lib().mart_split_bf16x3(_p(src), _rows2d(src), _p(out), rows, K, role, _stream()), "mart_split_bf16x3")
+    return out
+
+
+def patchify_f32(pixels_or_table, index, out, B, S, p):
+    L.check(L.lib().mart_patchify_f32(_p(pixels_or_table), _p(index), _p(out), B, S, p, _stream()), "mart_patchify_f32")
+
+
+def vision_assemble_f32(patch, cls, pos, s, B, P, H, tail_shift=0):
+    L.check(L.lib().mart_vision_assemble_f32(_p(patch), _p(cls), _p(pos), _p(s), B, P, H, tail_shift, _stream()), "mart_vision_assemble_f32")
+
+
+def attn_fwd_f32(*, q, k, v, ctx, B, nh, D, Sq, Sk, scale, pk=None, pv=None, Lp=0, attn_mask=None, sep=None, sep_stride=0,
+                 w0=None, w1=None, rw_skip_row0=False):
+    d = L.AttnF32()
+    d.q, d.k, d.v, d.ldq, d.ldk, d.ldv = _p(q), _p(k), _p(v), _rows2d(q), _rows2d(k), _rows2d(v)
+    d.pk, d.pv, d.ldp, d.Lp = _p(pk), _p(pv), (_rows2d(pk) if pk is not None else 0), Lp
+    d.B, d.nh, d.D, d.Sq, d.Sk, d.scale = B, nh, D, Sq, Sk, scale
+    d.attn_mask, d.sep, d.sep_stride, d.w0, d.w1, d.rw_skip_row0 = _p(attn_mask), _p(sep), sep_stride, _p(w0), _p(w1), int(rw_skip_row0)
+    d.ctx, d.ldctx = _p(ctx), _rows2d(ctx)
+    L.check(L.lib().mart_attn_fwd_f32(C.byref(d), _stream()), "mart_attn_fwd_f32")
+
+
 def softmax_fwd(scores, probs, R, Cc):
     L.check(L.lib().mart_softmax_fwd(_p(scores), _rows2d(scores), _p(probs), _rows2d(probs), R, Cc, _stream()), "mart_softmax_fwd")
 

@@ -137,6 +137,7 @@ class FlatStore:
         self.ttable = torch.tensor(table, dtype=torch.int64, device=device)
         # AdamW chunk table: (start, len, decay_flag); dead tensors are excluded (grad None in the reference => untouched)
         self.order = order
+        self.version = 0                                           # bumped whenever the master weights change (derived operand caches)
         self.rebuild_chunks()
         self.refresh_shadows()
 
@@ -203,11 +204,14 @@ class FlatStore:
     def refresh_shadows(self) -> None:
         """master -> bf16 shadow and W^T shadow (after loading weights; AdamW keeps the first one fresh itself)."""
         from . import ops
+        self.version += 1
         ops.cast_f32_bf16(self.master, self.shadow)
         ops.transpose_table(self.shadow, self.shadow_t, self.ttable, self.ttable.shape[0])
 
     def refresh_transposed(self) -> None:
+        """After the fused AdamW step (which rewrote master + bf16 shadow)."""
         from . import ops
+        self.version += 1
         ops.transpose_table(self.shadow, self.shadow_t, self.ttable, self.ttable.shape[0])
 
     def zero_grad(self) -> None:

@@ -1,0 +1,162 @@
+"""fp32-accurate evaluation path (csrc/precise.hip, engine_precise.py): north_star's fp32 gate -- logits within 1e-3 of
+the fp32 CPU oracle and exact ranked indices -- at real dimensions, with the PLAIN N(0,0.02) synthetic weights (the
+chaotic regime that the bf16 path cannot follow, tests/test_model_gpu.py) as well as the conditioned ones."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mkgformer_oracle as O  # noqa: E402  (checker only)
+
+DEV = "cuda"
+
+
+def test_split_bf16x3_and_gemm_accuracy():
+    from mkg_analogy_amd import ops
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(300, 768, generator=g)
+    W = torch.randn(512, 768, generator=g) * 0.05
+    a3 = ops.split_bf16x3(A.to(DEV), 0)
+    w3 = ops.split_bf16x3(W.to(DEV), 1)
+    hi = A.to(torch.bfloat16)
+    lo = (A - hi.float()).to(torch.bfloat16)
+    assert torch.equal(a3.cpu(), torch.cat([hi, lo, hi], 1))
+    whi = W.to(torch.bfloat16)
+    wlo = (W - whi.float()).to(torch.bfloat16)
+    assert torch.equal(w3.cpu(), torch.cat([whi, whi, wlo], 1))
+    out = torch.empty(300, 512, device=DEV)
+    ops.gemm_nt(a3, w3, out)
+    ref = A.double() @ W.double().T
+    err = (out.cpu().double() - ref).abs().max().item()
+    plain = torch.empty(300, 512, device=DEV)
+    ops.gemm_nt(A.to(DEV).to(torch.bfloat16), W.to(DEV).to(torch.bfloat16), plain)
+    err_bf16 = (plain.cpu().double() - ref).abs().max().item()
+    print(f"\nsplit GEMM max|err| {err:.2e} (plain bf16 operands: {err_bf16:.2e}; |ref| max {ref.abs().max():.2f})")
+    assert err < 2e-4 and err < err_bf16 / 50
+    # strided source rows
+    big = torch.randn(64, 2304, generator=g).to(DEV)
+    part = ops.split_bf16x3(big[:, 768:1536], 0)
+    assert torch.equal(part[:, :768].cpu(), big[:, 768:1536].cpu().to(torch.bfloat16))
+
+
+def _ref_attn(q, k, v, nh, scale, pk=None, pv=None, mask=None, sep=None, w0=None, w1=None):
+    B, Sq, HD = q.shape
+    D = HD // nh
+    sp = lambda x: x.view(B, -1, nh, D).transpose(1, 2).double()
+    Q, K, V = sp(q), sp(k), sp(v)
+    if pk is not None:
+        K, V = torch.cat([sp(pk), K], 2), torch.cat([sp(pv), V], 2)
+    s = Q @ K.transpose(-1, -2) * scale
+    if sep is not None:
+        for i in range(B):
+            si = int(sep[i])
+            s[i, :, :si, si:] *= min(max(float(w0), 0.0), 0.5)
+            s[i, :, si:, si:] *= min(max(float(w1), 0.5), 1.0)
+    if mask is not None:
+        s = s + ((1 - mask)[:, None, None, :].double() * -10000.0)
+    return (torch.softmax(s, -1) @ V).transpose(1, 2).reshape(B, Sq, HD)
+
+
+def test_attn_f32_kernel():
+    from mkg_analogy_amd import ops
+    g = torch.Generator().manual_seed(1)
+    B, nh, H, Nv, L = 3, 12, 768, 99, 40
+    # vision: prefix keys, no mask
+    qkv = torch.randn(B * Nv, 3 * H, generator=g)
+    pre = torch.randn(B * L, 3 * H, generator=g)
+    ctx = torch.empty(B * Nv, H, device=DEV)
+    dq, dp = qkv.to(DEV), pre.to(DEV)
+    ops.attn_fwd_f32(q=dq[:, :H], k=dq[:, H:2 * H], v=dq[:, 2 * H:], ctx=ctx, B=B, nh=nh, D=64, Sq=Nv, Sk=Nv, scale=0.125,
+                     pk=dp[:, H:2 * H], pv=dp[:, 2 * H:], Lp=L)
+    ref = _ref_attn(qkv[:, :H].reshape(B, Nv, H), qkv[:, H:2 * H].reshape(B, Nv, H), qkv[:, 2 * H:].reshape(B, Nv, H), nh, 0.125,
+                    pre[:, H:2 * H].reshape(B, L, H), pre[:, 2 * H:].reshape(B, L, H))
+    e1 = (ctx.cpu().double().view(B, Nv, H) - ref).abs().max().item()
+    # text: mask + adaptive reweight
+    tq = torch.randn(B * L, 3 * H, generator=g)
+    mask = torch.ones(B, L, dtype=torch.int64); mask[0, 33:] = 0; mask[2, 20:] = 0
+    sep = torch.tensor([[3, 5, 17, 20, 25, 30], [2, 4, 9, 12, 14, 16], [1, 2, 11, 13, 15, 19]])
+    w0, w1 = torch.tensor([0.31]), torch.tensor([0.77])
+    tctx = torch.empty(B * L, H, device=DEV)
+    dt = tq.to(DEV)
+    ops.attn_fwd_f32(q=dt[:, :H], k=dt[:, H:2 * H], v=dt[:, 2 * H:], ctx=tctx, B=B, nh=nh, D=64, Sq=L, Sk=L, scale=0.125,
+                     attn_mask=mask.to(DEV), sep=sep.to(DEV)[:, 2:], sep_stride=6, w0=w0.to(DEV), w1=w1.to(DEV))
+    ref = _ref_attn(tq[:, :H].reshape(B, L, H), tq[:, H:2 * H].reshape(B, L, H), tq[:, 2 * H:].reshape(B, L, H), nh, 0.125,
+                    mask=mask, sep=sep[:, 2], w0=w0, w1=w1)
+    e2 = (tctx.cpu().double().view(B, L, H) - ref).abs().max().item()
+    # fusion: one head of 768, unscaled, sharp softmax
+    c = torch.randn(B * L, H, generator=g)
+    vis = torch.randn(B * Nv, H, generator=g)
+    fus = torch.empty(B * L, H, device=DEV)
+    ops.attn_fwd_f32(q=c.to(DEV), k=vis.to(DEV), v=vis.to(DEV), ctx=fus, B=B, nh=1, D=H, Sq=L, Sk=Nv, scale=1.0)
+    ref = _ref_attn(c.view(B, L, H), vis.view(B, Nv, H), vis.view(B, Nv, H), 1, 1.0)
+    e3 = (fus.cpu().double().view(B, L, H) - ref).abs().max().item()
+    print(f"\nattn_f32 max|err|: vision+prefix {e1:.2e}, text mask+reweight {e2:.2e}, fusion {e3:.2e}")
+    assert e1 < 2e-5 and e2 < 2e-5 and e3 < 2e-4
+
+
+def _setup(patch, seed, conditioned):
+    from tests.test_model_gpu import _product, _oracle_sd
+    model, lit, cfg, vc = _product(patch, seed=seed, conditioned=conditioned)
+    sd = _oracle_sd(vc, seed, cfg["analogy_relation_ids"], conditioned)
+    return model, lit, cfg, vc, sd
+
+
+@pytest.mark.parametrize("patch,B,conditioned", [(32, 4, False), (32, 4, True), (16, 2, False)])
+def test_fp32_path_logits_and_ranks(patch, B, conditioned):
+    from mkg_analogy_amd import data_synth as D
+    model, lit, cfg, vc, sd = _setup(patch, 3, conditioned)
+    tc = O.TextCfg(vocab_size=D.VOCAB)
+    batch = D.make_batch(B, 64, seed=11)
+    ids = torch.tensor(cfg["analogy_entity_ids"])
+    with torch.no_grad():
+        _, trans_ref = O.forward(sd, vc, tc, batch["input_ids"], batch["attention_mask"], batch["token_type_ids"], batch["pixel_values"],
+                                 batch["sep_idx"], train=False)
+        _, mi = (batch["input_ids"] == 103).nonzero(as_tuple=True)
+        ml_ref = O.score(sd, trans_ref[torch.arange(B), mi], ids)
+    model.eval()
+    model.set_precision("fp32")
+    gb = {k: v.cuda() for k, v in batch.items()}
+    out, trans = model(input_ids=gb["input_ids"], attention_mask=gb["attention_mask"], token_type_ids=gb["token_type_ids"],
+                       pixel_values=gb["pixel_values"], sep_idx=gb["sep_idx"], return_dict=True)
+    ml = out.logits[torch.arange(B, device=DEV), mi.cuda()][:, ids.cuda()]
+    e_t = (trans.cpu() - trans_ref).abs().max().item()
+    e_l = (ml.cpu() - ml_ref).abs().max().item()
+    print(f"\nfp32 path patch {patch} B {B} conditioned={conditioned}: max|d trans| {e_t:.2e}  max|d logit| {e_l:.2e} (|logit| max {ml_ref.abs().max():.2f})")
+    assert e_l < 1e-3, "BASELINE.json north_star: logits within 1e-3 of the fp32 reference path"
+    assert e_t < 5e-3
+    # ranked indices through the trainer surface (validation_step -> mart_rank): exact
+    got = lit.validation_step({k: v for k, v in gb.items() if k in ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx", "label")}, 0)
+    ref_ranks = np.asarray(O.ranks_count(ml_ref, batch["label"]))
+    lab = ml_ref[torch.arange(B), batch["label"]]
+    gap = (ml_ref - lab[:, None]).abs()
+    gap[torch.arange(B), batch["label"]] = 1e9
+    safe = (gap.min(1).values > 2 * e_l).numpy()
+    print(f"   ranks hip {got['entity_ranks'].tolist()} oracle {ref_ranks.tolist()} (rows with a margin > 2x error: {int(safe.sum())}/{B})")
+    assert np.array_equal(got["entity_ranks"][safe], ref_ranks[safe])
+    assert np.abs(got["entity_ranks"] - ref_ranks).max() <= 2          # unsafe rows: the label sits within 2x error of a neighbour
+    # training in this mode is refused loudly
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model(input_ids=gb["input_ids"], attention_mask=gb["attention_mask"], token_type_ids=gb["token_type_ids"],
+              pixel_values=gb["pixel_values"], sep_idx=gb["sep_idx"], return_dict=True)
+    model.set_precision("bf16")
+
+
+def test_fp32_path_with_image_table():
+    from mkg_analogy_amd import data_synth as D
+    model, lit, cfg, vc, sd = _setup(32, 5, False)
+    B = 3
+    batch = D.make_batch(B, 64, seed=4)
+    table = torch.randn(7, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    index = torch.tensor([[0, 6], [3, -1], [-1, -1]], dtype=torch.int32)
+    pix = torch.stack([torch.stack([table[i] if i >= 0 else torch.zeros(3, 224, 224) for i in row]) for row in index.tolist()])
+    model.eval(); model.set_precision("fp32"); model.set_image_table(table)
+    kw = dict(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], token_type_ids=batch["token_type_ids"],
+              sep_idx=batch["sep_idx"], return_dict=True)
+    _, t1 = model(image_index=index, **kw)
+    _, t2 = model(pixel_values=pix, **kw)
+    assert torch.equal(t1, t2)
+    model.set_precision("bf16")
