@@ -31,6 +31,16 @@ __device__ __forceinline__ const bf16* side_row(const Side& s, int b, int h, int
   return s.own + ((long long)b * s.n_own + (j - s.n_pre)) * s.ld_own + h * 64;
 }
 
+// Loop-top barrier of the double-buffered tile loops.  The explicit vmcnt(0) is REQUIRED: the LDS-DMA of the tile about
+// to be read was issued by all four waves, and waves that skip the compute body (query / key rows past the end) would
+// otherwise reach the barrier with their quarter of the tile still in flight -- the compiler only places its own wait
+// in front of the LDS reads of the compute body, not in front of s_barrier.  (Seen as rare NaNs in dQ of the last,
+// partial query tile at B=256.)
+__device__ __forceinline__ void tile_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 // stage one 64x64 tile (rows r0..r0+63 of `s`) into LDS with the chunk swizzle c' = c ^ ((row>>1)&7)
 __device__ __forceinline__ void stage_tile(const Side& s, int b, int h, int r0, char* lds, int tid, int wave) {
 #pragma unroll
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
   stage_tile(K, b, h, 0, smem, tid, wave);
   stage_tile(V, b, h, 0, smem + TILE_BYTES, tid, wave);
   for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();
+    tile_barrier();
     if (kt + 1 < ntiles) {
       char* nb = smem + ((kt + 1) & 1) * STAGE_BYTES;
       stage_tile(K, b, h, (kt + 1) * 64, nb, tid, wave);
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
   stage_tile(K, b, h, 0, smem, tid, wave);
   stage_tile(V, b, h, 0, smem + TILE_BYTES, tid, wave);
   for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();
+    tile_barrier();
     if (kt + 1 < ntiles) {
       char* nb = smem + ((kt + 1) & 1) * STAGE_BYTES;
       stage_tile(K, b, h, (kt + 1) * 64, nb, tid, wave);
@@ -437,7 +447,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
   stage_tile(G, b, h, 0, smem + TILE_BYTES, tid, wave);
   stage_stats(0, smem);
   for (int qt = 0; qt < ntiles; ++qt) {
-    __syncthreads();
+    tile_barrier();
     if (qt + 1 < ntiles) {
       char* nb = smem + ((qt + 1) & 1) * STAGE_BYTES;
       stage_tile(Q, b, h, (qt + 1) * 64, nb, tid, wave);

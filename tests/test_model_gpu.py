@@ -244,3 +244,26 @@ def test_image_index_path_equals_pixel_values_path():
         _, t1 = model(pixel_values=pix.cuda(), **kw)
         _, t2 = model(image_index=idx, **kw)
     assert torch.equal(t1, t2)
+
+
+def test_full_size_training_steps_stay_finite():
+    """BASELINE configs[1] size (B=256, 393 vision tokens, L=64), 6 optimizer steps: loss, gradients and weights stay
+    finite.  Regression for a barrier bug in the attention tile loops (waves whose query rows lie past the end skipped the
+    compute body and with it the only wait on their share of the LDS-DMA) that showed up as rare NaNs only at this size."""
+    import bench
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    model, lit, cfg = bench.build(16, seed=0, device=dev, backbone="mkgformer")
+    batch = D.make_batch(256, 64, seed=1234, device=dev)
+    tr = Trainer(max_epochs=1, max_steps=150, world_size=1)
+    tr._setup(lit, [None] * 150)
+    losses = []
+    for i in range(6):
+        loss = tr.train_step(lit, batch, i)
+        torch.cuda.synchronize()
+        losses.append(float(loss))
+        assert math.isfinite(losses[-1]), losses
+        assert bool(torch.isfinite(model.store.grad).all()) and bool(torch.isfinite(model.store.master).all()), f"step {i}"
+    print("\nfull-size losses", [round(x, 4) for x in losses])
+    assert losses[-1] < losses[0]

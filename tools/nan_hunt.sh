@@ -1,0 +1,3 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+for i in 1 2 3 4 5 6 7 8; do echo "== run $i"; timeout 400 python tools/debug_nan.py 256 16 150 10 2>&1 | grep -E "^step" | tail -1 | cut -c1-200; done
