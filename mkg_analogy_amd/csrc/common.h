@@ -59,6 +59,15 @@ __device__ __forceinline__ void glds16(const void* gsrc_lane, void* lds_wave_bas
   __builtin_amdgcn_global_load_lds(GLB_PTR(gsrc_lane), LDS_PTR(lds_wave_base), 16, 0, 0);
 }
 
+// Same copy issued as opaque assembly.  With the builtin the compiler inserts an s_waitcnt vmcnt(0) in front of the next
+// ds_read_b64_tr_b16 (it cannot prove which LDS bytes the DMA writes), i.e. right after the prefetch of the NEXT tile has
+// been issued -- which serialises the prefetch with the transposed fragment reads of the CURRENT tile.  Kernels that use
+// this variant order the DMA themselves: an explicit s_waitcnt vmcnt(0) before the barrier that publishes the tile.
+__device__ __forceinline__ void glds16_raw(const void* gsrc_lane, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)LDS_PTR(lds_wave_base));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(gsrc_lane) : "memory", "m0");
+}
+
 // ---- bf16 <-> f32
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }

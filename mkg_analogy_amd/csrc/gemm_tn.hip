@@ -60,8 +60,8 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(Args p) {
       char* dX = sX + (r * NT + wave * 64) * 16;
       char* dY = sY + (r * NT + wave * 64) * 16;
       if (m < me) {
-        glds16(X + (long long)m * p.ldx + colX[r], dX);
-        glds16(Y + (long long)m * p.ldy + colY[r], dY);
+        glds16_raw(X + (long long)m * p.ldx + colX[r], dX);
+        glds16_raw(Y + (long long)m * p.ldy + colY[r], dY);
       } else {                                   // contraction tail: zero rows
         *(f32x4*)(dX + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         *(f32x4*)(dY + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(Args p) {
   const int nsteps = (me - ms + BKM - 1) / BKM;
   stage(ms, 0);
   for (int t = 0; t < nsteps; ++t) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own share of tile t landed (DMA is opaque asm: no compiler wait)
     __syncthreads();
     if (t + 1 < nsteps) stage(ms + (t + 1) * BKM, (t + 1) & 1);
     const char* sX = smem + (t & 1) * STAGE;
