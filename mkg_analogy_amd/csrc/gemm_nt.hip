@@ -314,7 +314,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   } else {
   stage(0, 0);
   for (int t = 0; t < nk; ++t) {
-    __syncthreads();                    // tile t landed (vmcnt(0) per wave, then barrier); buffer (t+1)&1 is free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile t landed -- explicit: never rely on the compiler's placement
+    __syncthreads();                    // tile t visible to all waves; buffer (t+1)&1 is free
     if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
     const char* sA = smem + (t & 1) * STAGE;
     const char* sB = sA + A_BYTES;
