@@ -514,7 +514,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (cfg == 999) { a.dbg = 1; cfg = 256; }
   if (cfg >= 70000 && cfg < 80000) { a.stagger_ticks = cfg - 70000; cfg = 256; }
   if (cfg == 9992 || cfg == 9993) { a.dbg = cfg - 9990; cfg = 256; }
-  if (cfg == 0) cfg = (t256 >= 224 || d->b_blocked) ? 256 : 128;
+  if (cfg == 0) cfg = ((t256 >= 224 && d->M > 128) || d->b_blocked) ? 256 : 128;   // short-M batched products (fusion, M = L = 64): 128-row tiles waste less
   MART_CHECK(!d->b_blocked || cfg == 256 || cfg == 999 || cfg == 2564, "gemm_nt: b_blocked requires the 256x256 tile");
   if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
   if (cfg == 2564 || cfg == 9994) { a.dbg = cfg == 9994; return launch<256, 256, 2, 2, 2>(a, batch, st); }
