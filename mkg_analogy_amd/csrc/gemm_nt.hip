@@ -55,7 +55,12 @@ struct Args {
   int dbg;                           // 1: skip the LDS-DMA after the first tile (timing experiment only)
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0>
+// Epilogue feature mask of the specialised ("fast") instantiations.  EPI < 0 = the general epilogue (tails, gathers,
+// bf16 residual, unaligned rows).  Every large product of the step maps to one of the fast masks; their epilogues are a few
+// hundred bytes of straight-line vector code (the general one made the kernel 200 KB and instruction-fetch bound).
+enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32 };
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0>   // ACTK: activation kind of the fast masks (literal: no erf code in the quick-GELU kernels)
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int BK = 64;
@@ -209,51 +214,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[u][j], af[u][i], acc[i][j]);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all fragment reads of this slot retired before the next barrier
     }
-  } else if constexpr (PIPE == 2) {
-    // ---- 4 waves, 128x128 per wave (one wave per SIMD, 256 accumulator registers): fragment reads per K-tile drop from
-    // 192 KB to 128 KB, ONE barrier per K-tile, and each wave software-pipelines its own LDS reads under its own MFMAs
-    // (fragments of k-step s+1 -- or of step 0 of the next tile -- are fetched while the 16 MFMAs of step s execute).
-    static_assert(TM == 4 && TN == 4, "PIPE 2 is the 2x2-wave 256x256 configuration");
-    const int key = (l31 >> 1) & 7;                      // same swizzle key for every fragment row of this lane
-    const char* baseA = smem + (wm0 + l31) * 128;
-    const char* baseB = smem + A_BYTES + (wn0 + l31) * 128;
-    bf16x8 fa[2][TM], fb[2][TN];
-    auto rd = [&](int buf, int ks, int slot) {
-      const int co = (((ks * 2 + h) ^ key) << 4) + buf * STAGE;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[slot][i] = *(const bf16x8*)(baseA + co + i * 4096);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[slot][j] = *(const bf16x8*)(baseB + co + j * 4096);
-    };
-    auto mma_half = [&](int slot, int i0) {
-#pragma unroll
-      for (int i = i0; i < i0 + 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(fb[slot][j], fa[slot][i], acc[i][j]);
-    };
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    rd(0, 0, 0);
-    for (int t = 0; t < nk; ++t) {
-      const int buf = t & 1;
-      if (t + 1 < nk && !p.dbg) stage(t + 1, buf ^ 1);
-      rd(buf, 1, 1);
-      mma_half(0, 0); mma_half(0, 2);
-      rd(buf, 2, 0);
-      mma_half(1, 0); mma_half(1, 2);
-      rd(buf, 3, 1);
-      mma_half(0, 0); mma_half(0, 2);
-      // tile t+1 landed (own DMA retired, then everybody's); all reads of tile t are retired as well (lgkmcnt(0) is
-      // implied by the MFMAs above having consumed them, the explicit wait covers the step-3 fragments)
-      mma_half(1, 0);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) rd(buf ^ 1, 0, 0);
-      mma_half(1, 2);
-    }
   } else if constexpr (WAVES_M == 2 && WAVES_N == 4) {
     // ---- ping-pong main loop (8 waves).  The two wave-rows of the tile (waves 0-3 / 4-7; waves w and w+4 share a
     // SIMD) run the same 4-phase K-tile sequence  R0 | M0 | R1 | M1  (R = fragment reads of two k-steps (+ LDS-DMA
@@ -337,7 +297,86 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   }
   }
 
-  // ---------------- epilogue: lane owns row m, 4 consecutive n per register quad
+  // ---------------- epilogue
+  // Accumulators -> LDS -> registers, WAVE-PRIVATE: each wave transposes its own WM x WN sub-tile through a private
+  // [32][WN+4] f32 region, one 32-row block at a time (16-byte writes in MFMA layout: conflict-free with the +4 pad;
+  // 16-byte reads with WN/4 lanes covering one row), so that ALL global epilogue traffic (bias, residual,
+  // pre-activation, output) is coalesced: a row segment of WN columns = 128 B of bf16 / 256 B of f32 per request.
+  // No block-level barrier after the first one, and all waves (both SIMD halves of the LDS store path) stay busy.
+  if (p.dbg == 2) return;                                        // timing experiment: no epilogue
+  constexpr int EP_LD = WN + 4;
+  constexpr int LPR = WN / 4, RPI = 64 / LPR;                    // lanes per row, rows per wave-instruction
+  constexpr int NIT = 32 / RPI;
+  __syncthreads();                                               // every wave is done with the K-loop buffers
+  float* ep = (float*)smem + wave * (32 * EP_LD);
+  const int er = lane / LPR, ec = (lane % LPR) * 4;
+  auto stage_block = [&](const f32x16 (&ai)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(ep + l31 * EP_LD + j * 32 + 8 * q + 4 * h) =
+            f32x4{ai[j][4 * q], ai[j][4 * q + 1], ai[j][4 * q + 2], ai[j][4 * q + 3]};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  if constexpr (EPI >= 0) {
+    // ---- fast lane: full-width tiles, 16-byte aligned rows (checked by the host dispatcher).  The streamed operands of a
+    // 32-row block (fp32 residual, z of the activation derivative) are fetched BEFORE the LDS round trip of the
+    // accumulators: NIT independent loads in flight per lane instead of one load -> compute -> store chain per quad.
+    const int n = n0 + wn0 + ec;
+    const long long cb = bz * p.sC, ab = bz * p.sAux;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *(const f32x4*)(p.bias + n);
+    if (p.bias2) bv += *(const f32x4*)(p.bias2 + n);
+    auto block = [&](const int i, const f32x16 (&ai)[TN]) {
+      f32x4 pr[NIT];
+      bf16x4 pz[NIT];
+      if constexpr ((EPI & (F_RES | F_MULZ)) != 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int m = min(m0 + wm0 + i * 32 + it * RPI + er, p.M - 1);
+          const long long orr = ab + (long long)m * p.ldres + n;
+          if constexpr ((EPI & F_RES) != 0) pr[it] = ld_stream((const f32x4*)(p.res_f32 + orr));
+          if constexpr ((EPI & F_MULZ) != 0) pz[it] = ld_stream((const bf16x4*)(p.mulz + orr));
+        }
+      }
+      stage_block(ai);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + er, m = m0 + wm0 + i * 32 + row;
+        f32x4 v = *(const f32x4*)(ep + row * EP_LD + ec);
+        v = v * p.alpha + bv;
+        const long long oc = cb + (long long)m * p.ldc + n;
+        const bool ok = m < p.M;
+        if constexpr ((EPI & F_PREACT) != 0) { if (ok) st_stream((bf16x4*)(p.preact + oc), f4_to_bf4(v)); }
+        if constexpr ((EPI & F_ACT) != 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACTK);
+        }
+        if constexpr ((EPI & F_MULZ) != 0) {
+          const f32x4 z = bf4_to_f4(pz[it]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= act_grad(z[e], ACTK);
+        }
+        if constexpr ((EPI & F_RES) != 0) v += pr[it];
+        if (ok) {
+          if constexpr ((EPI & F_CF32) != 0) st_stream((f32x4*)((float*)p.C + oc), v);
+          else st_stream((bf16x4*)((bf16*)p.C + oc), f4_to_bf4(v));
+          if constexpr ((EPI & F_C2) != 0) st_stream((bf16x4*)(p.C2 + cb + (long long)m * p.ldc2 + n), f4_to_bf4(v));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    };
+    block(0, acc[0]);
+    if constexpr (TM > 1) block(1, acc[1]);
+    if constexpr (TM > 2) block(2, acc[2]);
+    if constexpr (TM > 3) block(3, acc[3]);
+    static_assert(TM <= 4, "epilogue blocks are written out for TM <= 4");
+  } else {
+  // ---- general lane: lane owns row m, 4 consecutive n per register quad
   const bool vec = ((p.ldc & 3) == 0) && (!p.res_f32 && !p.res_bf16 && !p.mulz || (p.ldres & 3) == 0) &&
                    (!p.C2 || (p.ldc2 & 3) == 0);
   float* Cf = p.c_f32 ? (float*)p.C + bz * p.sC : nullptr;
@@ -426,29 +465,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       }
     }
   };
-  // Accumulators -> LDS -> registers, WAVE-PRIVATE: each wave transposes its own WM x WN sub-tile through a private
-  // [32][WN+4] f32 region, one 32-row block at a time (16-byte writes in MFMA layout: conflict-free with the +4 pad;
-  // 16-byte reads with WN/4 lanes covering one row), so that ALL global epilogue traffic (bias, residual,
-  // pre-activation, output) is coalesced: a row segment of WN columns = 128 B of bf16 / 256 B of f32 per request.
-  // No block-level barrier after the first one, and all waves (both SIMD halves of the LDS store path) stay busy.
-  if (p.dbg == 2) return;                                        // timing experiment: no epilogue
-  constexpr int EP_LD = WN + 4;
-  constexpr int LPR = WN / 4, RPI = 64 / LPR;                    // lanes per row, rows per wave-instruction
-  __syncthreads();                                               // every wave is done with the K-loop buffers
-  float* ep = (float*)smem + wave * (32 * EP_LD);
-  const int er = lane / LPR, ec = (lane % LPR) * 4;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(f32x4*)(ep + l31 * EP_LD + j * 32 + 8 * q + 4 * h) =
-            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+  auto block = [&](const int i, const f32x16 (&ai)[TN]) {
+    stage_block(ai);
 #pragma unroll 2
-    for (int it = 0; it < 32 / RPI; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int row = it * RPI + er;
       const int m = m0 + wm0 + i * 32 + row, n = n0 + wn0 + ec;
       const f32x4 a = *(const f32x4*)(ep + row * EP_LD + ec);
@@ -457,16 +477,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+  };
+  block(0, acc[0]);
+  if constexpr (TM > 1) block(1, acc[1]);
+  if constexpr (TM > 2) block(2, acc[2]);
+  if constexpr (TM > 3) block(3, acc[3]);
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0>
 int launch(const Args& a, int batch, hipStream_t st) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2, LDS_EPI = WAVES_M * WAVES_N * 32 * (BN / WAVES_N + 4) * 4;
   constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE>;
+  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, EPI, ACTK>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       mart_set_error("gemm_nt: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -515,9 +540,36 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (cfg >= 70000 && cfg < 80000) { a.stagger_ticks = cfg - 70000; cfg = 256; }
   if (cfg == 9992 || cfg == 9993) { a.dbg = cfg - 9990; cfg = 256; }
   if (cfg == 0) cfg = ((t256 >= 224 && d->M > 128) || d->b_blocked) ? 256 : 128;   // short-M batched products (fusion, M = L = 64): 128-row tiles waste less
-  MART_CHECK(!d->b_blocked || cfg == 256 || cfg == 999 || cfg == 2564, "gemm_nt: b_blocked requires the 256x256 tile");
+  if (cfg == 2561) { /* 256x256 tile, general epilogue (tests) */ }
+  MART_CHECK(!d->b_blocked || cfg == 256 || cfg == 999, "gemm_nt: b_blocked requires the 256x256 tile");
   if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
-  if (cfg == 2564 || cfg == 9994) { a.dbg = cfg == 9994; return launch<256, 256, 2, 2, 2>(a, batch, st); }
-  if (cfg == 256) return launch<256, 256, 2, 4>(a, batch, st);
+  // fast epilogue instantiations: full-width tiles, 16-byte aligned rows, no gathers / bf16 residual / debug modes
+  const int tile = cfg == 256 ? 256 : 128;
+  const bool aligned = (d->ldc % 4 == 0) && (a.ldres % 4 == 0) && (a.ldc2 % 4 == 0) && (d->N % tile == 0) && !d->res_bf16 &&
+                       !d->bias_by_brow && a.dbg == 0 && d->tile_cfg != 2561 &&
+                       ((uintptr_t)d->C % 16 == 0) && ((uintptr_t)d->res_f32 % 16 == 0) && ((uintptr_t)d->mulz % 8 == 0) &&
+                       ((uintptr_t)d->preact % 8 == 0) && ((uintptr_t)d->C2 % 8 == 0) && ((uintptr_t)d->bias % 16 == 0) &&
+                       ((uintptr_t)d->bias2 % 16 == 0) && (d->stride_c % 4 == 0) && (d->stride_aux % 4 == 0);
+  const bool two_acts = d->mulz && d->act != ACT_NONE;               // not a fast combination
+  const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
+                   (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
+  if (aligned) {
+#define MART_FAST(M_, K_)                                                                   \
+    if (mask == (M_) && kind == (K_))                                                         \
+      return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_)>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st);
+    const int kind = d->mulz ? d->mul_act : d->act;
+    MART_FAST(0, ACT_NONE)                        // bf16 out (+bias): QKV, data gradients
+    MART_FAST(F_CF32, ACT_NONE)                   // f32 out: scores, head
+    MART_FAST(F_CF32 | F_RES, ACT_NONE)           // residual stream: out-proj, fc2
+    MART_FAST(F_CF32 | F_RES | F_C2, ACT_NONE)    // ... with a bf16 copy for the fusion layers
+    MART_FAST(F_MULZ, ACT_QGELU)                  // data gradient through the activation (vision / text)
+    MART_FAST(F_MULZ, ACT_GELU)
+    MART_FAST(F_PREACT | F_ACT, ACT_QGELU)        // fc1 / intermediate: z and act(z)
+    MART_FAST(F_PREACT | F_ACT, ACT_GELU)
+    MART_FAST(F_CF32 | F_ACT, ACT_GELU)           // head transform / precise-path GELU (f32 out)
+    MART_FAST(F_CF32 | F_ACT, ACT_QGELU)
+#undef MART_FAST
+  }
+  if (cfg == 256 || cfg == 2561) return launch<256, 256, 2, 4>(a, batch, st);
   return launch<128, 128, 2, 2>(a, batch, st);
 }
