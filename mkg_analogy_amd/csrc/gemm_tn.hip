@@ -102,17 +102,24 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(Args p) {
     if (t + 1 < nsteps) stage(ms + (t + 1) * BKM, (t + 1) & 1);
     const char* sX = smem + (t & 1) * STAGE;
     const char* sY = sX + X_BYTES;
+    // fragments of k-step a+1 are fetched while the MFMAs of k-step a run (the wave's own LDS latency is hidden by its
+    // own matrix work, not only by the second wave of the SIMD)
+    bf16x8 xf[2][4], yf[2][2];
+    auto fetch = [&](int a, int slot) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xf[slot][i] = frag(sX, wnx0 + i * 32, a);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) yf[slot][j] = frag(sY, wny0 + j * 32, a);
+    };
+    fetch(0, 0);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      bf16x8 xf[4], yf[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xf[i] = frag(sX, wnx0 + i * 32, a);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) yf[j] = frag(sY, wny0 + j * 32, a);
+      const int cur = a & 1;
+      if (a + 1 < 4) fetch(a + 1, cur ^ 1);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc[i][0] = mfma32(xf[i], yf[0], acc[i][0]);
-        acc[i][1] = mfma32(xf[i], yf[1], acc[i][1]);
+        acc[i][0] = mfma32(xf[cur][i], yf[cur][0], acc[i][0]);
+        acc[i][1] = mfma32(xf[cur][i], yf[cur][1], acc[i][1]);
       }
       if (do_colsum && (wave & 3) == a) {                         // k-step a of every tile belongs to wave column a
         // each lane holds 8 contraction rows of column nx = ... + 32 i + l31: sum them on the VALU, which idles next to
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(Args p) {
         // the two waves that set the pace of the ty == 0 workgroups, 7-22 % of the kernel, and 64 accumulator VGPRs)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const u32x4 w = __builtin_bit_cast(u32x4, xf[i]);
+          const u32x4 w = __builtin_bit_cast(u32x4, xf[cur][i]);
           float s0 = 0.f, s1 = 0.f;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
