@@ -60,7 +60,9 @@ struct Args {
 // hundred bytes of straight-line vector code (the general one made the kernel 200 KB and instruction-fetch bound).
 enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0>   // ACTK: activation kind of the fast masks (literal: no erf code in the quick-GELU kernels)
+// PERSIST: one workgroup per CU slot walks over its tiles; the first K-tile of the NEXT tile is put in flight before the
+// epilogue of the current one, so the ~2-3 us of launch + first-DMA latency per tile hide behind the epilogue.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0, bool PERSIST = false>   // ACTK: activation kind of the fast masks (literal: no erf code in the quick-GELU kernels)
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int BK = 64;
@@ -86,8 +88,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   }
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+  const int total_tiles = tiles_m * tiles_n;
   const long long bz = blockIdx.y;
 
   const bf16* A = p.A + bz * p.sA;
@@ -95,26 +96,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   const bf16* A2 = p.A2 ? p.A2 + bz * p.sA : nullptr;
   const bf16* B2 = p.B2 ? p.B2 + bz * p.sB : nullptr;
 
-  // per-thread source offsets (elements) of the chunks this thread stages; constant over the K loop
+  // per-thread source offsets (elements) of the chunks this thread stages; constant over the K loop of one tile
+  int vb = blockIdx.x, m0 = 0, n0 = 0;
   unsigned offA[RA], offB[RB];
+  long long blkB1 = 0, blkB2 = 0;
+  auto set_tile = [&](int vbid) {
+    const int lid = xcd_remap(vbid, total_tiles);
+    m0 = (lid / tiles_n) * BM; n0 = (lid % tiles_n) * BN;
 #pragma unroll
-  for (int r = 0; r < RA; ++r) {
-    int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
-    int gm = min(m0 + row, p.M - 1);
-    if (p.a_rows) gm = p.a_rows[gm];
-    offA[r] = (unsigned)gm * (unsigned)p.lda + lc * 8;
-  }
+    for (int r = 0; r < RA; ++r) {
+      int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
+      int gm = min(m0 + row, p.M - 1);
+      if (p.a_rows) gm = p.a_rows[gm];
+      offA[r] = (unsigned)gm * (unsigned)p.lda + lc * 8;
+    }
 #pragma unroll
-  for (int r = 0; r < RB; ++r) {
-    int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
-    int gn = min(n0 + row, p.N - 1);
-    if (p.b_rows) gn = p.b_rows[gn];
-    offB[r] = (unsigned)gn * (unsigned)p.ldb + lc * 8;
-    if (p.b_blocked) offB[r] = (unsigned)(row & 255) * 64 + lc * 8 + (unsigned)(row >> 8) * 0;   // inside the 256x64 block
-  }
-  // tile-blocked weights: block (n0/256, kt) of operand with K' columns starts at ((n0/256)*(K'/64) + kt) * 16384 elements
-  const long long blkB1 = p.b_blocked ? (long long)(n0 >> 8) * (p.K >> 6) * 16384 : 0;
-  const long long blkB2 = p.b_blocked ? (long long)(n0 >> 8) * (p.K2 >> 6) * 16384 : 0;
+    for (int r = 0; r < RB; ++r) {
+      int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
+      int gn = min(n0 + row, p.N - 1);
+      if (p.b_rows) gn = p.b_rows[gn];
+      offB[r] = (unsigned)gn * (unsigned)p.ldb + lc * 8;
+      if (p.b_blocked) offB[r] = (unsigned)(row & 255) * 64 + lc * 8;       // inside the 256x64 block
+    }
+    // tile-blocked weights: block (n0/256, kt) of operand with K' columns starts at ((n0/256)*(K'/64) + kt) * 16384 elements
+    blkB1 = p.b_blocked ? (long long)(n0 >> 8) * (p.K >> 6) * 16384 : 0;
+    blkB2 = p.b_blocked ? (long long)(n0 >> 8) * (p.K2 >> 6) * 16384 : 0;
+  };
+  set_tile(vb);
 
   const int nk1 = p.K / BK, nk = nk1 + p.K2 / BK;
 
@@ -131,6 +139,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   };
 
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  // LDS read addressing: row -> byte base and swizzle key
+  int rowA[TM], rowB[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) rowA[i] = wm0 + i * 32 + l31;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) rowB[j] = wn0 + j * 32 + l31;
+
+  bool have0 = false;                  // K-tile 0 of the current tile is already in flight (persistent variant)
+  for (;;) {
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -138,13 +155,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // LDS read addressing: row -> byte base and swizzle key
-  int rowA[TM], rowB[TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) rowA[i] = wm0 + i * 32 + l31;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) rowB[j] = wn0 + j * 32 + l31;
 
   if constexpr (PIPE == 1) {
     // ---- 4-slot ring of 32-deep K-steps (32 KB per slot), LDS-DMA three steps ahead behind COUNTED vmcnt waits: the
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     };
-    stage(0, 0);
+    if (!have0) stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();          // one-phase lag of the lower wave-row
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();          // balance the barrier count
   } else {
-  stage(0, 0);
+  if (!have0) stage(0, 0);
   for (int t = 0; t < nk; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own share of tile t landed -- explicit: never rely on the compiler's placement
     __syncthreads();                    // tile t visible to all waves; buffer (t+1)&1 is free
@@ -303,12 +313,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   // 16-byte reads with WN/4 lanes covering one row), so that ALL global epilogue traffic (bias, residual,
   // pre-activation, output) is coalesced: a row segment of WN columns = 128 B of bf16 / 256 B of f32 per request.
   // No block-level barrier after the first one, and all waves (both SIMD halves of the LDS store path) stay busy.
-  if (p.dbg == 2) return;                                        // timing experiment: no epilogue
+  if (p.dbg == 2) return;                                        // timing experiment: no epilogue (non-persistent only)
   constexpr int EP_LD = WN + 4;
   constexpr int LPR = WN / 4, RPI = 64 / LPR;                    // lanes per row, rows per wave-instruction
   constexpr int NIT = 32 / RPI;
   __syncthreads();                                               // every wave is done with the K-loop buffers
-  float* ep = (float*)smem + wave * (32 * EP_LD);
+  const int em0 = m0, en0 = n0;                                  // the tile being written out
+  bool more = false;
+  if constexpr (PERSIST) {
+    const int nvb = vb + (int)gridDim.x;
+    more = nvb < total_tiles;
+    if (more) { vb = nvb; set_tile(vb); stage(0, 0); }            // next tile's first K-tile lands in buffer 0 during the epilogue
+  }
+  float* ep = (float*)(smem + (PERSIST ? STAGE : 0)) + wave * (32 * EP_LD);   // persistent: staging lives above buffer 0
   const int er = lane / LPR, ec = (lane % LPR) * 4;
   auto stage_block = [&](const f32x16 (&ai)[TN]) {
 #pragma unroll
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     // ---- fast lane: full-width tiles, 16-byte aligned rows (checked by the host dispatcher).  The streamed operands of a
     // 32-row block (fp32 residual, z of the activation derivative) are fetched BEFORE the LDS round trip of the
     // accumulators: NIT independent loads in flight per lane instead of one load -> compute -> store chain per quad.
-    const int n = n0 + wn0 + ec;
+    const int n = en0 + wn0 + ec;
     const long long cb = bz * p.sC, ab = bz * p.sAux;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bv = *(const f32x4*)(p.bias + n);
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       if constexpr ((EPI & (F_RES | F_MULZ)) != 0) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          const int m = min(m0 + wm0 + i * 32 + it * RPI + er, p.M - 1);
+          const int m = min(em0 + wm0 + i * 32 + it * RPI + er, p.M - 1);
           const long long orr = ab + (long long)m * p.ldres + n;
           if constexpr ((EPI & F_RES) != 0) pr[it] = ld_stream((const f32x4*)(p.res_f32 + orr));
           if constexpr ((EPI & F_MULZ) != 0) pz[it] = ld_stream((const bf16x4*)(p.mulz + orr));
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       stage_block(ai);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int row = it * RPI + er, m = m0 + wm0 + i * 32 + row;
+        const int row = it * RPI + er, m = em0 + wm0 + i * 32 + row;
         f32x4 v = *(const f32x4*)(ep + row * EP_LD + ec);
         v = v * p.alpha + bv;
         const long long oc = cb + (long long)m * p.ldc + n;
@@ -470,7 +487,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll 2
     for (int it = 0; it < NIT; ++it) {
       const int row = it * RPI + er;
-      const int m = m0 + wm0 + i * 32 + row, n = n0 + wn0 + ec;
+      const int m = em0 + wm0 + i * 32 + row, n = en0 + wn0 + ec;
       const f32x4 a = *(const f32x4*)(ep + row * EP_LD + ec);
       if (p.dbg == 3) { if (a[0] == 1.2345f) *(float*)p.C = a[1]; }             // timing experiment: LDS staging only
       else if (m < p.M && n < p.N) emit(m, n, a[0], a[1], a[2], a[3]);
@@ -483,15 +500,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   if constexpr (TM > 2) block(2, acc[2]);
   if constexpr (TM > 3) block(3, acc[3]);
   }
+  if (!more) break;
+  have0 = true;
+  }   // tile loop
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0, bool PERSIST = false>
 int launch(const Args& a, int batch, hipStream_t st) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
-  constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2, LDS_EPI = WAVES_M * WAVES_N * 32 * (BN / WAVES_N + 4) * 4;
+  constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2;
+  constexpr int LDS_EPI = WAVES_M * WAVES_N * 32 * (BN / WAVES_N + 4) * 4 + (PERSIST ? (BM + BN) * 64 * 2 : 0);   // persistent: staging above buffer 0
   constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
   static bool attr_set = false;
-  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, EPI, ACTK>;
+  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, EPI, ACTK, PERSIST>;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       mart_set_error("gemm_nt: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -500,6 +521,10 @@ int launch(const Args& a, int batch, hipStream_t st) {
     attr_set = true;
   }
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  if (PERSIST) {                                                 // one workgroup per CU slot (256 CUs; LDS allows 1 / 2 per CU)
+    const int slots = 256 * (LDS <= 80 * 1024 ? 2 : 1);
+    if (tiles > slots) tiles = slots;
+  }
   hipLaunchKernelGGL(kern, dim3(tiles, batch), dim3(NT), LDS, st, a);
   MART_LAUNCH_CHECK();
   return 0;
@@ -540,13 +565,14 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (cfg >= 70000 && cfg < 80000) { a.stagger_ticks = cfg - 70000; cfg = 256; }
   if (cfg == 9992 || cfg == 9993) { a.dbg = cfg - 9990; cfg = 256; }
   if (cfg == 0) cfg = ((t256 >= 224 && d->M > 128) || d->b_blocked) ? 256 : 128;   // short-M batched products (fusion, M = L = 64): 128-row tiles waste less
-  if (cfg == 2561) { /* 256x256 tile, general epilogue (tests) */ }
+  if (cfg == 2561 || cfg == 2562) { /* 256x256 tile: 2561 general epilogue, 2562 fast epilogue without the persistent loop (A/B) */ if (cfg == 2562) cfg = 256; }
   MART_CHECK(!d->b_blocked || cfg == 256 || cfg == 999, "gemm_nt: b_blocked requires the 256x256 tile");
   if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
   // fast epilogue instantiations: full-width tiles, 16-byte aligned rows, no gathers / bf16 residual / debug modes
   const int tile = cfg == 256 ? 256 : 128;
   const bool aligned = (d->ldc % 4 == 0) && (a.ldres % 4 == 0) && (a.ldc2 % 4 == 0) && (d->N % tile == 0) && !d->res_bf16 &&
                        !d->bias_by_brow && a.dbg == 0 && d->tile_cfg != 2561 &&
+                      
                        ((uintptr_t)d->C % 16 == 0) && ((uintptr_t)d->res_f32 % 16 == 0) && ((uintptr_t)d->mulz % 8 == 0) &&
                        ((uintptr_t)d->preact % 8 == 0) && ((uintptr_t)d->C2 % 8 == 0) && ((uintptr_t)d->bias % 16 == 0) &&
                        ((uintptr_t)d->bias2 % 16 == 0) && (d->stride_c % 4 == 0) && (d->stride_aux % 4 == 0);
@@ -554,9 +580,13 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
                    (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
   if (aligned) {
+    // persistent loop: +6-7 % where the epilogue is light (bf16 out), neutral with the fp32 residual, -11 % with two bf16
+    // outputs (the next tile's first wait also drains the stores) -> only for the light masks
+    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ);
 #define MART_FAST(M_, K_)                                                                   \
-    if (mask == (M_) && kind == (K_))                                                         \
-      return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_)>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st);
+    if (mask == (M_) && kind == (K_)) {                                                       \
+      if (persist) return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_), true>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_), true>(a, batch, st); \
+      return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_)>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st); }
     const int kind = d->mulz ? d->mul_act : d->act;
     MART_FAST(0, ACT_NONE)                        // bf16 out (+bias): QKV, data gradients
     MART_FAST(F_CF32, ACT_NONE)                   // f32 out: scores, head
