@@ -87,16 +87,25 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
   }
   for (int m = wave_g; m < p.M; m += nwaves) {
     const float mean = p.mean[m], rstd = p.rstd[m];
-    f32x4 dy[VMAX], xh[VMAX];
+    f32x4 dy[VMAX], xh[VMAX], addv[VMAX];
     float s1 = 0.f, s2 = 0.f;
+    // every operand of the row is requested up front (the residual-gradient add used to be loaded after the row
+    // reduction: one exposed HBM round trip per row); all of them are read once -> nontemporal
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+      if (v < nv) {
+        const long long o = (long long)m * p.H + (v * 64 + lane) * 4;
+        addv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.add_f32) addv[v] = __builtin_nontemporal_load((const f32x4*)(p.add_f32 + o));
+      }
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
       if (v < nv) {
         const long long o = (long long)m * p.H + (v * 64 + lane) * 4;
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        if (p.dy_f32) d = *(const f32x4*)(p.dy_f32 + o);
-        if (dyb) d += bf4_to_f4(*(const bf16x4*)(dyb + o));
-        f32x4 s = *(const f32x4*)(p.s + o);
+        if (p.dy_f32) d = __builtin_nontemporal_load((const f32x4*)(p.dy_f32 + o));
+        if (dyb) d += bf4_to_f4(__builtin_nontemporal_load((const bf16x4*)(dyb + o)));
+        f32x4 s = __builtin_nontemporal_load((const f32x4*)(p.s + o));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float xhat = (s[e] - mean) * rstd;
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
           }
           *(bf16x4*)((bf16*)p.ds_bf16 + o) = f4_to_bf4(dd);
         }
-        if (p.add_f32) ds += *(const f32x4*)(p.add_f32 + o);
+        if (p.add_f32) ds += addv[v];
         if (p.ds_f32) *(f32x4*)(p.ds_f32 + o) = ds;
         if (p.ds_bf16 && p.bf16_total) *(bf16x4*)((bf16*)p.ds_bf16 + o) = f4_to_bf4(ds);
       }
