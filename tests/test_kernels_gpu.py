@@ -90,6 +90,39 @@ def test_gemm_nt_epilogues(ops, cfg):
         close(out, lin * zz.grad, 3e-2, 1e-2, f"mulz act {act}")
 
 
+@pytest.mark.parametrize("M,N", [(256 * 300 + 17, 768), (128 * 530 + 5, 256)])
+def test_gemm_nt_persistent_loop_and_general_fallback(ops, M, N):
+    """More tiles than CU slots: the persistent fast kernels walk several tiles per workgroup (M tail rows in the last
+    one); every epilogue family against torch, and the general-epilogue kernel (tile_cfg 2561) against the fast ones."""
+    K = 128
+    A, B = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.06)
+    lin = A.float() @ B.float().t()
+    bias = rnd(N, seed=13, dtype=F32)
+    res = rnd(M, N, seed=14, dtype=F32)
+    z = rnd(M, N, seed=15)
+    outb, outg = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, B, outb, bias=bias)                                   # light mask: persistent
+    close(outb, lin + bias, 3e-2, 1e-2, "persistent bf16")
+    ops.gemm_nt(A, B, outg, bias=bias, tile_cfg=2561)                    # general epilogue, same tile
+    assert torch.equal(outb, outg)
+    ops.gemm_nt(A, B, outb, mulz=z, mul_act=ops.ACT_QGELU)               # persistent, streamed operand
+    zz = z.float()
+    sg = torch.sigmoid(1.702 * zz)
+    close(outb, lin * (sg * (1 + 1.702 * zz * (1 - sg))), 3e-2, 1e-2, "persistent mulz")
+    of, c2 = torch.empty(M, N, device=DEV, dtype=F32), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, B, of, bias=bias, res_f32=res, C2=c2)                 # residual-stream fast lane
+    close(of, lin + bias + res, 2e-3, 2e-3, "res_f32 fast")
+    close(c2, lin + bias + res, 3e-2, 1e-2, "C2 fast")
+    og = torch.empty(M, N, device=DEV, dtype=F32)
+    ops.gemm_nt(A, B, og, bias=bias, res_f32=res, tile_cfg=2561)
+    assert torch.equal(of, og)
+    pre = torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, B, outb, bias=bias, act=ops.ACT_QGELU, preact=pre)
+    y = lin + bias
+    close(pre, y, 3e-2, 1e-2, "preact fast")
+    close(outb, y * torch.sigmoid(1.702 * y), 3e-2, 1e-2, "qgelu fast")
+
+
 def test_gemm_nt_dual_k_gather_batch(ops):
     M, N, K = 300, 512, 128
     A, B, A2, B2 = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=.1), rnd(M, K, seed=3), rnd(N, K, seed=4, scale=.1)

@@ -11,7 +11,7 @@ f = glob.glob("gpurun_out/_pmc/*counter_collection.csv")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for row in csv.DictReader(open(f[0])):
     if sys.argv[1] in row["Kernel_Name"]:
-        agg[row["Kernel_Name"][:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        agg[sys.argv[1] + " (all matching launches)"][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kn, d in agg.items():
     for k, v in d.items():
         print(f"{kn} {k} {sum(v)/len(v):.0f} n={len(v)}")
