@@ -49,6 +49,8 @@ class UnimoEngine:
         self.overlap_wgrad = os.environ.get("MART_OVERLAP_WGRAD", "1") == "1"   # weight-gradient GEMMs on a side stream (+2.5 % step rate)
         self._side: Optional[torch.cuda.Stream] = None
         self._side_busy = False
+        self.two_stream = os.environ.get("MART_TWO_STREAM", "1") == "1"   # text layers on their own stream (+3 % step rate)
+        self._tstream: Optional[torch.cuda.Stream] = None
 
     # ------------------------------------------------------------------ helpers
     def _lin(self, name):
@@ -79,6 +81,53 @@ class UnimoEngine:
         Y.record_stream(self._side)
         self._side_busy = True
 
+    # ---- text stream (two_stream): the text layers are issued on their own HIP stream; events mirror the cross-wiring of
+    # the model (text K/V -> vision attention, vision output -> text fusion, and the reverse edges in backward), so small
+    # text kernels fill the gaps of the big vision kernels instead of running alone on the GPU.  With two_stream off every
+    # helper is a no-op and both "streams" are the current one: one code path.
+    def _text_ctx(self):
+        import contextlib
+        return torch.cuda.stream(self._tstream) if self._tstream is not None else contextlib.nullcontext()
+
+    def _text_begin(self):
+        if not self.two_stream:
+            self._tstream = None
+        elif self._tstream is None:
+            self._tstream = torch.cuda.Stream()
+        if self._tstream is not None:
+            self._tstream.wait_stream(torch.cuda.current_stream())
+
+    def _text_done(self):
+        if self._tstream is not None:
+            torch.cuda.current_stream().wait_stream(self._tstream)
+
+    def _text_record(self):
+        if self._tstream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._tstream)
+        return ev
+
+    def _main_record(self):
+        if self._tstream is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def _text_wait(self, ev):
+        if self._tstream is not None and ev is not None:
+            self._tstream.wait_event(ev)
+
+    def _main_wait(self, ev):
+        if self._tstream is not None and ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def _text_uses(self, t):
+        """A tensor allocated on the main stream that text-stream kernels will touch (allocator must not recycle it early)."""
+        if self._tstream is not None:
+            t.record_stream(self._tstream)
+
     def _join(self):
         """Main stream waits for every weight-gradient GEMM issued so far."""
         if self._side_busy:
@@ -100,6 +149,7 @@ class UnimoEngine:
                                      ids=input_ids, tt=token_type_ids, am=attention_mask, sep=sep_idx)
         p_h = self.p_hidden if train else 0.0
         p_a = self.p_attn if train else 0.0
+        self._text_begin()                            # text stream starts behind whatever produced the inputs
 
         # ---- vision embeddings: patchify -> GEMM -> assemble(+cls,+pos) -> pre-LN    (modeling_unimo.py:119-132,711)
         Kp = 3 * p * p
@@ -124,18 +174,20 @@ class UnimoEngine:
         sv["vemb"] = (patches, s_v, mean, rstd)
 
         # ---- text embeddings (modeling_unimo.py:152-186)
-        u = "unimo.text_embeddings."
-        s_t, tmean, trstd = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
-        xt, xtb = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-        ops.text_embed_fwd(ids=input_ids, tt=token_type_ids, word=st.m(u + "word_embeddings.weight"), pos=st.m(u + "position_embeddings.weight"),
-                           type_=st.m(u + "token_type_embeddings.weight"), gamma=st.m(u + "LayerNorm.weight"), beta=st.m(u + "LayerNorm.bias"),
-                           eps=self.eps_t, p_drop=p_h, seed=seed + 1, B=B, Lq=Lq, H=H, s_out=s_t, mean=tmean, rstd=trstd, out_f32=xt, out_bf16=xtb)
-        sv["temb"] = (s_t, tmean, trstd)
+        with self._text_ctx():
+            u = "unimo.text_embeddings."
+            s_t, tmean, trstd = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
+            xt, xtb = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+            ops.text_embed_fwd(ids=input_ids, tt=token_type_ids, word=st.m(u + "word_embeddings.weight"), pos=st.m(u + "position_embeddings.weight"),
+                               type_=st.m(u + "token_type_embeddings.weight"), gamma=st.m(u + "LayerNorm.weight"), beta=st.m(u + "LayerNorm.bias"),
+                               eps=self.eps_t, p_drop=p_h, seed=seed + 1, B=B, Lq=Lq, H=H, s_out=s_t, mean=tmean, rstd=trstd, out_f32=xt, out_bf16=xtb)
+            sv["temb"] = (s_t, tmean, trstd)
         if self.taps is not None:
             self.taps["vis_emb"] = xv.view(B, Nv, H).clone()
             self.taps["txt_emb"] = xt.view(B, Lq, H).clone()
 
         t_qkv_prev = None
+        ev_tqkv = ev_vis = None
         for l in range(self.n_layers):
             # ================= vision layer l (CLIPEncoderLayer.forward, modeling_unimo.py:490-527)
             v = f"unimo.encoder.vision_layers.{l}."
@@ -147,6 +199,8 @@ class UnimoEngine:
             ops.gemm_nt(h1, st.fused([n + ".weight" for n in names]), qkv, bias=st.fused([n + ".bias" for n in names], st.master))
             ctx, lse = _e((Mv, H), BF, dev), _e((B, nh, Nv), F32, dev)
             pre = t_qkv_prev if l >= self.fuse_from else None
+            if pre is not None:
+                self._main_wait(ev_tqkv)                                   # K/V of text layer l-1 are produced on the text stream
             akw = dict(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, lse=lse, B=B, nh=nh, Sq=Nv, Sk=Nv, scale=0.125,
                        pk=pre[:, H:2 * H] if pre is not None else None, pv=pre[:, 2 * H:] if pre is not None else None,
                        Lp=Lq if pre is not None else 0)
@@ -167,69 +221,80 @@ class UnimoEngine:
             sv[f"v{l}"] = dict(x=xv, m1=m1, r1=r1, h1=h1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, m2=m2, r2=r2, h2=h2, z=z, f=f, pre=pre)
             xv = x2
 
+            if l >= self.fuse_from:
+                ev_vis = self._main_record()                               # x2b (input of the fusion of text layer l) is final
             # ================= text layer l (BertLayer.forward, modeling_unimo.py:540-577)
-            t = f"unimo.encoder.text_layer.{l}."
-            tqkv = _e((Mt, 3 * H), BF, dev)
-            names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
-            ops.gemm_nt(xtb, st.fused([n + ".weight" for n in names]), tqkv, bias=st.fused([n + ".bias" for n in names], st.master))
-            tctx, tlse = _e((Mt, H), BF, dev), _e((B, nh, Lq), F32, dev)
-            w0 = st.m(t + "attention.self.adaptive_weight.0")
-            w1 = st.m(t + "attention.self.adaptive_weight.1")
-            tkw = dict(q=tqkv[:, :H], k=tqkv[:, H:2 * H], v=tqkv[:, 2 * H:], ctx=tctx, lse=tlse, B=B, nh=nh, Sq=Lq, Sk=Lq, scale=0.125,
-                       attn_mask=attention_mask, sep=sep_idx[:, 2:] if sep_idx is not None else None,
-                       sep_stride=sep_idx.shape[1] if sep_idx is not None else 0,
-                       w0=w0 if sep_idx is not None else None, w1=w1 if sep_idx is not None else None,
-                       p_drop=p_a, seed=seed + 10 + 4 * l)
-            ops.attn_fwd(**tkw)
-            fus = probs = visT = None
-            if l >= self.fuse_from:                                   # BertFusion.forward, modeling_unimo.py:400-414
-                scores = _e((Mt, Nvp), F32, dev)
-                ops.gemm_nt(tctx, x2b, scores, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
-                probs = _e((Mt, Nvp), BF, dev)
-                ops.softmax_fwd(scores, probs, Mt, Nv)
-                visT = _e((B * H, Nvp), BF, dev)
-                ops.transpose_bf16(x2b, visT, Nv, H, Nvp, batch=B, stride_i=Nv * H, stride_o=H * Nvp)
-                fus = _e((Mt, H), BF, dev)
-                ops.gemm_nt(probs, visT, fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
-            so = _e((Mt, H), BF, dev)
-            w, b = self._lin(t + "attention.output.dense")
-            ops.gemm_nt(tctx, w, so, bias=b)
-            s1, am1, ar1 = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
-            a, ab = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-            ops.ln_fwd(x_f32=xt, y_bf16=so, p_drop=p_h, seed=seed + 11 + 4 * l, gamma=st.m(t + "attention.output.LayerNorm.weight"),
-                       beta=st.m(t + "attention.output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=am1, rstd=ar1, s_out=s1, out_f32=a, out_bf16=ab)
-            zt, ht = _e((Mt, I), BF, dev), _e((Mt, I), BF, dev)
-            w, b = self._lin(t + "intermediate.dense")
-            if fus is not None:
-                wf, bf_ = self._lin(t + "intermediate.fusion_dense")
-                ops.gemm_nt(ab, w, ht, A2=fus, B2=wf, bias=b, bias2=bf_, act=ops.ACT_GELU, preact=zt)
-            else:
-                ops.gemm_nt(ab, w, ht, bias=b, act=ops.ACT_GELU, preact=zt)
-            oo = _e((Mt, H), BF, dev)
-            w, b = self._lin(t + "output.dense")
-            ops.gemm_nt(ht, w, oo, bias=b)
-            s2, om, orr = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
-            xo, xob = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-            ops.ln_fwd(x_f32=a, y_bf16=oo, p_drop=p_h, seed=seed + 12 + 4 * l, gamma=st.m(t + "output.LayerNorm.weight"),
-                       beta=st.m(t + "output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=om, rstd=orr, s_out=s2, out_f32=xo, out_bf16=xob)
-            sv[f"t{l}"] = dict(xb=xtb, qkv=tqkv, ctx=tctx, lse=tlse, tkw=tkw, fus=fus, probs=probs, visT=visT, visb=x2b,
-                               s1=s1, m1=am1, r1=ar1, ab=ab, zt=zt, ht=ht, s2=s2, m2=om, r2=orr)
-            xt, xtb = xo, xob
+            with self._text_ctx():
+                t = f"unimo.encoder.text_layer.{l}."
+                tqkv = _e((Mt, 3 * H), BF, dev)
+                names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
+                ops.gemm_nt(xtb, st.fused([n + ".weight" for n in names]), tqkv, bias=st.fused([n + ".bias" for n in names], st.master))
+                if l >= self.export_from:
+                    ev_tqkv = self._text_record()
+                tctx, tlse = _e((Mt, H), BF, dev), _e((B, nh, Lq), F32, dev)
+                w0 = st.m(t + "attention.self.adaptive_weight.0")
+                w1 = st.m(t + "attention.self.adaptive_weight.1")
+                tkw = dict(q=tqkv[:, :H], k=tqkv[:, H:2 * H], v=tqkv[:, 2 * H:], ctx=tctx, lse=tlse, B=B, nh=nh, Sq=Lq, Sk=Lq, scale=0.125,
+                           attn_mask=attention_mask, sep=sep_idx[:, 2:] if sep_idx is not None else None,
+                           sep_stride=sep_idx.shape[1] if sep_idx is not None else 0,
+                           w0=w0 if sep_idx is not None else None, w1=w1 if sep_idx is not None else None,
+                           p_drop=p_a, seed=seed + 10 + 4 * l)
+                ops.attn_fwd(**tkw)
+                fus = probs = visT = None
+                if l >= self.fuse_from:                                   # BertFusion.forward, modeling_unimo.py:400-414
+                    self._text_wait(ev_vis)
+                    scores = _e((Mt, Nvp), F32, dev)
+                    ops.gemm_nt(tctx, x2b, scores, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
+                    probs = _e((Mt, Nvp), BF, dev)
+                    ops.softmax_fwd(scores, probs, Mt, Nv)
+                    visT = _e((B * H, Nvp), BF, dev)
+                    ops.transpose_bf16(x2b, visT, Nv, H, Nvp, batch=B, stride_i=Nv * H, stride_o=H * Nvp)
+                    fus = _e((Mt, H), BF, dev)
+                    ops.gemm_nt(probs, visT, fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
+                so = _e((Mt, H), BF, dev)
+                w, b = self._lin(t + "attention.output.dense")
+                ops.gemm_nt(tctx, w, so, bias=b)
+                s1, am1, ar1 = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
+                a, ab = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+                ops.ln_fwd(x_f32=xt, y_bf16=so, p_drop=p_h, seed=seed + 11 + 4 * l, gamma=st.m(t + "attention.output.LayerNorm.weight"),
+                           beta=st.m(t + "attention.output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=am1, rstd=ar1, s_out=s1, out_f32=a, out_bf16=ab)
+                zt, ht = _e((Mt, I), BF, dev), _e((Mt, I), BF, dev)
+                w, b = self._lin(t + "intermediate.dense")
+                if fus is not None:
+                    wf, bf_ = self._lin(t + "intermediate.fusion_dense")
+                    ops.gemm_nt(ab, w, ht, A2=fus, B2=wf, bias=b, bias2=bf_, act=ops.ACT_GELU, preact=zt)
+                else:
+                    ops.gemm_nt(ab, w, ht, bias=b, act=ops.ACT_GELU, preact=zt)
+                oo = _e((Mt, H), BF, dev)
+                w, b = self._lin(t + "output.dense")
+                ops.gemm_nt(ht, w, oo, bias=b)
+                s2, om, orr = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
+                xo, xob = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+                ops.ln_fwd(x_f32=a, y_bf16=oo, p_drop=p_h, seed=seed + 12 + 4 * l, gamma=st.m(t + "output.LayerNorm.weight"),
+                           beta=st.m(t + "output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=om, rstd=orr, s_out=s2, out_f32=xo, out_bf16=xob)
+                sv[f"t{l}"] = dict(xb=xtb, qkv=tqkv, ctx=tctx, lse=tlse, tkw=tkw, fus=fus, probs=probs, visT=visT, visb=x2b,
+                                   s1=s1, m1=am1, r1=ar1, ab=ab, zt=zt, ht=ht, s2=s2, m2=om, r2=orr)
+                xt, xtb = xo, xob
             t_qkv_prev = tqkv if l >= self.export_from else None
             if self.taps is not None:
                 self.taps[f"vis{l}"] = xv.view(B, Nv, H).clone()
                 self.taps[f"txt{l}"] = xt.view(B, Lq, H).clone()
 
         # ---- MLM head transform (BertPredictionHeadTransform.forward, modeling_unimo.py:972-975)
-        hp = "cls.predictions.transform."
-        y, zh = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-        w, b = self._lin(hp + "dense")
-        ops.gemm_nt(xtb, w, y, bias=b, act=ops.ACT_GELU, preact=zh)
-        trans, transb = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-        hm, hr = _e((Mt,), F32, dev), _e((Mt,), F32, dev)
-        ops.ln_fwd(x_f32=y, gamma=st.m(hp + "LayerNorm.weight"), beta=st.m(hp + "LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=hm, rstd=hr,
-                   out_f32=trans, out_bf16=transb)
-        sv["head"] = (xtb, y, zh, hm, hr)
+        with self._text_ctx():
+            hp = "cls.predictions.transform."
+            y, zh = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+            w, b = self._lin(hp + "dense")
+            ops.gemm_nt(xtb, w, y, bias=b, act=ops.ACT_GELU, preact=zh)
+            trans, transb = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+            hm, hr = _e((Mt,), F32, dev), _e((Mt,), F32, dev)
+            ops.ln_fwd(x_f32=y, gamma=st.m(hp + "LayerNorm.weight"), beta=st.m(hp + "LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=hm, rstd=hr,
+                       out_f32=trans, out_bf16=transb)
+            sv["head"] = (xtb, y, zh, hm, hr)
+        self._text_done()
+        if self._tstream is not None:                  # allocated on the text stream, consumed by the caller on the main stream
+            trans.record_stream(torch.cuda.current_stream())
+            transb.record_stream(torch.cuda.current_stream())
         return trans.view(B, Lq, H), transb, sv
 
     # ------------------------------------------------------------------ backward
@@ -244,76 +309,89 @@ class UnimoEngine:
         notify = self.grad_ready or (lambda off: None)
 
         # ---- head transform
-        xtb, y, zh, hm, hr = sv["head"]
-        hp = "cls.predictions.transform."
-        dyb = _e((Mt, H), BF, dev)
-        ops.ln_bwd(dy_f32=dtrans.contiguous().view(Mt, H), s=y, mean=hm, rstd=hr, gamma=st.m(hp + "LayerNorm.weight"), M=Mt, H=H, ds_bf16=dyb,
-                   dgamma=st.g(hp + "LayerNorm.weight"), dbeta=st.g(hp + "LayerNorm.bias"))
-        dzh = _e((Mt, H), BF, dev)
-        ops.act_bwd(dyb, zh, ops.ACT_GELU, dzh)
-        self._wgrad(dzh, xtb, hp + "dense.weight", hp + "dense.bias")
-        d_f32 = _e((Mt, H), F32, dev)                                 # gradient w.r.t. the text stream, f32 part
-        ops.gemm_nt(dzh, st.wt("head"), d_f32)
-        d_b16 = None                                                  # ... plus an optional bf16 part
+        self._text_begin()                                            # text stream starts behind the main stream (dtrans is ready)
+        dtrans = dtrans.contiguous()
+        self._text_uses(dtrans)
+        with self._text_ctx():
+            xtb, y, zh, hm, hr = sv["head"]
+            hp = "cls.predictions.transform."
+            dyb = _e((Mt, H), BF, dev)
+            ops.ln_bwd(dy_f32=dtrans.contiguous().view(Mt, H), s=y, mean=hm, rstd=hr, gamma=st.m(hp + "LayerNorm.weight"), M=Mt, H=H, ds_bf16=dyb,
+                       dgamma=st.g(hp + "LayerNorm.weight"), dbeta=st.g(hp + "LayerNorm.bias"))
+            dzh = _e((Mt, H), BF, dev)
+            ops.act_bwd(dyb, zh, ops.ACT_GELU, dzh)
+            self._wgrad(dzh, xtb, hp + "dense.weight", hp + "dense.bias")
+            d_f32 = _e((Mt, H), F32, dev)                                 # gradient w.r.t. the text stream, f32 part
+            ops.gemm_nt(dzh, st.wt("head"), d_f32)
+            d_b16 = None                                                  # ... plus an optional bf16 part
         if self.grad_ready is not None:
-            self._join()
+            self._join(); self._text_done(); self._text_begin()
         notify(st.slots["unimo.encoder.text_layer.%d.attention.self.query.weight" % (self.n_layers - 1)].offset)
 
         dxv = torch.zeros((Mv, H), device=dev, dtype=F32)             # gradient w.r.t. the vision stream
         dxvb = _e((Mv, H), BF, dev)
+        ev_vdone = self._main_record()                                # dxv / dxvb exist
+        ev_vattn = ev_tfus = None
         for l in reversed(range(self.n_layers)):
             # ================= text layer l
-            t = f"unimo.encoder.text_layer.{l}."
-            s = sv[f"t{l}"]
-            fused = s["fus"] is not None
-            ds2, doo = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-            ops.ln_bwd(dy_f32=d_f32, dy_bf16=d_b16, s=s["s2"], mean=s["m2"], rstd=s["r2"], gamma=st.m(t + "output.LayerNorm.weight"), M=Mt, H=H,
-                       ds_f32=ds2, ds_bf16=doo, p_drop=p_h, seed=seed + 12 + 4 * l,
-                       dgamma=st.g(t + "output.LayerNorm.weight"), dbeta=st.g(t + "output.LayerNorm.bias"))
-            self._wgrad(doo, s["ht"], t + "output.dense.weight", t + "output.dense.bias")
-            dzt = _e((Mt, I), BF, dev)
-            ops.gemm_nt(doo, st.wt(f"t{l}.out"), dzt, mulz=s["zt"], mul_act=ops.ACT_GELU)
-            self._wgrad(dzt, s["ab"], t + "intermediate.dense.weight", t + "intermediate.dense.bias")
-            da2 = _e((Mt, H), BF, dev)
-            ops.gemm_nt(dzt, st.wt(f"t{l}.int"), da2)
-            dctx_fus = None
-            if fused:
-                self._wgrad(dzt, s["fus"], t + "intermediate.fusion_dense.weight", t + "intermediate.fusion_dense.bias")
-                dfus = _e((Mt, H), BF, dev)
-                ops.gemm_nt(dzt, st.wt(f"t{l}.fus"), dfus)
-                dprobs = _e((Mt, Nvp), F32, dev)
-                ops.gemm_nt(dfus, s["visb"], dprobs, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
-                dsc = _e((Mt, Nvp), BF, dev)
-                ops.softmax_bwd(s["probs"], dprobs, dsc, Mt, Nv)
-                dctx_fus = _e((Mt, H), BF, dev)
-                ops.gemm_nt(dsc, s["visT"], dctx_fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
-                # d(vis) = dS^T ctx + P^T d(fus), accumulated into the vision-stream gradient
-                ops.gemm_tn(dsc, s["ctx"], dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
-                ops.gemm_tn(s["probs"], dfus, dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
-            ds1, dso = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-            ops.ln_bwd(dy_f32=ds2, dy_bf16=da2, s=s["s1"], mean=s["m1"], rstd=s["r1"], gamma=st.m(t + "attention.output.LayerNorm.weight"), M=Mt, H=H,
-                       ds_f32=ds1, ds_bf16=dso, p_drop=p_h, seed=seed + 11 + 4 * l,
-                       dgamma=st.g(t + "attention.output.LayerNorm.weight"), dbeta=st.g(t + "attention.output.LayerNorm.bias"))
-            self._wgrad(dso, s["ctx"], t + "attention.output.dense.weight", t + "attention.output.dense.bias")
-            dctx = _e((Mt, H), BF, dev)
-            ops.gemm_nt(dso, st.wt(f"t{l}.ao"), dctx, res_bf16=dctx_fus)
-            # attention backward; for layers whose (K,V) fed a vision layer the k/v blocks already hold the prefix grads
-            has_prefix_grad = self.export_from <= l < self.n_layers - 1
-            dqkv = s.get("dqkv")
-            if dqkv is None:
-                dqkv = _e((Mt, 3 * H), BF, dev)
-            delta = _e((B, nh, Lq), F32, dev)
-            sep_on = s["tkw"]["sep"] is not None
-            ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:], accum_dkv=has_prefix_grad,
-                         dw=st.g(t + "attention.self.adaptive_weight.0") if sep_on else None, **s["tkw"])
-            names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
-            gw = st.fused([n + ".weight" for n in names], st.grad)
-            self._tn(dqkv, s["xb"], gw, colsum=st.fused([n + ".bias" for n in names], st.grad))
-            dtb = _e((Mt, H), BF, dev)
-            ops.gemm_nt(dqkv, st.wt(f"t{l}.qkv"), dtb)
-            d_f32, d_b16 = ds1, dtb
+            with self._text_ctx():
+                t = f"unimo.encoder.text_layer.{l}."
+                s = sv[f"t{l}"]
+                fused = s["fus"] is not None
+                ds2, doo = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+                ops.ln_bwd(dy_f32=d_f32, dy_bf16=d_b16, s=s["s2"], mean=s["m2"], rstd=s["r2"], gamma=st.m(t + "output.LayerNorm.weight"), M=Mt, H=H,
+                           ds_f32=ds2, ds_bf16=doo, p_drop=p_h, seed=seed + 12 + 4 * l,
+                           dgamma=st.g(t + "output.LayerNorm.weight"), dbeta=st.g(t + "output.LayerNorm.bias"))
+                self._wgrad(doo, s["ht"], t + "output.dense.weight", t + "output.dense.bias")
+                dzt = _e((Mt, I), BF, dev)
+                ops.gemm_nt(doo, st.wt(f"t{l}.out"), dzt, mulz=s["zt"], mul_act=ops.ACT_GELU)
+                self._wgrad(dzt, s["ab"], t + "intermediate.dense.weight", t + "intermediate.dense.bias")
+                da2 = _e((Mt, H), BF, dev)
+                ops.gemm_nt(dzt, st.wt(f"t{l}.int"), da2)
+                dctx_fus = None
+                if fused:
+                    self._wgrad(dzt, s["fus"], t + "intermediate.fusion_dense.weight", t + "intermediate.fusion_dense.bias")
+                    dfus = _e((Mt, H), BF, dev)
+                    ops.gemm_nt(dzt, st.wt(f"t{l}.fus"), dfus)
+                    dprobs = _e((Mt, Nvp), F32, dev)
+                    ops.gemm_nt(dfus, s["visb"], dprobs, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
+                    dsc = _e((Mt, Nvp), BF, dev)
+                    ops.softmax_bwd(s["probs"], dprobs, dsc, Mt, Nv)
+                    dctx_fus = _e((Mt, H), BF, dev)
+                    ops.gemm_nt(dsc, s["visT"], dctx_fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
+                    self._text_wait(ev_vdone)                                  # dxv holds the gradient left by vision layer l+1
+                    # d(vis) = dS^T ctx + P^T d(fus), accumulated into the vision-stream gradient
+                    ops.gemm_tn(dsc, s["ctx"], dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
+                    ops.gemm_tn(s["probs"], dfus, dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
+                    ev_tfus = self._text_record()
+                ds1, dso = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+                ops.ln_bwd(dy_f32=ds2, dy_bf16=da2, s=s["s1"], mean=s["m1"], rstd=s["r1"], gamma=st.m(t + "attention.output.LayerNorm.weight"), M=Mt, H=H,
+                           ds_f32=ds1, ds_bf16=dso, p_drop=p_h, seed=seed + 11 + 4 * l,
+                           dgamma=st.g(t + "attention.output.LayerNorm.weight"), dbeta=st.g(t + "attention.output.LayerNorm.bias"))
+                self._wgrad(dso, s["ctx"], t + "attention.output.dense.weight", t + "attention.output.dense.bias")
+                dctx = _e((Mt, H), BF, dev)
+                ops.gemm_nt(dso, st.wt(f"t{l}.ao"), dctx, res_bf16=dctx_fus)
+                # attention backward; for layers whose (K,V) fed a vision layer the k/v blocks already hold the prefix grads
+                has_prefix_grad = self.export_from <= l < self.n_layers - 1
+                dqkv = s.get("dqkv")
+                if dqkv is None:
+                    dqkv = _e((Mt, 3 * H), BF, dev)
+                delta = _e((B, nh, Lq), F32, dev)
+                sep_on = s["tkw"]["sep"] is not None
+                if has_prefix_grad:
+                    self._text_wait(ev_vattn)                              # prefix gradients written by vision layer l+1's attention backward
+                ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:], accum_dkv=has_prefix_grad,
+                             dw=st.g(t + "attention.self.adaptive_weight.0") if sep_on else None, **s["tkw"])
+                names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
+                gw = st.fused([n + ".weight" for n in names], st.grad)
+                self._tn(dqkv, s["xb"], gw, colsum=st.fused([n + ".bias" for n in names], st.grad))
+                dtb = _e((Mt, H), BF, dev)
+                ops.gemm_nt(dqkv, st.wt(f"t{l}.qkv"), dtb)
+                d_f32, d_b16 = ds1, dtb
 
             # ================= vision layer l
+            if l >= self.fuse_from:
+                self._main_wait(ev_tfus)                                   # text layer l added d(vis) into dxv
             v = f"unimo.encoder.vision_layers.{l}."
             s = sv[f"v{l}"]
             if l >= self.fuse_from or l == self.n_layers - 1:          # fusion of text layer l just added d(vis) into dxv
@@ -338,12 +416,14 @@ class UnimoEngine:
             if pre is not None:                                        # prefix grads land in text layer l-1's dqkv buffer (k,v blocks)
                 dpre = _e((Mt, 3 * H), BF, dev)
                 sv[f"t{l - 1}"]["dqkv"] = dpre
+                self._text_uses(dpre)
             q = s["qkv"]
             ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:],
                          dpk=dpre[:, H:2 * H] if dpre is not None else None, dpv=dpre[:, 2 * H:] if dpre is not None else None,
                          q=q[:, :H], k=q[:, H:2 * H], v=q[:, 2 * H:], ctx=s["ctx"], lse=s["lse"], B=B, nh=nh, Sq=Nv, Sk=Nv, scale=0.125,
                          pk=pre[:, H:2 * H] if pre is not None else None, pv=pre[:, 2 * H:] if pre is not None else None,
                          Lp=Lq if pre is not None else 0)
+            ev_vattn = self._main_record()
             names = [v + f"self_attn.{n}" for n in ("q_proj", "k_proj", "v_proj")]
             self._tn(dqkv, s["h1"], st.fused([n + ".weight" for n in names], st.grad), colsum=st.fused([n + ".bias" for n in names], st.grad))
             dh1 = dctx
@@ -352,23 +432,25 @@ class UnimoEngine:
             self._join()                                               # dxvb (read by the fc2 weight-gradient GEMM) is rewritten next
             ops.ln_bwd(dy_bf16=dh1, s=s["x"], mean=s["m1"], rstd=s["r1"], gamma=st.m(v + "layer_norm1.weight"), M=Mv, H=H, add_f32=dx1,
                        ds_f32=dxv, ds_bf16=dxvb, bf16_total=True, dgamma=st.g(v + "layer_norm1.weight"), dbeta=st.g(v + "layer_norm1.bias"))
+            ev_vdone = self._main_record()
             sv[f"v{l}"] = None
             sv[f"t{l}"] = None
             if l > 0:
                 if self.grad_ready is not None:
-                    self._join()
+                    self._join(); self._text_done(); self._text_begin()
                 notify(st.slots[f"unimo.encoder.text_layer.{l - 1}.attention.self.query.weight"].offset)
 
         # ---- text embeddings backward: dropout -> LN -> scatter
-        s_t, tmean, trstd = sv["temb"]
-        u = "unimo.text_embeddings."
-        dyd = _e((Mt, H), F32, dev)
-        ops.dropout_bwd_f32(d_f32, d_b16, dyd, Mt * H, p_h, seed + 1)
-        dse = _e((Mt, H), F32, dev)
-        ops.ln_bwd(dy_f32=dyd, s=s_t, mean=tmean, rstd=trstd, gamma=st.m(u + "LayerNorm.weight"), M=Mt, H=H, ds_f32=dse,
-                   dgamma=st.g(u + "LayerNorm.weight"), dbeta=st.g(u + "LayerNorm.bias"))
-        ops.text_embed_scatter(dse, sv["ids"], sv["tt"], st.g(u + "word_embeddings.weight"), st.g(u + "position_embeddings.weight"),
-                               st.g(u + "token_type_embeddings.weight"), B, Lq, H)
+        with self._text_ctx():
+            s_t, tmean, trstd = sv["temb"]
+            u = "unimo.text_embeddings."
+            dyd = _e((Mt, H), F32, dev)
+            ops.dropout_bwd_f32(d_f32, d_b16, dyd, Mt * H, p_h, seed + 1)
+            dse = _e((Mt, H), F32, dev)
+            ops.ln_bwd(dy_f32=dyd, s=s_t, mean=tmean, rstd=trstd, gamma=st.m(u + "LayerNorm.weight"), M=Mt, H=H, ds_f32=dse,
+                       dgamma=st.g(u + "LayerNorm.weight"), dbeta=st.g(u + "LayerNorm.bias"))
+            ops.text_embed_scatter(dse, sv["ids"], sv["tt"], st.g(u + "word_embeddings.weight"), st.g(u + "position_embeddings.weight"),
+                                   st.g(u + "token_type_embeddings.weight"), B, Lq, H)
         # ---- vision embeddings backward: pre-LN -> assemble -> patch GEMM weight gradient
         patches, s_v, vmean, vrstd = sv["vemb"]
         dsv = _e((Mv, H), F32, dev)
@@ -379,5 +461,6 @@ class UnimoEngine:
                                 B, P, H)
         gw = st.g("unimo.vision_embeddings.patch_embedding.weight")
         self._tn(dpe, patches, gw.view(H, -1))
+        self._text_done()                                             # main stream waits for the text stream
         self._join()
         notify(st.total)
