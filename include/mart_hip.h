@@ -160,7 +160,9 @@ typedef struct {
   void* dq; void* dk; void* dv; int lddq, lddk, lddv;               /* bf16 out */
   void* dpk; void* dpv; int lddp;                                   /* bf16 out for prefix keys */
   int accum_dkv;                                                    /* dk/dv += (text K/V already hold the prefix grads) */
-  float* dw;                                                        /* [2] atomically accumulated d(w0), d(w1) */
+  float* dw;                                                        /* [2] accumulated d(w0), d(w1) */
+  float* dw_ws;                                                     /* optional workspace, 2 * 4 * B * nh * ceil(Sq/128) floats: per-wave partials of dw, summed by a
+                                                                       second tiny kernel instead of thousands of atomics on two addresses */
 } mart_attn_bwd_desc;
 int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream);
 

@@ -69,7 +69,7 @@ class AttnF32(C.Structure):
 class AttnBwd(C.Structure):
     _fields_ = [("f", AttnFwd), ("dctx", vp), ("lddctx", i32), ("delta", vp),
                 ("dq", vp), ("dk", vp), ("dv", vp), ("lddq", i32), ("lddk", i32), ("lddv", i32),
-                ("dpk", vp), ("dpv", vp), ("lddp", i32), ("accum_dkv", i32), ("dw", vp)]
+                ("dpk", vp), ("dpv", vp), ("lddp", i32), ("accum_dkv", i32), ("dw", vp), ("dw_ws", vp)]
 
 
 class AdamW(C.Structure):

@@ -391,10 +391,38 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
   if (TEXT && pb.dw && ctl.sep >= 0) {
     dc0 = wave_sum(dc0); dc1 = wave_sum(dc1);
     if (lane == 0) {
-      const float w0 = p.w0[0], w1 = p.w1[0];
-      if (w0 >= 0.f && w0 <= 0.5f) atomicAdd(pb.dw + 0, dc0);     // clamp sub-gradient: passes inside and AT the bounds
-      if (w1 >= 0.5f && w1 <= 1.f) atomicAdd(pb.dw + 1, dc1);
+      if (pb.dw_ws) {
+        // one private slot per wave; attn_dw_reduce_k sums them.  (Every wave of every workgroup adding to the same two
+        // floats = 6144 contended device-scope atomics per launch: 0.15 ms, more than the rest of the kernel.)
+        const long long slot = (((long long)b * p.nh + h) * gridDim.x + blockIdx.x) * (NTH / 64) + wave;
+        pb.dw_ws[2 * slot] = dc0; pb.dw_ws[2 * slot + 1] = dc1;
+      } else {
+        const float w0 = p.w0[0], w1 = p.w1[0];
+        if (w0 >= 0.f && w0 <= 0.5f) atomicAdd(pb.dw + 0, dc0);     // clamp sub-gradient: passes inside and AT the bounds
+        if (w1 >= 0.5f && w1 <= 1.f) atomicAdd(pb.dw + 1, dc1);
+      }
     }
+  } else if (TEXT && pb.dw && pb.dw_ws && lane == 0) {
+    const long long slot = (((long long)b * p.nh + h) * gridDim.x + blockIdx.x) * (NTH / 64) + wave;
+    pb.dw_ws[2 * slot] = 0.f; pb.dw_ws[2 * slot + 1] = 0.f;
+  }
+}
+
+// sum of the per-wave partials of d(w0), d(w1) -> gradient (clamp sub-gradient: passes inside and AT the bounds)
+__global__ void attn_dw_reduce_k(const float* __restrict__ ws, long long n, const float* w0p, const float* w1p, float* dw) {
+  float a = 0.f, c = 0.f;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) { a += ws[2 * i]; c += ws[2 * i + 1]; }
+  a = wave_sum(a); c = wave_sum(c);
+  __shared__ float red[2][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[0][w] = a; red[1][w] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sa = 0.f, sc = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { sa += red[0][i]; sc += red[1][i]; }
+    const float w0 = w0p[0], w1 = w1p[0];
+    if (w0 >= 0.f && w0 <= 0.5f) dw[0] += sa;
+    if (w1 >= 0.5f && w1 <= 1.f) dw[1] += sc;
   }
 }
 
@@ -597,6 +625,11 @@ extern "C" int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream) {
   if (text) hipLaunchKernelGGL(attn_bwd_dq_k<true>, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   else hipLaunchKernelGGL(attn_bwd_dq_k<false>, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   MART_LAUNCH_CHECK();
+  if (text && d->dw && d->dw_ws && f.sep) {
+    const long long n = (long long)f.B * f.nh * ((f.Sq + 127) / 128) * (NTH / 64);
+    hipLaunchKernelGGL(attn_dw_reduce_k, dim3(1), dim3(1024), 0, st, d->dw_ws, n, f.w0, f.w1, d->dw);
+    MART_LAUNCH_CHECK();
+  }
   if (text) hipLaunchKernelGGL(attn_bwd_dkv_k<true>, dim3((f.Lp + f.Sk + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   else hipLaunchKernelGGL(attn_bwd_dkv_k<false>, dim3((f.Lp + f.Sk + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   MART_LAUNCH_CHECK();

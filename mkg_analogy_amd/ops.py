@@ -164,6 +164,10 @@ def attn_bwd(*, dctx, delta, dq, dk, dv, dpk=None, dpv=None, accum_dkv=False, dw
     d.lddq, d.lddk, d.lddv = _rows2d(dq), _rows2d(dk), _rows2d(dv)
     d.dpk, d.dpv, d.lddp = _p(dpk), _p(dpv), (_rows2d(dpk) if dpk is not None else 0)
     d.accum_dkv, d.dw = int(accum_dkv), _p(dw)
+    ws = None
+    if dw is not None:                               # per-wave partials of d(w0), d(w1) instead of contended atomics
+        ws = torch.empty(2 * 4 * kw["B"] * kw["nh"] * ((kw["Sq"] + 127) // 128), device=dw.device, dtype=F32)
+        d.dw_ws = _p(ws)
     L.check(L.lib().mart_attn_bwd(C.byref(d), _stream()), "mart_attn_bwd")
 
 
