@@ -1,5 +1,6 @@
 // HBM-bound row kernels: LayerNorm family, embeddings, row softmax, transposes.
 // One wave64 per row, 16-byte vector accesses, fp32 statistics (two-pass in registers).
+#include <cstdlib>
 #include "common.h"
 #include "mart_hip.h"
 
@@ -405,7 +406,10 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_bwd: H must be a multiple of 256 and <= 1024");
   MART_CHECK(d->s && d->mean && d->rstd && d->gamma && (d->ds_f32 || d->ds_bf16), "ln_bwd: null pointer");
   int g = row_grid(d->M);
-  if (g > 2048) g = 2048;
+  // 6 workgroups fit a CU (24.6 KB of static LDS each) and every workgroup ends with 2H contended atomics (dgamma, dbeta):
+  // grid = 3 per CU in ONE round measured best (768: 257 us; 1536: 262 us; 2048, i.e. 1.33 rounds: 288 us at M = 100608)
+  static int cap = getenv("MART_LN_BWD_GRID") ? atoi(getenv("MART_LN_BWD_GRID")) : 768;
+  if (g > cap) g = cap;
   if (d->H <= 768) hipLaunchKernelGGL(ln_bwd_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(ln_bwd_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
