@@ -23,15 +23,24 @@ def _e(shape, dtype, dev):
     return torch.empty(shape, device=dev, dtype=dtype)
 
 
-class PreciseUnimoForward:
+class _PreciseBase:
+    """Operand handling shared by the fp32-accurate forwards: cached weight splits, split-GEMM linear, fp32 LayerNorm, scoring."""
+    st: FlatStore
+
+    def _init_base(self, store: FlatStore):
+        self.st = store
+        self._w3: Dict[str, Tuple[int, torch.Tensor]] = {}
+
+
+class PreciseUnimoForward(_PreciseBase):
     def __init__(self, store: FlatStore, vision_cfg, text_cfg):
-        self.st, self.vc, self.tc = store, vision_cfg, text_cfg
+        self._init_base(store)
+        self.vc, self.tc = vision_cfg, text_cfg
         self.H, self.nh, self.I = text_cfg.hidden_size, text_cfg.num_attention_heads, text_cfg.intermediate_size
         self.n_layers = text_cfg.num_hidden_layers
         assert self.H // self.nh == 64
         self.eps_t, self.eps_v = float(text_cfg.layer_norm_eps), 1e-5
         self.fuse_from, self.export_from = 8, 7
-        self._w3: Dict[str, Tuple[int, torch.Tensor]] = {}
 
     # ------------------------------------------------------------------ operands
     def w3(self, names: Sequence[str]) -> torch.Tensor:
@@ -145,3 +154,93 @@ class PreciseUnimoForward:
         out = _e((rows.numel(), ids.numel()), F32, trans.device)
         ops.gemm_nt(t3, self.w3([word_name]), out, a_rows=rows, b_rows=ids, bias=self.st.m(bias_name), bias_by_brow=True)
         return out
+
+
+for _name in ("w3", "lin", "_ln", "score"):
+    setattr(_PreciseBase, _name, PreciseUnimoForward.__dict__[_name])
+
+
+class PreciseFlavaForward(_PreciseBase):
+    """fp32-accurate twin of ``flava_engine.FlavaEngine.forward`` (MarT/models/modeling_flava.py:1373-1476, :2150-2204;
+    SURVEY 8(a) row 19): three pre-LN stacks (image 1+P+P tokens with the tail-position quirk, text with the FLAVA variant
+    of the adaptive reweight -- query row 0 exempt --, multimodal over 1 + image + text tokens without a mask), the two
+    *_to_mm projections of the pre-final-layernorm streams, final multimodal layernorm, MLM head transform."""
+
+    def __init__(self, store: FlatStore, config):
+        self._init_base(store)
+        self.cfg = config
+        tc, ic, mc = config.text_config, config.image_config, config.multimodal_config
+        self.H, self.nh, self.I = tc.hidden_size, tc.num_attention_heads, tc.intermediate_size
+        assert self.H // self.nh == 64
+        self.nt, self.ni, self.nm = tc.num_hidden_layers, ic.num_hidden_layers, mc.num_hidden_layers
+        self.eps = float(tc.layer_norm_eps)
+
+    def _block(self, p: str, x: torch.Tensor, B: int, S: int, **attn):
+        """FlavaLayer.forward (:635-665): x + Attn(LN x); x + MLP(LN x)."""
+        H, I = self.H, self.I
+        a = p + "attention.attention."
+        h1 = self._ln(x, p + "layernorm_before.weight", p + "layernorm_before.bias", self.eps)
+        qkv = self.lin(h1, [a + f"{n}.weight" for n in ("query", "key", "value")], [a + f"{n}.bias" for n in ("query", "key", "value")], 3 * H)
+        ctx = _e((x.shape[0], H), F32, x.device)
+        ops.attn_fwd_f32(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, B=B, nh=self.nh, D=64, Sq=S, Sk=S, scale=0.125, **attn)
+        x1 = self.lin(ctx, [p + "attention.output.dense.weight"], [p + "attention.output.dense.bias"], H, res_f32=x)
+        h2 = self._ln(x1, p + "layernorm_after.weight", p + "layernorm_after.bias", self.eps)
+        f = self.lin(h2, [p + "intermediate.dense.weight"], [p + "intermediate.dense.bias"], I, act=ops.ACT_GELU)
+        return self.lin(f, [p + "output.dense.weight"], [p + "output.dense.bias"], H, res_f32=x1)
+
+    @torch.no_grad()
+    def forward(self, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, image_table=None, image_index=None):
+        st, H = self.st, self.H
+        dev = input_ids.device
+        B, Lq = input_ids.shape
+        ic = self.cfg.image_config
+        S, p = ic.image_size, ic.patch_size
+        P = (S // p) ** 2
+        Nv = 1 + 2 * P
+        Sm = 1 + Nv + Lq
+        Mi, Mt, Mm = B * Nv, B * Lq, B * Sm
+        Kp = 3 * p * p
+        # ---- image embeddings (:308-343) + stack
+        patches = _e((B * 2 * P, Kp), F32, dev)
+        if image_index is not None:
+            ops.patchify_f32(image_table, image_index.contiguous().view(-1), patches, B, S, p)
+        else:
+            ops.patchify_f32(pixel_values.contiguous(), None, patches, B, S, p)
+        e = "flava.image_model.embeddings."
+        pe = self.lin(patches, [e + "patch_embeddings.projection.weight"], [e + "patch_embeddings.projection.bias"], H)
+        xi = _e((Mi, H), F32, dev)
+        ops.vision_assemble_f32(pe, st.m(e + "cls_token"), st.m(e + "position_embeddings"), xi, B, P, H, tail_shift=1)
+        for l in range(self.ni):
+            xi = self._block(f"flava.image_model.encoder.layer.{l}.", xi, B, Nv)
+        # ---- text embeddings (:406-438) + stack (reweight variant :494-496)
+        t = "flava.text_model.embeddings."
+        s_t, tmean, trstd, xt = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev), _e((Mt, H), F32, dev)
+        ops.text_embed_fwd(ids=input_ids, tt=token_type_ids, word=st.m(t + "word_embeddings.weight"), pos=st.m(t + "position_embeddings.weight"),
+                           type_=st.m(t + "token_type_embeddings.weight"), gamma=st.m(t + "LayerNorm.weight"), beta=st.m(t + "LayerNorm.bias"),
+                           eps=self.eps, p_drop=0.0, seed=0, B=B, Lq=Lq, H=H, s_out=s_t, mean=tmean, rstd=trstd, out_f32=xt, out_bf16=None)
+        on = sep_idx is not None
+        for l in range(self.nt):
+            pfx = f"flava.text_model.encoder.layer.{l}."
+            a = pfx + "attention.attention."
+            xt = self._block(pfx, xt, B, Lq, attn_mask=attention_mask, sep=sep_idx[:, 2:] if on else None,
+                             sep_stride=sep_idx.shape[1] if on else 0, w0=st.m(a + "adaptive_weight.0") if on else None,
+                             w1=st.m(a + "adaptive_weight.1") if on else None, rw_skip_row0=True)
+        # ---- multimodal input [cls | image_to_mm(img) | text_to_mm(txt)] (:1430,1450,1455-1456) + stack (no mask :1456)
+        xm = _e((B, Sm, H), F32, dev)
+        xm[:, 0, :].copy_(st.m("flava.multimodal_model.cls_token").view(1, H))
+        ops.gemm_nt(ops.split_bf16x3(xi, 0), self.w3(["flava.image_to_mm_projection.weight"]), xm[0, 1:],
+                    bias=st.m("flava.image_to_mm_projection.bias"), M=Nv, batch=B, stride_a=Nv * 3 * H, stride_c=Sm * H)
+        ops.gemm_nt(ops.split_bf16x3(xt, 0), self.w3(["flava.text_to_mm_projection.weight"]), xm[0, 1 + Nv:],
+                    bias=st.m("flava.text_to_mm_projection.bias"), M=Lq, batch=B, stride_a=Lq * 3 * H, stride_c=Sm * H)
+        xm = xm.view(Mm, H)
+        for l in range(self.nm):
+            xm = self._block(f"flava.multimodal_model.encoder.layer.{l}.", xm, B, Sm)
+        # ---- final layernorm, text positions, MLM head transform (:1209, :2187-2188, :1676-1680)
+        mm = self._ln(xm, "flava.multimodal_model.layernorm.weight", "flava.multimodal_model.layernorm.bias", self.eps)
+        rows = (torch.arange(B, device=dev, dtype=torch.int32)[:, None] * Sm + (1 + Nv) +
+                torch.arange(Lq, device=dev, dtype=torch.int32)[None]).reshape(-1).contiguous()
+        y = _e((Mt, H), F32, dev)
+        ops.gemm_nt(ops.split_bf16x3(mm, 0), self.w3(["cls.transform.dense.weight"]), y, a_rows=rows, bias=st.m("cls.transform.dense.bias"),
+                    act=ops.ACT_GELU)
+        trans = self._ln(y, "cls.transform.LayerNorm.weight", "cls.transform.LayerNorm.bias", self.eps)
+        return trans.view(B, Lq, H)

@@ -240,6 +240,14 @@ class FlavaForMaskedLM(nn.Module):
     def sync_shadows(self):
         self.finalize().refresh_shadows()
 
+    def set_precision(self, precision: str):
+        """"bf16" (training + eval) or "fp32" (evaluation only: fp32 activations, split-bf16 MFMA contractions, fp32 attention;
+        engine_precise.PreciseFlavaForward)."""
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
+        return self
+
     def forward(self, input_ids=None, pixel_values=None, attention_mask=None, token_type_ids=None, bool_masked_pos=None, position_ids=None,
                 image_attention_mask=None, skip_multimodal_encoder=None, output_attentions=None, output_hidden_states=True, return_dict=None,
                 labels=None, sep_idx=None):
@@ -254,6 +262,17 @@ class FlavaForMaskedLM(nn.Module):
         if sep_idx is not None:
             sep_idx = sep_idx.to(dev, torch.int64).contiguous()
         pixel_values = pixel_values.to(dev, torch.float32)
+        if getattr(self, "precision", "bf16") == "fp32":
+            if self.training or labels is not None:
+                raise NotImplementedError("precision='fp32' is the evaluation path (forward only, no labels); call model.eval() or set_precision('bf16')")
+            pr = getattr(self, "_precise", None)
+            if pr is None or pr.st is not st:
+                from ..engine_precise import PreciseFlavaForward
+                pr = self._precise = PreciseFlavaForward(st, self.config)
+            trans = pr.forward(input_ids, attention_mask, token_type_ids, pixel_values, sep_idx)
+            out = MaskedLMOutput(loss=None, logits=Fn.LazyLogits(trans, None, st, word_name="flava.text_model.embeddings.word_embeddings.weight",
+                                                                 bias_name="cls.bias", precise=pr), hidden_states=None, attentions=None)
+            return (out, trans) if return_dict else ((out.logits,), trans)
         self._step += 1
         holder: Dict[str, torch.Tensor] = {}
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx,

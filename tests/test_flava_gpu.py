@@ -89,3 +89,20 @@ def test_flava_forward_backward_vs_oracle():
     for n in ("flava.logit_scale", "flava.image_model.pooler.dense.weight", "flava.text_model.layernorm.weight",
               "flava.image_model.encoder.layer.3.attention.attention.adaptive_weight.0"):
         assert float(st.g(n).abs().max()) == 0.0
+    # ---- fp32-accurate evaluation path (engine_precise.PreciseFlavaForward): north_star's 1e-3 gate on logits
+    model.eval()
+    model.set_precision("fp32")
+    out32, trans32 = model(input_ids=gb["input_ids"], attention_mask=gb["attention_mask"], token_type_ids=gb["token_type_ids"],
+                           pixel_values=gb["pixel_values"], sep_idx=gb["sep_idx"], return_dict=True)
+    ml32 = out32.logits[torch.arange(B, device="cuda"), mi.cuda()][:, ids.cuda()]
+    e32 = float((ml32.cpu() - ml_ref.detach()).abs().max())
+    t32 = float((trans32.cpu() - trans_ref.detach()).abs().max())
+    print(f"   fp32 path: logits max|err| {e32:.3e}  trans max|err| {t32:.3e}")
+    assert e32 < 1e-3 and t32 < 5e-3
+    ev32 = lit._eval(dict(gb), 0)
+    lab = ml_ref.detach()[torch.arange(B), batch["label"]]
+    gap = (ml_ref.detach() - lab[:, None]).abs()
+    gap[torch.arange(B), batch["label"]] = 1e9
+    safe = (gap.min(1).values > 2 * e32).numpy()
+    assert np.array_equal(ev32["entity_ranks"][safe], np.asarray(O.ranks_count(ml_ref.detach(), batch["label"]))[safe])
+    model.set_precision("bf16")
