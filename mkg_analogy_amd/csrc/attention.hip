@@ -9,6 +9,7 @@
 //  vision (CLIPAttention, modeling_unimo.py:212-272): softmax(q k^T * dh^-0.5), no mask, keys = [text prefix | own]
 //  text   (BertSelfAttention, :317-377): scores/8 -> adaptive analogy reweight (:342-349) -> + (1-mask)*-1e4
 //          (:355,:55-56) -> softmax -> dropout(p) on the probabilities (:362)
+#include <cstdlib>
 #include "common.h"
 #include "mart_hip.h"
 
@@ -112,13 +113,15 @@ __device__ __forceinline__ float reweight(const TextCtl& c, int qi, int kj) {
 }
 
 // =========================================================================== forward
-template <bool TEXT>
+// TPW = query tiles (32 rows) per wave.  With TPW = 2 a wave carries two independent softmax / accumulator chains, so the
+// exp-heavy VALU work of one tile overlaps the MFMAs of the other inside the wave, a workgroup covers 256 query rows, and
+// the K/V stream of a head is read by half as many workgroups.
+template <bool TEXT, int TPW>
 __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
   const int Stot = p.Lp + p.Sk;
   const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
@@ -126,17 +129,23 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
   constexpr bool text = TEXT;          // vision instantiation: no mask / reweight / dropout code at all
   const LaneOffs lo = make_offs(lane);
 
-  const int qi = q0 + l31;
-  const bool active = q0 < p.Sq;                      // wave-uniform
-  const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + min(qi, p.Sq - 1)) * p.ldq + h * 64;
-  bf16x8 qf[4];
+  int q0[TPW], qi[TPW];
+  bool active[TPW];
+  bf16x8 qf[TPW][4];
+  f32x16 ot[TPW][2];
+  float m_run[TPW], l_run[TPW];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
-
-  f32x16 ot[2];
+  for (int u = 0; u < TPW; ++u) {
+    q0[u] = blockIdx.x * (128 * TPW) + (wave * TPW + u) * 32;
+    qi[u] = q0[u] + l31;
+    active[u] = q0[u] < p.Sq;                          // wave-uniform
+    const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + min(qi[u], p.Sq - 1)) * p.ldq + h * 64;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
-  float m_run = -1.0e30f, l_run = 0.f;
+    for (int ks = 0; ks < 4; ++ks) qf[u][ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ot[u][0][r] = 0.f; ot[u][1][r] = 0.f; }
+    m_run[u] = -1.0e30f; l_run[u] = 0.f;
+  }
   const float c2 = p.scale * LOG2E;
 
   const int ntiles = (Stot + 63) / 64;
@@ -151,106 +160,125 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
     }
     const char* sK = smem + (kt & 1) * STAGE_BYTES;
     const char* sV = sK + TILE_BYTES;
-    if (!active) continue;                            // wave past the last query row: only stages tiles and keeps the barriers
+    if (!active[0]) continue;                         // wave past the last query row: only stages tiles and keeps the barriers
     // S^T[key][q] = K q^T
-    f32x16 st[2];
+    f32x16 st[TPW][2];
+    float pv[TPW][2][16];
+    float alpha[TPW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int u = 0; u < TPW; ++u) {
+      if (u > 0 && !active[u]) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+      for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) st[t] = mfma32(tile_frag(sK, t, ks, lo), qf[ks], st[t]);
-    }
-    // online softmax in the log2 domain: m_run, the saved statistic and every exponent are base-2 (one v_exp_f32 each)
-    float pv[2][16];
-    float rs = 0.f, alpha;
-    if (!text && kt * 64 + 64 <= Stot) {              // fast path (vision, full tile): 4 VALU per score
-      float mx = st[0][0];
+        for (int r = 0; r < 16; ++r) st[u][t][r] = 0.f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
-      // deferred rescale: while no row's maximum grew by more than 2^8 keep the old reference maximum (probabilities then
-      // reach at most 256, harmless in bf16/f32) and skip the O-wide rescale; decided per wave, before any P is formed
-      float m_new = m_run;
-      alpha = 1.f;
-      if (!__all(mx - m_run <= 8.0f)) {
-        m_new = fmaxf(m_run, mx);
-        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        for (int ks = 0; ks < 4; ++ks) st[u][t] = mfma32(tile_frag(sK, t, ks, lo), qf[u][ks], st[u][t]);
       }
+    }
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+    for (int u = 0; u < TPW; ++u) {
+      if (u > 0 && !active[u]) continue;
+      // online softmax in the log2 domain: m_run, the saved statistic and every exponent are base-2 (one v_exp_f32 each)
+      float rs = 0.f;
+      if (!text && kt * 64 + 64 <= Stot) {              // fast path (vision, full tile): 4 VALU per score
+        float mx = st[u][0][0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -m_new));
-          rs += e;
-          pv[t][r] = e;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
+        // deferred rescale: while no row's maximum grew by more than 2^8 keep the old reference maximum (probabilities then
+        // reach at most 256, harmless in bf16/f32) and skip the O-wide rescale; decided per wave, before any P is formed
+        float m_new = m_run[u];
+        alpha[u] = 1.f;
+        if (!__all(mx - m_run[u] <= 8.0f)) {
+          m_new = fmaxf(m_run[u], mx);
+          alpha[u] = __builtin_amdgcn_exp2f(m_run[u] - m_new);
         }
-      m_run = m_new;
-    } else {
-      float mx = -1.0e30f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
-          float s = st[t][r] * p.scale;
-          if (text) {
-            s *= reweight(ctl, qi, kj);
-            if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(st[u][t][r], c2, -m_new));
+            rs += e;
+            pv[u][t][r] = e;
           }
-          s *= LOG2E;
-          if (kj >= Stot) s = -1.0e30f;
-          pv[t][r] = s;
-          mx = fmaxf(mx, s);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run[u] = m_new;
+      } else {
+        float mx = -1.0e30f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(pv[t][r] - m_new);
-          rs += e;
-          float used = e;
-          if (TEXT && ctl.p_drop > 0.f) {
+          for (int r = 0; r < 16; ++r) {
             const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
-            const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
-            used = dropout_keep(ctl.seed, idx, ctl.p_drop) ? e * ctl.inv_keep : 0.f;
+            float s = st[u][t][r] * p.scale;
+            if (text) {
+              s *= reweight(ctl, qi[u], kj);
+              if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+            }
+            s *= LOG2E;
+            if (kj >= Stot) s = -1.0e30f;
+            pv[u][t][r] = s;
+            mx = fmaxf(mx, s);
           }
-          pv[t][r] = used;
-        }
-      m_run = m_new;
-    }
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    if (!__all(alpha == 1.f)) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[u], mx);
+        alpha[u] = __builtin_amdgcn_exp2f(m_run[u] - m_new);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(pv[u][t][r] - m_new);
+            rs += e;
+            float used = e;
+            if (TEXT && ctl.p_drop > 0.f) {
+              const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
+              const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi[u]) * (uint64_t)Stot + (uint64_t)kj;
+              used = dropout_keep(ctl.seed, idx, ctl.p_drop) ? e * ctl.inv_keep : 0.f;
+            }
+            pv[u][t][r] = used;
+          }
+        m_run[u] = m_new;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run[u] = l_run[u] * alpha[u] + rs;
+      if (!__all(alpha[u] == 1.f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ot[u][0][r] *= alpha[u]; ot[u][1][r] *= alpha[u]; }
+      }
     }
-    // O^T[d][q] += V^T P^T
+    // O^T[d][q] += V^T P^T   (the transposed V fragments are shared by the wave's tiles)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const bf16x8 pf = pack8(&pv[t][8 * a]);
+        bf16x8 vf[2];
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) ot[dt] = mfma32(tile_frag_tr(sV, t * 32 + 16 * a, dt, lo), pf, ot[dt]);
+        for (int dt = 0; dt < 2; ++dt) vf[dt] = tile_frag_tr(sV, t * 32 + 16 * a, dt, lo);
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+          if (u > 0 && !active[u]) continue;
+          const bf16x8 pf = pack8(&pv[u][t][8 * a]);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) ot[u][dt] = mfma32(vf[dt], pf, ot[u][dt]);
+        }
       }
   }
-  if (qi < p.Sq) {
-    const float inv = 1.f / l_run;
-    bf16* op = (bf16*)p.ctx + ((long long)b * p.Sq + qi) * p.ldctx + h * 64;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int u = 0; u < TPW; ++u) {
+    if (qi[u] < p.Sq) {
+      const float inv = 1.f / l_run[u];
+      bf16* op = (bf16*)p.ctx + ((long long)b * p.Sq + qi[u]) * p.ldctx + h * 64;
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        f32x4 v = {ot[dt][4 * qd] * inv, ot[dt][4 * qd + 1] * inv, ot[dt][4 * qd + 2] * inv, ot[dt][4 * qd + 3] * inv};
-        *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
-      }
-    if (hh == 0 && p.lse) p.lse[((long long)b * p.nh + h) * p.Sq + qi] = m_run + __builtin_amdgcn_logf(l_run);   // log2-domain LSE
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          f32x4 v = {ot[u][dt][4 * qd] * inv, ot[u][dt][4 * qd + 1] * inv, ot[u][dt][4 * qd + 2] * inv, ot[u][dt][4 * qd + 3] * inv};
+          *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
+        }
+      if (hh == 0 && p.lse) p.lse[((long long)b * p.nh + h) * p.Sq + qi[u]] = m_run[u] + __builtin_amdgcn_logf(l_run[u]);   // log2-domain LSE
+    }
   }
 }
 
@@ -585,10 +613,11 @@ int check_fwd(const mart_attn_fwd_desc* d) {
 bool g_attr_set = false;
 int set_attrs() {
   if (g_attr_set) return 0;
-  const void* ks[6] = {(const void*)attn_fwd_k<false>, (const void*)attn_fwd_k<true>, (const void*)attn_bwd_dq_k<false>,
-                       (const void*)attn_bwd_dq_k<true>, (const void*)attn_bwd_dkv_k<false>, (const void*)attn_bwd_dkv_k<true>};
+  const void* ks[7] = {(const void*)attn_fwd_k<false, 1>, (const void*)attn_fwd_k<false, 2>, (const void*)attn_fwd_k<true, 1>,
+                       (const void*)attn_bwd_dq_k<false>, (const void*)attn_bwd_dq_k<true>, (const void*)attn_bwd_dkv_k<false>,
+                       (const void*)attn_bwd_dkv_k<true>};
   bool ok = true;
-  for (int i = 0; i < 6; ++i) ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+  for (int i = 0; i < 7; ++i) ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
   if (!ok) {
     mart_set_error("attn: hipFuncSetAttribute failed");
     return -2;
@@ -602,8 +631,10 @@ extern "C" int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream) {
   if (int rc = check_fwd(d)) return rc;
   if (int rc = set_attrs()) return rc;
   const bool text = d->attn_mask || d->sep || d->p_drop > 0.f;
-  if (text) hipLaunchKernelGGL(attn_fwd_k<true>, dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
-  else hipLaunchKernelGGL(attn_fwd_k<false>, dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
+  static const int tpw = getenv("MART_ATTN_TPW") ? atoi(getenv("MART_ATTN_TPW")) : 2;
+  if (text) hipLaunchKernelGGL((attn_fwd_k<true, 1>), dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
+  else if (tpw == 2 && d->Sq > 128) hipLaunchKernelGGL((attn_fwd_k<false, 2>), dim3((d->Sq + 255) / 256, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL((attn_fwd_k<false, 1>), dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
   return 0;
 }
