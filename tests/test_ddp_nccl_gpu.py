@@ -30,4 +30,6 @@ def test_bench_under_torchrun_nccl_one_rank():
                   "--master-port", "29517"] + common, {"MART_FORCE_PG": "1"})
     print("\nplain", plain["loss"], plain["value"], "| nccl(1 rank, forced buckets)", ddp["loss"], ddp["value"])
     assert ddp["n_gpus"] == 1 and ddp["config"]["parallelism"] == "dp1"
-    assert abs(ddp["loss"] - plain["loss"]) < 1e-2          # same seeds and kernels; fp32 atomics order differs run to run (train mode, 4 steps)
+    # same seeds and kernels; fp32 atomics order differs run to run and 4 train-mode steps of this chaotic model amplify it:
+    # four plain runs of this very command gave 7.5603 ... 7.5878 (spread 0.028), so the bound is a sanity check only
+    assert abs(ddp["loss"] - plain["loss"]) < 0.1
