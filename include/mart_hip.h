@@ -49,7 +49,10 @@ typedef struct {
   float alpha;
   void* C; int ldc; int c_f32;
   void* C2; int ldc2;                                             /* optional bf16 copy; 0 -> ldc */
-  int tile_cfg;                                                   /* 0 auto, 128, 256 */
+  int tile_cfg;                                                   /* 0 auto (256x256 tiles from 224 tiles up and M > 128, else 128x128), 128, 256.
+                                                                     Measurement / test hooks, never used by the engine: 2560 BK=32 four-slot ring, 2561 256-tile with the
+                                                                     general epilogue, 2562 fast epilogue without the persistent loop, 999 / 9992 / 9993 timing experiments
+                                                                     (results are wrong on purpose), 70000+t start stagger of t x 10 ns per CU group */
   int b_blocked;                                                  /* B (and B2) stored tile-blocked [N/256][K/64][256][64] (mart_block_table): every LDS-DMA stage of the weight
                                                                      operand is one contiguous 32 KB run instead of 256 strided 128-B rows; needs N % 256 == 0, no b_rows */
 } mart_gemm_nt_desc;
