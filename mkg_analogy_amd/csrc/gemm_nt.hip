@@ -338,7 +338,60 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     __builtin_amdgcn_wave_barrier();
   };
 
-  if constexpr (EPI >= 0) {
+  if constexpr (EPI >= 0 && (EPI & (F_RES | F_MULZ | F_CF32 | F_C2)) == 0) {
+    // ---- bf16-only outputs without streamed operands (plain / bias, and fc1's pre-activation + activation): bias and
+    // activation are applied in MFMA layout, the results go through LDS as packed bf16 (half the staging traffic of the
+    // f32 round trip) and leave as 16-byte stores, 8 lanes per 128-byte row segment.
+    constexpr int NO = ((EPI & F_PREACT) != 0) ? 2 : 1;          // outputs
+    constexpr int RS = WN * 2 + 16;                               // staging row stride in bytes (16-byte aligned rows)
+    static_assert(WN == 64, "bf16 staging is laid out for 64-column wave tiles");
+    char* epb = smem + (PERSIST ? STAGE : 0) + wave * (NO * 32 * RS);
+    const long long cb = bz * p.sC;
+    f32x4 bq[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bq[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int n = en0 + wn0 + j * 32 + 8 * q + 4 * h;
+        if (p.bias) bq[j][q] = *(const f32x4*)(p.bias + n);
+        if (p.bias2) bq[j][q] += *(const f32x4*)(p.bias2 + n);
+      }
+    const int rr = lane >> 3, rc = (lane & 7) * 8;                // read-back: row within 8, first of 8 columns
+    auto block = [&](const int i, const f32x16 (&ai)[TN]) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = f32x4{ai[j][4 * q], ai[j][4 * q + 1], ai[j][4 * q + 2], ai[j][4 * q + 3]} * p.alpha + bq[j][q];
+          char* dst = epb + l31 * RS + (j * 32 + 8 * q + 4 * h) * 2;
+          if constexpr ((EPI & F_PREACT) != 0) *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(v);
+          if constexpr ((EPI & F_ACT) != 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACTK);
+          }
+          *(bf16x4*)dst = f4_to_bf4(v);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + rr, m = em0 + wm0 + i * 32 + row;
+        const bf16x8 o = *(const bf16x8*)(epb + row * RS + rc * 2);
+        const long long oc = cb + (long long)m * p.ldc + en0 + wn0 + rc;
+        if (m < p.M) {
+          st_stream((bf16x8*)((bf16*)p.C + oc), o);
+          if constexpr ((EPI & F_PREACT) != 0) st_stream((bf16x8*)(p.preact + oc), *(const bf16x8*)(epb + 32 * RS + row * RS + rc * 2));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    };
+    block(0, acc[0]);
+    if constexpr (TM > 1) block(1, acc[1]);
+    if constexpr (TM > 2) block(2, acc[2]);
+    if constexpr (TM > 3) block(3, acc[3]);
+  } else if constexpr (EPI >= 0) {
     // ---- fast lane: full-width tiles, 16-byte aligned rows (checked by the host dispatcher).  The streamed operands of a
     // 32-row block (fp32 residual, z of the activation derivative) are fetched BEFORE the LDS round trip of the
     // accumulators: NIT independent loads in flight per lane instead of one load -> compute -> store chain per quad.
@@ -570,7 +623,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
   // fast epilogue instantiations: full-width tiles, 16-byte aligned rows, no gathers / bf16 residual / debug modes
   const int tile = cfg == 256 ? 256 : 128;
-  const bool aligned = (d->ldc % 4 == 0) && (a.ldres % 4 == 0) && (a.ldc2 % 4 == 0) && (d->N % tile == 0) && !d->res_bf16 &&
+  const bool aligned = (d->ldc % (d->c_f32 ? 4 : 8) == 0) && ((uintptr_t)d->preact % 16 == 0) && (d->stride_c % 8 == 0 || d->c_f32) &&
+                       (d->ldc % 4 == 0) && (a.ldres % 4 == 0) && (a.ldc2 % 4 == 0) && (d->N % tile == 0) && !d->res_bf16 &&
                        !d->bias_by_brow && a.dbg == 0 && d->tile_cfg != 2561 &&
                       
                        ((uintptr_t)d->C % 16 == 0) && ((uintptr_t)d->res_f32 % 16 == 0) && ((uintptr_t)d->mulz % 8 == 0) &&
