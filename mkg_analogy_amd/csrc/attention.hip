@@ -282,28 +282,6 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
   }
 }
 
-// =========================================================================== delta = rowsum(dO * O)
-__global__ void attn_delta_k(const bf16* __restrict__ o, int ldo, const bf16* __restrict__ dout, int lddo, float* __restrict__ delta,
-                             int B, int nh, int Sq) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, q, h) with h fastest
-  const long long n = (long long)B * Sq * nh;
-  if (i >= n) return;
-  const int h = (int)(i % nh);
-  const long long row = i / nh;                                             // b*Sq + q
-  const bf16* a = o + row * ldo + h * 64;
-  const bf16* g = dout + row * lddo + h * 64;
-  float acc = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    bf16x8 x = *(const bf16x8*)(a + c * 8), y = *(const bf16x8*)(g + c * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc += (float)x[e] * (float)y[e];
-  }
-  const long long bq = row;
-  const int bb = (int)(bq / Sq), q = (int)(bq % Sq);
-  delta[((long long)bb * nh + h) * Sq + q] = acc;
-}
-
 // =========================================================================== backward, dQ pass (owner = queries)
 template <bool TEXT>
 __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
@@ -330,8 +308,23 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
     gf[ks] = *(const bf16x8*)(gp + ks * 16 + hh * 8);
   }
   const long long li = ((long long)b * p.nh + h) * p.Sq + qc;
-  const float lse = p.lse[li], delta = pb.delta[li];   // lse is the log2-domain statistic saved by the forward pass
+  const float lse = p.lse[li];                          // log2-domain statistic saved by the forward pass
   const bool qvalid = qi < p.Sq;
+  // delta = rowsum(dO * O): this lane holds half of the row's dO already; the matching half of O is one more 64-byte read.
+  // Written out for the dK/dV pass (replaces a separate kernel over both tensors).
+  float delta;
+  {
+    const bf16* op = (const bf16*)p.ctx + ((long long)b * p.Sq + qc) * p.ldctx + h * 64;
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 of = *(const bf16x8*)(op + ks * 16 + hh * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += (float)of[e] * (float)gf[ks][e];
+    }
+    delta = dsum + __shfl_xor(dsum, 32, 64);
+    if (qvalid && hh == 0) pb.delta[li] = delta;
+  }
   const float c2 = p.scale * LOG2E;
 
   f32x16 dq[2];
@@ -648,10 +641,6 @@ extern "C" int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream) {
   if (int rc = set_attrs()) return rc;
   hipStream_t st = (hipStream_t)stream;
   const mart_attn_fwd_desc& f = d->f;
-  const long long n = (long long)f.B * f.Sq * f.nh;
-  hipLaunchKernelGGL(attn_delta_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16*)f.ctx, f.ldctx, (const bf16*)d->dctx,
-                     d->lddctx, d->delta, f.B, f.nh, f.Sq);
-  MART_LAUNCH_CHECK();
   const bool text = f.attn_mask || f.sep || f.p_drop > 0.f;
   if (text) hipLaunchKernelGGL(attn_bwd_dq_k<true>, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   else hipLaunchKernelGGL(attn_bwd_dq_k<false>, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
