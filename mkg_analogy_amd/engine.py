@@ -334,6 +334,7 @@ class UnimoEngine:
         ev_vattn = ev_tfus = None
         for l in reversed(range(self.n_layers)):
             # ================= text layer l
+            dxvb_fresh = False
             with self._text_ctx():
                 t = f"unimo.encoder.text_layer.{l}."
                 s = sv[f"t{l}"]
@@ -372,7 +373,8 @@ class UnimoEngine:
                         ops.transpose_bf16(dfus, dfT, Lq, H, Lq, batch=B, stride_i=Lq * H, stride_o=H * Lq)
                         self._text_wait(ev_vdone)                              # dxv holds the gradient left by vision layer l+1
                         ops.gemm_nt(dscT, ctxT, dxv, A2=prT, B2=dfT, M=Nv, N=H, batch=B, stride_a=Nv * Lq, stride_b=H * Lq,
-                                    stride_c=Nv * H, stride_aux=Nv * H, res_f32=dxv)
+                                    stride_c=Nv * H, stride_aux=Nv * H, res_f32=dxv, C2=dxvb)     # ... and refreshes the bf16 copy
+                        dxvb_fresh = True
                     else:
                         self._text_wait(ev_vdone)
                         ops.gemm_tn(dsc, s["ctx"], dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
@@ -408,7 +410,7 @@ class UnimoEngine:
                 self._main_wait(ev_tfus)                                   # text layer l added d(vis) into dxv
             v = f"unimo.encoder.vision_layers.{l}."
             s = sv[f"v{l}"]
-            if l >= self.fuse_from or l == self.n_layers - 1:          # fusion of text layer l just added d(vis) into dxv
+            if (l >= self.fuse_from or l == self.n_layers - 1) and not dxvb_fresh:   # fusion of text layer l added d(vis) into dxv
                 ops.add_f32_bf16(dxv, None, None, dxvb)                # -> refresh the bf16 copy (otherwise ln1 bwd wrote it)
             self._wgrad(dxvb, s["f"], v + "mlp.fc2.weight", v + "mlp.fc2.bias")
             dz = _e((Mv, I), BF, dev)
