@@ -508,23 +508,21 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
     const float* sLse = (const float*)(sQ + 2 * TILE_BYTES);
     const float* sDel = sLse + 64;
     if (k0 >= Stot) continue;                         // idle wave (keys past the end): staging + barriers only
-    // S[q][key] = Q k^T ; dP[q][key] = dO v^T      (lane = key)
-    f32x16 st[2], dp[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { st[t][r] = 0.f; dp[t][r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        st[t] = mfma32(tile_frag(sQ, t, ks, lo), kf[ks], st[t]);
-        dp[t] = mfma32(tile_frag(sG, t, ks, lo), vf[ks], dp[t]);
-      }
-    }
-    // dV^T[d][key] += dO^T Pd ; dK^T[d][key] += Q^T dS, eight q rows (one MFMA k-slice) at a time so the probabilities
-    // live only as packed bf16 (dS carries no `scale`: it is applied once to dK at the end)
+    // S[q][key] = Q k^T ; dP[q][key] = dO v^T      (lane = key), one 32-row half of the query tile at a time so that only
+    // one S / dP accumulator pair is live (register budget: a third wave per SIMD)
     const bool fast = !text && qt * 64 + 64 <= p.Sq;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        st = mfma32(tile_frag(sQ, t, ks, lo), kf[ks], st);
+        dp = mfma32(tile_frag(sG, t, ks, lo), vf[ks], dp);
+      }
+      // dV^T[d][key] += dO^T Pd ; dK^T[d][key] += Q^T dS, eight q rows (one MFMA k-slice) at a time so the probabilities
+      // live only as packed bf16 (dS carries no `scale`: it is applied once to dK at the end)
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         float pd8[8], ds8[8];
@@ -537,9 +535,9 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * qd + e;
-              const float pr = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -l4[e]));
+              const float pr = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -l4[e]));
               pd8[4 * q2 + e] = pr;
-              ds8[4 * q2 + e] = pr * (dp[t][r] - d4[e]);
+              ds8[4 * q2 + e] = pr * (dp[r] - d4[e]);
             }
           }
         } else {
@@ -548,7 +546,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
             const int r = 8 * a + i;
             const int ql = t * 32 + mfma_row(r, hh);
             const int qi = qt * 64 + ql;
-            float f = 1.f, sc = st[t][r] * p.scale;
+            float f = 1.f, sc = st[r] * p.scale;
             if (text) { f = reweight(ctl, qi, kj); sc = sc * f + maskadd; }
             const float pr = (kvalid && qi < p.Sq) ? __builtin_amdgcn_exp2f(sc * LOG2E - sLse[ql]) : 0.f;
             float keep = 1.f;
@@ -557,7 +555,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
               keep = dropout_keep(ctl.seed, idx, ctl.p_drop) ? ctl.inv_keep : 0.f;
             }
             pd8[i] = pr * keep;
-            ds8[i] = pr * (dp[t][r] * keep - sDel[ql]) * f;
+            ds8[i] = pr * (dp[r] * keep - sDel[ql]) * f;
           }
         }
         const bf16x8 pf = pack8(pd8);
@@ -568,6 +566,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
           dk[dt] = mfma32(tile_frag_tr(sQ, t * 32 + 16 * a, dt, lo), df, dk[dt]);
         }
       }
+    }
   }
   if (!kvalid) return;
   bf16* okp; bf16* ovp; bool acc = false;
