@@ -345,59 +345,54 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
     const char* sK = smem + (kt & 1) * STAGE_BYTES;
     const char* sV = sK + TILE_BYTES;
     if (q0 >= p.Sq) continue;                         // idle wave (rows past Sq): staging + barriers only
-    f32x16 st[2], dp[2];
+    const bool fastp = !text && kt * 64 + 64 <= Stot; // fast path: fma, exp2, sub, mul per score
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 2; ++t) {                      // one 32-key half at a time: one S / dP accumulator pair live
+      f32x16 st, dp;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { st[t][r] = 0.f; dp[t][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        st[t] = mfma32(tile_frag(sK, t, ks, lo), qf[ks], st[t]);
-        dp[t] = mfma32(tile_frag(sV, t, ks, lo), gf[ks], dp[t]);
+        st = mfma32(tile_frag(sK, t, ks, lo), qf[ks], st);
+        dp = mfma32(tile_frag(sV, t, ks, lo), gf[ks], dp);
       }
-    }
-    float dsv[2][16];                                    // d/d(raw q.k) / scale  (scale applied once to the accumulators)
-    if (!text && kt * 64 + 64 <= Stot) {              // fast path: fma, exp2, sub, mul per score
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
+      float dsv[16];                                     // d/d(raw q.k) / scale  (scale applied once to the accumulators)
+      if (fastp) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, -lse));
-          dsv[t][r] = pr * (dp[t][r] - delta);
+          const float pr = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse));
+          dsv[r] = pr * (dp[r] - delta);
         }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
+      } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
-          const float spre = st[t][r] * p.scale;
-          float f = 1.f, s = spre;
+          const float spre = st[r] * p.scale;
+          float f = 1.f, sc = spre;
           if (text) {
             f = reweight(ctl, qi, kj);
-            s *= f;
-            if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+            sc *= f;
+            if (ctl.mask_row && kj < Stot) sc += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
           }
-          float pr = (kj < Stot && qvalid) ? __builtin_amdgcn_exp2f(s * LOG2E - lse) : 0.f;
-          float dpd = dp[t][r];
+          float pr = (kj < Stot && qvalid) ? __builtin_amdgcn_exp2f(sc * LOG2E - lse) : 0.f;
+          float dpd = dp[r];
           if (TEXT && ctl.p_drop > 0.f) {
             const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
             dpd = dropout_keep(ctl.seed, idx, ctl.p_drop) ? dpd * ctl.inv_keep : 0.f;
           }
           const float ds = pr * (dpd - delta);           // d/d(post-reweight, pre-mask score)
           if (TEXT && ctl.sep >= 0 && kj >= ctl.sep) { if (qi >= ctl.sep) dc1 += ds * spre; else if (!(ctl.skip0 && qi == 0)) dc0 += ds * spre; }
-          dsv[t][r] = ds * f;
+          dsv[r] = ds * f;
         }
-    }
-    // dQ^T[d][q] += K^T dS^T
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
+      }
+      // dQ^T[d][q] += K^T dS^T
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const bf16x8 df = pack8(&dsv[t][8 * a]);
+        const bf16x8 df = pack8(&dsv[8 * a]);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tile_frag_tr(sK, t * 32 + 16 * a, dt, lo), df, dq[dt]);
       }
+    }
   }
   if (qvalid) {
     bf16* op = (bf16*)pb.dq + ((long long)b * p.Sq + qi) * pb.lddq + h * 64;
