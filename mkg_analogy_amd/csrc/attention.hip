@@ -283,14 +283,14 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
 }
 
 // =========================================================================== backward, dQ pass (owner = queries)
-template <bool TEXT>
+// TPW query tiles per wave as in the forward kernel (two independent exp / dS chains per wave, half the K/V streams).
+template <bool TEXT, int TPW>
 __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const mart_attn_fwd_desc& p = pb.f;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
   const int Stot = p.Lp + p.Sk;
   const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
@@ -298,38 +298,42 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
   constexpr bool text = TEXT;          // vision instantiation: no mask / reweight / dropout code at all
   const LaneOffs lo = make_offs(lane);
 
-  const int qi = q0 + l31, qc = min(qi, p.Sq - 1);
-  const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + qc) * p.ldq + h * 64;
-  const bf16* gp = (const bf16*)pb.dctx + ((long long)b * p.Sq + qc) * pb.lddctx + h * 64;
-  bf16x8 qf[4], gf[4];
+  int q0[TPW], qi[TPW];
+  bool qvalid[TPW];
+  bf16x8 qf[TPW][4], gf[TPW][4];
+  float lse[TPW], delta[TPW];
+  f32x16 dq[TPW][2];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    qf[ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
-    gf[ks] = *(const bf16x8*)(gp + ks * 16 + hh * 8);
-  }
-  const long long li = ((long long)b * p.nh + h) * p.Sq + qc;
-  const float lse = p.lse[li];                          // log2-domain statistic saved by the forward pass
-  const bool qvalid = qi < p.Sq;
-  // delta = rowsum(dO * O): this lane holds half of the row's dO already; the matching half of O is one more 64-byte read.
-  // Written out for the dK/dV pass (replaces a separate kernel over both tensors).
-  float delta;
-  {
+  for (int u = 0; u < TPW; ++u) {
+    q0[u] = blockIdx.x * (128 * TPW) + (wave * TPW + u) * 32;
+    qi[u] = q0[u] + l31;
+    const int qc = min(qi[u], p.Sq - 1);
+    qvalid[u] = qi[u] < p.Sq;
+    const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + qc) * p.ldq + h * 64;
+    const bf16* gp = (const bf16*)pb.dctx + ((long long)b * p.Sq + qc) * pb.lddctx + h * 64;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[u][ks] = *(const bf16x8*)(qp + ks * 16 + hh * 8);
+      gf[u][ks] = *(const bf16x8*)(gp + ks * 16 + hh * 8);
+    }
+    const long long li = ((long long)b * p.nh + h) * p.Sq + qc;
+    lse[u] = p.lse[li];                                 // log2-domain statistic saved by the forward pass
+    // delta = rowsum(dO * O): this lane holds half of the row's dO already; the matching half of O is one more 64-byte
+    // read.  Written out for the dK/dV pass (replaces a separate kernel over both tensors).
     const bf16* op = (const bf16*)p.ctx + ((long long)b * p.Sq + qc) * p.ldctx + h * 64;
     float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const bf16x8 of = *(const bf16x8*)(op + ks * 16 + hh * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dsum += (float)of[e] * (float)gf[ks][e];
+      for (int e = 0; e < 8; ++e) dsum += (float)of[e] * (float)gf[u][ks][e];
     }
-    delta = dsum + __shfl_xor(dsum, 32, 64);
-    if (qvalid && hh == 0) pb.delta[li] = delta;
+    delta[u] = dsum + __shfl_xor(dsum, 32, 64);
+    if (qvalid[u] && hh == 0) pb.delta[li] = delta[u];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[u][0][r] = 0.f; dq[u][1][r] = 0.f; }
   }
   const float c2 = p.scale * LOG2E;
-
-  f32x16 dq[2];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
   float dc0 = 0.f, dc1 = 0.f;
 
   const int ntiles = (Stot + 63) / 64;
@@ -344,65 +348,72 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
     }
     const char* sK = smem + (kt & 1) * STAGE_BYTES;
     const char* sV = sK + TILE_BYTES;
-    if (q0 >= p.Sq) continue;                         // idle wave (rows past Sq): staging + barriers only
+    if (q0[0] >= p.Sq) continue;                      // idle wave (rows past Sq): staging + barriers only
     const bool fastp = !text && kt * 64 + 64 <= Stot; // fast path: fma, exp2, sub, mul per score
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {                      // one 32-key half at a time: one S / dP accumulator pair live
-      f32x16 st, dp;
+    for (int t = 0; t < 2; ++t) {                      // one 32-key half at a time: one S / dP accumulator pair live per tile
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+      for (int u = 0; u < TPW; ++u) {
+        if (u > 0 && q0[u] >= p.Sq) continue;
+        f32x16 st, dp;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        st = mfma32(tile_frag(sK, t, ks, lo), qf[ks], st);
-        dp = mfma32(tile_frag(sV, t, ks, lo), gf[ks], dp);
-      }
-      float dsv[16];                                     // d/d(raw q.k) / scale  (scale applied once to the accumulators)
-      if (fastp) {
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse));
-          dsv[r] = pr * (dp[r] - delta);
+        for (int ks = 0; ks < 4; ++ks) {
+          st = mfma32(tile_frag(sK, t, ks, lo), qf[u][ks], st);
+          dp = mfma32(tile_frag(sV, t, ks, lo), gf[u][ks], dp);
         }
-      } else {
+        float dsv[16];                                     // d/d(raw q.k) / scale  (scale applied once to the accumulators)
+        if (fastp) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
-          const float spre = st[r] * p.scale;
-          float f = 1.f, sc = spre;
-          if (text) {
-            f = reweight(ctl, qi, kj);
-            sc *= f;
-            if (ctl.mask_row && kj < Stot) sc += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+          for (int r = 0; r < 16; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse[u]));
+            dsv[r] = pr * (dp[r] - delta[u]);
           }
-          float pr = (kj < Stot && qvalid) ? __builtin_amdgcn_exp2f(sc * LOG2E - lse) : 0.f;
-          float dpd = dp[r];
-          if (TEXT && ctl.p_drop > 0.f) {
-            const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
-            dpd = dropout_keep(ctl.seed, idx, ctl.p_drop) ? dpd * ctl.inv_keep : 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
+            const float spre = st[r] * p.scale;
+            float f = 1.f, sc = spre;
+            if (text) {
+              f = reweight(ctl, qi[u], kj);
+              sc *= f;
+              if (ctl.mask_row && kj < Stot) sc += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+            }
+            float pr = (kj < Stot && qvalid[u]) ? __builtin_amdgcn_exp2f(sc * LOG2E - lse[u]) : 0.f;
+            float dpd = dp[r];
+            if (TEXT && ctl.p_drop > 0.f) {
+              const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi[u]) * (uint64_t)Stot + (uint64_t)kj;
+              dpd = dropout_keep(ctl.seed, idx, ctl.p_drop) ? dpd * ctl.inv_keep : 0.f;
+            }
+            const float ds = pr * (dpd - delta[u]);        // d/d(post-reweight, pre-mask score)
+            if (TEXT && ctl.sep >= 0 && kj >= ctl.sep) { if (qi[u] >= ctl.sep) dc1 += ds * spre; else if (!(ctl.skip0 && qi[u] == 0)) dc0 += ds * spre; }
+            dsv[r] = ds * f;
           }
-          const float ds = pr * (dpd - delta);           // d/d(post-reweight, pre-mask score)
-          if (TEXT && ctl.sep >= 0 && kj >= ctl.sep) { if (qi >= ctl.sep) dc1 += ds * spre; else if (!(ctl.skip0 && qi == 0)) dc0 += ds * spre; }
-          dsv[r] = ds * f;
         }
-      }
-      // dQ^T[d][q] += K^T dS^T
+        // dQ^T[d][q] += K^T dS^T
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const bf16x8 df = pack8(&dsv[8 * a]);
+        for (int a = 0; a < 2; ++a) {
+          const bf16x8 df = pack8(&dsv[8 * a]);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tile_frag_tr(sK, t * 32 + 16 * a, dt, lo), df, dq[dt]);
+          for (int dt = 0; dt < 2; ++dt) dq[u][dt] = mfma32(tile_frag_tr(sK, t * 32 + 16 * a, dt, lo), df, dq[u][dt]);
+        }
       }
     }
   }
-  if (qvalid) {
-    bf16* op = (bf16*)pb.dq + ((long long)b * p.Sq + qi) * pb.lddq + h * 64;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+  for (int u = 0; u < TPW; ++u) {
+    if (qvalid[u]) {
+      bf16* op = (bf16*)pb.dq + ((long long)b * p.Sq + qi[u]) * pb.lddq + h * 64;
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        f32x4 v = {dq[dt][4 * qd] * p.scale, dq[dt][4 * qd + 1] * p.scale, dq[dt][4 * qd + 2] * p.scale, dq[dt][4 * qd + 3] * p.scale};
-        *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
-      }
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          f32x4 v = {dq[u][dt][4 * qd] * p.scale, dq[u][dt][4 * qd + 1] * p.scale, dq[u][dt][4 * qd + 2] * p.scale, dq[u][dt][4 * qd + 3] * p.scale};
+          *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
+        }
+    }
   }
   if (TEXT && pb.dw && ctl.sep >= 0) {
     dc0 = wave_sum(dc0); dc1 = wave_sum(dc1);
@@ -600,11 +611,11 @@ int check_fwd(const mart_attn_fwd_desc* d) {
 bool g_attr_set = false;
 int set_attrs() {
   if (g_attr_set) return 0;
-  const void* ks[7] = {(const void*)attn_fwd_k<false, 1>, (const void*)attn_fwd_k<false, 2>, (const void*)attn_fwd_k<true, 1>,
-                       (const void*)attn_bwd_dq_k<false>, (const void*)attn_bwd_dq_k<true>, (const void*)attn_bwd_dkv_k<false>,
+  const void* ks[8] = {(const void*)attn_fwd_k<false, 1>, (const void*)attn_fwd_k<false, 2>, (const void*)attn_fwd_k<true, 1>,
+                       (const void*)attn_bwd_dq_k<false, 1>, (const void*)attn_bwd_dq_k<false, 2>, (const void*)attn_bwd_dq_k<true, 1>, (const void*)attn_bwd_dkv_k<false>,
                        (const void*)attn_bwd_dkv_k<true>};
   bool ok = true;
-  for (int i = 0; i < 7; ++i) ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+  for (int i = 0; i < 8; ++i) ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
   if (!ok) {
     mart_set_error("attn: hipFuncSetAttribute failed");
     return -2;
@@ -636,8 +647,10 @@ extern "C" int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const mart_attn_fwd_desc& f = d->f;
   const bool text = f.attn_mask || f.sep || f.p_drop > 0.f;
-  if (text) hipLaunchKernelGGL(attn_bwd_dq_k<true>, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
-  else hipLaunchKernelGGL(attn_bwd_dq_k<false>, dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
+  static const int tpw = getenv("MART_ATTN_TPW_DQ") ? atoi(getenv("MART_ATTN_TPW_DQ")) : 2;
+  if (text) hipLaunchKernelGGL((attn_bwd_dq_k<true, 1>), dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
+  else if (tpw == 2 && f.Sq > 128) hipLaunchKernelGGL((attn_bwd_dq_k<false, 2>), dim3((f.Sq + 255) / 256, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
+  else hipLaunchKernelGGL((attn_bwd_dq_k<false, 1>), dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   MART_LAUNCH_CHECK();
   if (text && d->dw && d->dw_ws && f.sep) {
     const long long n = (long long)f.B * f.nh * ((f.Sq + 127) / 128) * (NTH / 64);
