@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--seq-len", type=int, default=64)
     ap.add_argument("--patch", type=int, default=16, help="16 -> 196 patches/image (BASELINE), 32 -> 49 (reference default CLIP-B/32)")
     ap.add_argument("--model", default="mkgformer", choices=["mkgformer", "flava"], help="flava = BASELINE configs[3] (parity case; not the headline)")
+    ap.add_argument("--task", default="finetune", choices=["finetune", "pretrain"],
+                    help="pretrain = BASELINE configs[4]: MarKG link-prediction step, LSCE over the full 11 292-entity / 192-relation slices (use --seq-len 96)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
@@ -165,7 +167,10 @@ def main():
     ops.require_gpu()
     dev = torch.device("cuda", local)
     model, lit, cfg = build(a.patch, seed=0, device=dev, backbone=a.model)
-    batch = D.make_batch(a.batch, a.seq_len, seed=1234 + rank, device=dev)
+    pre = a.task == "pretrain"
+    if pre:
+        lit.args.pretrain = 1
+    batch = D.make_batch(a.batch, a.seq_len, seed=1234 + rank, device=dev, pretrain=pre)
     total = a.steps + a.warmup + 4
     tr = Trainer(max_epochs=1, max_steps=10 * total, world_size=world)
     tr._setup(lit, [None] * (10 * total * world))
@@ -229,18 +234,18 @@ def main():
     metrics = tr.validate(lit, [batch])
 
     if rank == 0:
-        out = {"metric": "analogy examples/sec (fine-tune step)", "value": round(value, 2), "unit": "examples/s", "n_gpus": world,
+        out = {"metric": "analogy examples/sec (fine-tune step)" if not pre else "link-prediction examples/sec (pre-train step)", "value": round(value, 2), "unit": "examples/s", "n_gpus": world,
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": (f"MKGformer (BERT-base + ViT-B/{a.patch} patches)" if a.model == "mkgformer" else "FLAVA-base (12+12+6 layers)") +
-                          " fine-tune step, MARS-shaped batch", "batch_per_gpu": a.batch,
+                          (" fine-tune step, MARS-shaped batch" if not pre else " MarKG pre-train step (full entity / relation heads)"), "batch_per_gpu": a.batch,
                           "global_batch": a.batch * world, "seq_len": a.seq_len, "patches_per_image": P, "vision_tokens": 1 + 2 * P,
-                          "entity_head": 2063, "vocab": D.VOCAB, "parallelism": f"dp{world}", "weights": "random-init N(0,0.02)"},
+                          "entity_head": 2063 if not pre else 11292, "vocab": D.VOCAB, "parallelism": f"dp{world}", "weights": "random-init N(0,0.02)"},
                "loss": round(float(loss), 4), "hits1": metrics.get("Eval_entity/hits1"),
                "train_gflop_per_example": round(train_gflop, 1)}
         if roof is not None:
             out["roofline"] = roof
-        if not a.no_cpu_baseline and world == 1 and a.model == "mkgformer":
+        if not a.no_cpu_baseline and world == 1 and a.model == "mkgformer" and not pre:
             out["cpu_baseline"] = cpu_baseline(a.patch, a.seq_len)
         print(json.dumps(out), flush=True)
     if world > 1:
