@@ -10,8 +10,14 @@ BF = torch.bfloat16
 
 
 def timeit(fn, iters=20, warm=3):
-    for _ in range(warm):
+    # the first config timed after an allocation phase used to read 10-15 % slow (clocks still ramping): warm for >= 50 ms
+    t0 = time.perf_counter()
+    n = 0
+    while n < warm or time.perf_counter() - t0 < 0.05:
         fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
