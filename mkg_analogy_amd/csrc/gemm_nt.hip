@@ -12,6 +12,7 @@
 //     per-lane source address -- the gather costs nothing extra
 //   * workgroup ids remapped so that neighbouring tiles (same A panel) share an XCD's L2
 #include "common.h"
+#include <type_traits>
 #include "mart_hip.h"
 
 namespace {
@@ -413,13 +414,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
         }
       }
       stage_block(ai);
+      // Row guard hoisted to one wave-uniform test per block: with a per-row branch around the stores the compiler can no
+      // longer count the outstanding stores at the join and waits vmcnt(0) before every use of a prefetched operand --
+      // i.e. each row iteration waited for the previous row's store to be acknowledged by memory.
+      auto rows = [&](auto guard) {
+      constexpr bool GUARD = decltype(guard)::value;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int row = it * RPI + er, m = em0 + wm0 + i * 32 + row;
         f32x4 v = *(const f32x4*)(ep + row * EP_LD + ec);
         v = v * p.alpha + bv;
         const long long oc = cb + (long long)m * p.ldc + n;
-        const bool ok = m < p.M;
+        const bool ok = !GUARD || m < p.M;
         if constexpr ((EPI & F_PREACT) != 0) { if (ok) st_stream((bf16x4*)(p.preact + oc), f4_to_bf4(v)); }
         if constexpr ((EPI & F_ACT) != 0) {
 #pragma unroll
@@ -437,6 +443,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
           if constexpr ((EPI & F_C2) != 0) st_stream((bf16x4*)(p.C2 + cb + (long long)m * p.ldc2 + n), f4_to_bf4(v));
         }
       }
+      };
+      if (em0 + wm0 + i * 32 + 32 <= p.M) rows(std::false_type{}); else rows(std::true_type{});
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     };
