@@ -23,6 +23,7 @@ extern "C" {
 #define MART_ACT_NONE 0
 #define MART_ACT_GELU 1   /* erf GELU   : transformers ACT2FN["gelu"],       modeling_unimo.py:454,967 */
 #define MART_ACT_QGELU 2  /* quick GELU : transformers ACT2FN["quick_gelu"], modeling_unimo.py:279     */
+#define MART_ACT_STORED 3 /* mul_act only: mulz already holds act'(z) (written by a forward call with preact_grad) */
 
 const char* mart_last_error(void);
 int mart_abi_version(void);
@@ -32,6 +33,9 @@ int mart_check_device(void);
 /* ---------------------------------------------------------------- dense contractions
  * C = epi( alpha * (A[M,K] B[N,K]^T + A2[M,K2] B2[N,K2]^T) ), bf16 operands, fp32 accumulate.
  * epi: +bias(+bias2) -> store preact -> act -> *act'(mulz) -> +res_f32 -> +res_bf16 -> store C (bf16|f32) [+C2 bf16]
+ * preact_grad: the preact buffer receives act'(z) instead of z -- the forward pass has sigmoid / erf of z in registers
+ * anyway, and the backward product (mulz = that buffer, mul_act = MART_ACT_STORED) becomes a plain multiply: the two
+ * transcendentals per element of the derivative were a third of the data-gradient GEMM's epilogue time.
  * Replaces nn.Linear / F.linear / conv-as-GEMM / bmm call sites: modeling_unimo.py:123-124 (patch embedding),
  * :223-225,270 (CLIP q/k/v/out_proj), :284-286 (CLIP MLP), :327-333 (BERT q/k/v), :388,459-463,475 (BERT dense,
  * intermediate.dense + fusion_dense as one K=2H contraction, output.dense), :405,411 (fusion bmm),
@@ -53,6 +57,7 @@ typedef struct {
                                                                      Measurement / test hooks, never used by the engine: 2560 BK=32 four-slot ring, 2561 256-tile with the
                                                                      general epilogue, 2562 fast epilogue without the persistent loop, 999 / 9992 / 9993 timing experiments
                                                                      (results are wrong on purpose), 70000+t start stagger of t x 10 ns per CU group */
+  int preact_grad;                                                /* preact receives act'(z) rather than z (needs preact and act) */
   int b_blocked;                                                  /* B (and B2) stored tile-blocked [N/256][K/64][256][64] (mart_block_table): every LDS-DMA stage of the weight
                                                                      operand is one contiguous 32 KB run instead of 256 strided 128-B rows; needs N % 256 == 0, no b_rows */
 } mart_gemm_nt_desc;

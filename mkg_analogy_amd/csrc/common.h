@@ -84,6 +84,7 @@ __device__ __forceinline__ f32x4 bf4_to_f4(bf16x4 v) {
 #define ACT_NONE 0
 #define ACT_GELU 1
 #define ACT_QGELU 2
+#define ACT_STORED 3   // act_grad only: the operand already is act'(z)
 // sigmoid(1.702 z) with the hardware exp2 / rcp (1 ulp each): the IEEE division the plain expression compiles to is ten
 // VALU instructions per element -- 128 elements per lane in a 256x256 GEMM epilogue, i.e. microseconds per tile.
 __device__ __forceinline__ float qgelu_sigmoid(float z) {
@@ -94,7 +95,19 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == ACT_QGELU) return z * qgelu_sigmoid(z);
   return z;
 }
+// a = act(z), g = act'(z) from one evaluation of the sigmoid / erf
+__device__ __forceinline__ void act_fwd_grad(float z, int act, float& a, float& g) {
+  if (act == ACT_GELU) {
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);
+    a = z * cdf; g = cdf + z * pdf;
+  } else if (act == ACT_QGELU) {
+    const float s = qgelu_sigmoid(z);
+    a = z * s; g = s * (1.0f + 1.702f * z * (1.0f - s));
+  } else { a = z; g = 1.0f; }
+}
 __device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == ACT_STORED) return z;
   if (act == ACT_GELU) {
     float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
     float pdf = 0.39894228040143267794f * __expf(-0.5f * z * z);

@@ -45,7 +45,7 @@ struct Args {
   long long sA, sB, sC, sAux;       // batch strides in elements (A/A2, B/B2, C/C2/preact, residual/mulz)
   const float* bias; const float* bias2; int bias_by_brow;
   int act;
-  bf16* preact;
+  bf16* preact; int preact_grad;
   const bf16* mulz; int mul_act;
   const float* res_f32; const bf16* res_bf16; int ldres;
   float alpha;
@@ -59,7 +59,7 @@ struct Args {
 // Epilogue feature mask of the specialised ("fast") instantiations.  EPI < 0 = the general epilogue (tails, gathers,
 // bf16 residual, unaligned rows).  Every large product of the step maps to one of the fast masks; their epilogues are a few
 // hundred bytes of straight-line vector code (the general one made the kernel 200 KB and instruction-fetch bound).
-enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32 };
+enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32, F_PGRAD = 64 };   // F_PGRAD: preact holds act'(z)
 
 // PERSIST: one workgroup per CU slot walks over its tiles; the first K-tile of the NEXT tile is put in flight before the
 // epilogue of the current one, so the ~2-3 us of launch + first-DMA latency per tile hide behind the epilogue.
@@ -339,6 +339,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     __builtin_amdgcn_wave_barrier();
   };
 
+  static_assert(EPI < 0 || (EPI & F_PGRAD) == 0 || (EPI & (F_PREACT | F_ACT | F_RES | F_MULZ | F_CF32 | F_C2)) == (F_PREACT | F_ACT),
+                "act'(z) output is a fast-lane option of the bf16 pre-activation + activation epilogue only");
   if constexpr (EPI >= 0 && (EPI & (F_RES | F_MULZ | F_CF32 | F_C2)) == 0) {
     // ---- bf16-only outputs without streamed operands (plain / bias, and fc1's pre-activation + activation): bias and
     // activation are applied in MFMA layout, the results go through LDS as packed bf16 (half the staging traffic of the
@@ -366,10 +368,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
         for (int q = 0; q < 4; ++q) {
           f32x4 v = f32x4{ai[j][4 * q], ai[j][4 * q + 1], ai[j][4 * q + 2], ai[j][4 * q + 3]} * p.alpha + bq[j][q];
           char* dst = epb + l31 * RS + (j * 32 + 8 * q + 4 * h) * 2;
-          if constexpr ((EPI & F_PREACT) != 0) *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(v);
-          if constexpr ((EPI & F_ACT) != 0) {
+          if constexpr ((EPI & F_PGRAD) != 0) {
+            f32x4 g;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACTK);
+            for (int e = 0; e < 4; ++e) { float a_, g_; act_fwd_grad(v[e], ACTK, a_, g_); v[e] = a_; g[e] = g_; }
+            *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(g);
+          } else {
+            if constexpr ((EPI & F_PREACT) != 0) *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(v);
+            if constexpr ((EPI & F_ACT) != 0) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACTK);
+            }
           }
           *(bf16x4*)dst = f4_to_bf4(v);
         }
@@ -401,57 +410,69 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bv = *(const f32x4*)(p.bias + n);
     if (p.bias2) bv += *(const f32x4*)(p.bias2 + n);
-    auto block = [&](const int i, const f32x16 (&ai)[TN]) {
-      f32x4 pr[NIT];
-      bf16x4 pz[NIT];
-      if constexpr ((EPI & (F_RES | F_MULZ)) != 0) {
+    // Straight-line code per arm: one wave-uniform row-guard test for the whole sub-tile (with a per-row branch around
+    // the stores -- or even a per-block one -- the compiler cannot count the outstanding stores at the join and waits
+    // vmcnt(0) before every use of a prefetched operand: each row then waited for the previous row's store to be
+    // acknowledged by memory).  The streamed operands run NPRE blocks ahead of their use and are requested before the
+    // stores of the blocks in between, so the in-order vmcnt wait for them never covers a store of this tile.
+    constexpr bool PF = (EPI & (F_RES | F_MULZ)) != 0;
+    constexpr int NPRE = !PF ? 1 : (EPI & F_RES) != 0 ? (TM < 2 ? TM : 2) : (PERSIST && TM > 3 ? 2 : TM);   // 32 / 16 VGPRs per block in flight (persistent: next to the following tile's addressing)
+    auto run = [&](auto guard) {
+      constexpr bool GUARD = decltype(guard)::value;
+      f32x4 pr[NPRE][NIT];
+      bf16x4 pz[NPRE][NIT];
+      auto fetch = [&](const int i) {
+        if constexpr (PF) {
+#pragma unroll
+          for (int it = 0; it < NIT; ++it) {
+            const int m = min(em0 + wm0 + i * 32 + it * RPI + er, p.M - 1);
+            const long long orr = ab + (long long)m * p.ldres + n;
+            if constexpr ((EPI & F_RES) != 0) pr[i % NPRE][it] = ld_stream((const f32x4*)(p.res_f32 + orr));
+            if constexpr ((EPI & F_MULZ) != 0) pz[i % NPRE][it] = ld_stream((const bf16x4*)(p.mulz + orr));
+          }
+        }
+      };
+      auto block = [&](const int i, const f32x16 (&ai)[TN]) {
+        stage_block(ai);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          const int m = min(em0 + wm0 + i * 32 + it * RPI + er, p.M - 1);
-          const long long orr = ab + (long long)m * p.ldres + n;
-          if constexpr ((EPI & F_RES) != 0) pr[it] = ld_stream((const f32x4*)(p.res_f32 + orr));
-          if constexpr ((EPI & F_MULZ) != 0) pz[it] = ld_stream((const bf16x4*)(p.mulz + orr));
-        }
-      }
-      stage_block(ai);
-      // Row guard hoisted to one wave-uniform test per block: with a per-row branch around the stores the compiler can no
-      // longer count the outstanding stores at the join and waits vmcnt(0) before every use of a prefetched operand --
-      // i.e. each row iteration waited for the previous row's store to be acknowledged by memory.
-      auto rows = [&](auto guard) {
-      constexpr bool GUARD = decltype(guard)::value;
+          const int row = it * RPI + er, m = em0 + wm0 + i * 32 + row;
+          f32x4 v = *(const f32x4*)(ep + row * EP_LD + ec);
+          v = v * p.alpha + bv;
+          const long long oc = cb + (long long)m * p.ldc + n;
+          const bool ok = !GUARD || m < p.M;
+          if constexpr ((EPI & F_PREACT) != 0) { if (ok) st_stream((bf16x4*)(p.preact + oc), f4_to_bf4(v)); }
+          if constexpr ((EPI & F_ACT) != 0) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int row = it * RPI + er, m = em0 + wm0 + i * 32 + row;
-        f32x4 v = *(const f32x4*)(ep + row * EP_LD + ec);
-        v = v * p.alpha + bv;
-        const long long oc = cb + (long long)m * p.ldc + n;
-        const bool ok = !GUARD || m < p.M;
-        if constexpr ((EPI & F_PREACT) != 0) { if (ok) st_stream((bf16x4*)(p.preact + oc), f4_to_bf4(v)); }
-        if constexpr ((EPI & F_ACT) != 0) {
+            for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACTK);
+          }
+          if constexpr ((EPI & F_MULZ) != 0) {
+            const f32x4 z = bf4_to_f4(pz[i % NPRE][it]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACTK);
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad(z[e], ACTK);
+          }
+          if constexpr ((EPI & F_RES) != 0) v += pr[i % NPRE][it];
+          if (ok) {
+            if constexpr ((EPI & F_CF32) != 0) st_stream((f32x4*)((float*)p.C + oc), v);
+            else st_stream((bf16x4*)((bf16*)p.C + oc), f4_to_bf4(v));
+            if constexpr ((EPI & F_C2) != 0) st_stream((bf16x4*)(p.C2 + cb + (long long)m * p.ldc2 + n), f4_to_bf4(v));
+          }
         }
-        if constexpr ((EPI & F_MULZ) != 0) {
-          const f32x4 z = bf4_to_f4(pz[it]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= act_grad(z[e], ACTK);
-        }
-        if constexpr ((EPI & F_RES) != 0) v += pr[it];
-        if (ok) {
-          if constexpr ((EPI & F_CF32) != 0) st_stream((f32x4*)((float*)p.C + oc), v);
-          else st_stream((bf16x4*)((bf16*)p.C + oc), f4_to_bf4(v));
-          if constexpr ((EPI & F_C2) != 0) st_stream((bf16x4*)(p.C2 + cb + (long long)m * p.ldc2 + n), f4_to_bf4(v));
-        }
-      }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
       };
-      if (em0 + wm0 + i * 32 + 32 <= p.M) rows(std::false_type{}); else rows(std::true_type{});
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
+      fetch(0);
+      if constexpr (NPRE > 1) fetch(1);
+      if constexpr (NPRE > 2) fetch(2);
+      if constexpr (NPRE > 3) fetch(3);
+      block(0, acc[0]);
+      if constexpr (NPRE < TM) fetch(NPRE);                        // refill the slot block 0 just freed
+      if constexpr (TM > 1) block(1, acc[1]);
+      if constexpr (NPRE + 1 < TM) fetch(NPRE + 1);
+      if constexpr (TM > 2) block(2, acc[2]);
+      if constexpr (TM > 3) block(3, acc[3]);
     };
-    block(0, acc[0]);
-    if constexpr (TM > 1) block(1, acc[1]);
-    if constexpr (TM > 2) block(2, acc[2]);
-    if constexpr (TM > 3) block(3, acc[3]);
+    if (em0 + wm0 + WM <= p.M) run(std::false_type{}); else run(std::true_type{});
     static_assert(TM <= 4, "epilogue blocks are written out for TM <= 4");
   } else {
   // ---- general lane: lane owns row m, 4 consecutive n per register quad
@@ -486,10 +507,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     }
     const long long oc = (long long)m * p.ldc + n;
     if (PA) {
-      if (full) st_stream((bf16x4*)(PA + oc), f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]}));
+      float pa[4] = {v[0], v[1], v[2], v[3]};
+      if (p.preact_grad) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pa[e] = act_grad(v[e], p.act);
+      }
+      if (full) st_stream((bf16x4*)(PA + oc), f4_to_bf4(f32x4{pa[0], pa[1], pa[2], pa[3]}));
       else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) PA[oc + e] = f2bf(v[e]);
+        for (int e = 0; e < 4; ++e) if (e < nv) PA[oc + e] = f2bf(pa[e]);
       }
     }
     if (p.act != ACT_NONE) {
@@ -602,6 +628,9 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   MART_CHECK((d->K2 == 0) == (d->A2 == nullptr) && (d->K2 == 0) == (d->B2 == nullptr), "gemm_nt: A2/B2/K2 inconsistent");
   MART_CHECK(d->C != nullptr && d->ldc >= d->N, "gemm_nt: bad C/ldc");
   MART_CHECK(!d->bias_by_brow || d->b_rows, "gemm_nt: bias_by_brow needs b_rows");
+  MART_CHECK(d->act >= ACT_NONE && d->act <= ACT_QGELU, "gemm_nt: act must be NONE, GELU or QGELU");
+  MART_CHECK(!d->preact_grad || (d->preact && d->act != ACT_NONE), "gemm_nt: preact_grad needs preact and an activation");
+  MART_CHECK(d->mul_act >= ACT_NONE && d->mul_act <= ACT_STORED && (d->mul_act == ACT_NONE || d->mulz), "gemm_nt: bad mul_act");
   MART_CHECK(!d->b_blocked || (d->N % 256 == 0 && !d->b_rows && (d->batch <= 1 || d->stride_b == 0)), "gemm_nt: b_blocked needs N % 256 == 0, no b_rows, shared B");
   MART_CHECK((long long)d->M * d->lda < (1LL << 32) && (long long)d->N * d->ldb < (1LL << 32) || d->a_rows || d->b_rows,
              "gemm_nt: operand too large for 32-bit element offsets");
@@ -611,7 +640,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   a.a_rows = d->a_rows; a.b_rows = d->b_rows;
   a.sA = d->stride_a; a.sB = d->stride_b; a.sC = d->stride_c; a.sAux = d->stride_aux;
   a.bias = d->bias; a.bias2 = d->bias2; a.bias_by_brow = d->bias_by_brow;
-  a.act = d->act; a.preact = (bf16*)d->preact; a.mulz = (const bf16*)d->mulz; a.mul_act = d->mul_act;
+  a.act = d->act; a.preact = (bf16*)d->preact; a.preact_grad = d->preact_grad; a.mulz = (const bf16*)d->mulz; a.mul_act = d->mul_act;
   a.res_f32 = d->res_f32; a.res_bf16 = (const bf16*)d->res_bf16; a.ldres = d->ldres ? d->ldres : d->ldc;
   a.alpha = d->alpha; a.C = d->C; a.ldc = d->ldc; a.c_f32 = d->c_f32; a.C2 = (bf16*)d->C2;
   a.ldc2 = d->ldc2 ? d->ldc2 : d->ldc;
@@ -639,7 +668,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
                        ((uintptr_t)d->preact % 8 == 0) && ((uintptr_t)d->C2 % 8 == 0) && ((uintptr_t)d->bias % 16 == 0) &&
                        ((uintptr_t)d->bias2 % 16 == 0) && (d->stride_c % 4 == 0) && (d->stride_aux % 4 == 0);
   const bool two_acts = d->mulz && d->act != ACT_NONE;               // not a fast combination
-  const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
+  const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->preact_grad ? F_PGRAD : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
                    (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
   if (aligned) {
     // persistent loop: +6-7 % where the epilogue is light (bf16 out), neutral with the fp32 residual, -11 % with two bf16
@@ -654,10 +683,13 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
     MART_FAST(F_CF32, ACT_NONE)                   // f32 out: scores, head
     MART_FAST(F_CF32 | F_RES, ACT_NONE)           // residual stream: out-proj, fc2
     MART_FAST(F_CF32 | F_RES | F_C2, ACT_NONE)    // ... with a bf16 copy for the fusion layers
-    MART_FAST(F_MULZ, ACT_QGELU)                  // data gradient through the activation (vision / text)
-    MART_FAST(F_MULZ, ACT_GELU)
-    MART_FAST(F_PREACT | F_ACT, ACT_QGELU)        // fc1 / intermediate: z and act(z)
-    MART_FAST(F_PREACT | F_ACT, ACT_GELU)
+    MART_FAST(F_MULZ, ACT_STORED)                 // data gradient through the activation: * act'(z) saved by the forward pass
+    MART_FAST(F_PREACT | F_ACT | F_PGRAD, ACT_QGELU)   // fc1 / intermediate: act(z) and act'(z)
+    MART_FAST(F_PREACT | F_ACT | F_PGRAD, ACT_GELU)
+    MART_FAST(F_ACT, ACT_QGELU)                   // ... activation only (forward under no_grad)
+    MART_FAST(F_ACT, ACT_GELU)
+    MART_FAST(F_PREACT | F_ACT, ACT_QGELU)        // ... z itself (callers that differentiate later with mul_act = the activation)
+    MART_FAST(F_MULZ, ACT_QGELU)
     MART_FAST(F_CF32 | F_ACT, ACT_GELU)           // head transform / precise-path GELU (f32 out)
     MART_FAST(F_CF32 | F_ACT, ACT_QGELU)
 #undef MART_FAST

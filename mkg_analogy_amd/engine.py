@@ -148,6 +148,7 @@ class UnimoEngine:
         sv: Dict[str, object] = dict(B=B, L=Lq, P=P, Nv=Nv, Nvp=Nvp, train=train, seed=seed,
                                      ids=input_ids, tt=token_type_ids, am=attention_mask, sep=sep_idx)
         p_h = self.p_hidden if train else 0.0
+        keep = bool(getattr(self, "save_for_backward", True))      # False under torch.no_grad(): backward-only outputs are skipped
         p_a = self.p_attn if train else 0.0
         self._text_begin()                            # text stream starts behind whatever produced the inputs
 
@@ -211,9 +212,10 @@ class UnimoEngine:
             h2, m2, r2 = _e((Mv, H), BF, dev), _e((Mv,), F32, dev), _e((Mv,), F32, dev)
             ops.ln_fwd(x_f32=x1, gamma=st.m(v + "layer_norm2.weight"), beta=st.m(v + "layer_norm2.bias"), eps=self.eps_v, M=Mv, H=H,
                        mean=m2, rstd=r2, out_bf16=h2)
-            z, f = _e((Mv, I), BF, dev), _e((Mv, I), BF, dev)
+            # z holds act'(fc1 output) (the only thing the backward pass needs of it); nothing is written under no_grad
+            z, f = (_e((Mv, I), BF, dev) if keep else None), _e((Mv, I), BF, dev)
             w, b = self._lin(v + "mlp.fc1")
-            ops.gemm_nt(h2, w, f, bias=b, act=ops.ACT_QGELU, preact=z)
+            ops.gemm_nt(h2, w, f, bias=b, act=ops.ACT_QGELU, preact=z, preact_grad=keep)
             x2 = _e((Mv, H), F32, dev)
             x2b = _e((Mv, H), BF, dev) if l >= self.fuse_from else None
             w, b = self._lin(v + "mlp.fc2")
@@ -258,13 +260,13 @@ class UnimoEngine:
                 a, ab = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
                 ops.ln_fwd(x_f32=xt, y_bf16=so, p_drop=p_h, seed=seed + 11 + 4 * l, gamma=st.m(t + "attention.output.LayerNorm.weight"),
                            beta=st.m(t + "attention.output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=am1, rstd=ar1, s_out=s1, out_f32=a, out_bf16=ab)
-                zt, ht = _e((Mt, I), BF, dev), _e((Mt, I), BF, dev)
+                zt, ht = (_e((Mt, I), BF, dev) if keep else None), _e((Mt, I), BF, dev)
                 w, b = self._lin(t + "intermediate.dense")
                 if fus is not None:
                     wf, bf_ = self._lin(t + "intermediate.fusion_dense")
-                    ops.gemm_nt(ab, w, ht, A2=fus, B2=wf, bias=b, bias2=bf_, act=ops.ACT_GELU, preact=zt)
+                    ops.gemm_nt(ab, w, ht, A2=fus, B2=wf, bias=b, bias2=bf_, act=ops.ACT_GELU, preact=zt, preact_grad=keep)
                 else:
-                    ops.gemm_nt(ab, w, ht, bias=b, act=ops.ACT_GELU, preact=zt)
+                    ops.gemm_nt(ab, w, ht, bias=b, act=ops.ACT_GELU, preact=zt, preact_grad=keep)
                 oo = _e((Mt, H), BF, dev)
                 w, b = self._lin(t + "output.dense")
                 ops.gemm_nt(ht, w, oo, bias=b)
@@ -345,7 +347,7 @@ class UnimoEngine:
                            dgamma=st.g(t + "output.LayerNorm.weight"), dbeta=st.g(t + "output.LayerNorm.bias"))
                 self._wgrad(doo, s["ht"], t + "output.dense.weight", t + "output.dense.bias")
                 dzt = _e((Mt, I), BF, dev)
-                ops.gemm_nt(doo, st.wt(f"t{l}.out"), dzt, mulz=s["zt"], mul_act=ops.ACT_GELU)
+                ops.gemm_nt(doo, st.wt(f"t{l}.out"), dzt, mulz=s["zt"], mul_act=ops.ACT_STORED)
                 self._wgrad(dzt, s["ab"], t + "intermediate.dense.weight", t + "intermediate.dense.bias")
                 da2 = _e((Mt, H), BF, dev)
                 ops.gemm_nt(dzt, st.wt(f"t{l}.int"), da2)
@@ -414,7 +416,7 @@ class UnimoEngine:
                 ops.add_f32_bf16(dxv, None, None, dxvb)                # -> refresh the bf16 copy (otherwise ln1 bwd wrote it)
             self._wgrad(dxvb, s["f"], v + "mlp.fc2.weight", v + "mlp.fc2.bias")
             dz = _e((Mv, I), BF, dev)
-            ops.gemm_nt(dxvb, st.wt(f"v{l}.fc2"), dz, mulz=s["z"], mul_act=ops.ACT_QGELU)
+            ops.gemm_nt(dxvb, st.wt(f"v{l}.fc2"), dz, mulz=s["z"], mul_act=ops.ACT_STORED)
             self._wgrad(dz, s["h2"], v + "mlp.fc1.weight", v + "mlp.fc1.bias")
             dh2 = _e((Mv, H), BF, dev)
             ops.gemm_nt(dz, st.wt(f"v{l}.fc1"), dh2)

@@ -111,8 +111,9 @@ class FlavaEngine:
         h2, m2, r2 = _e((M, H), BF, dev), _e((M,), F32, dev), _e((M,), F32, dev)
         ops.ln_fwd(x_f32=x1, gamma=st.m(p + "layernorm_after.weight"), beta=st.m(p + "layernorm_after.bias"), eps=self.eps, M=M, H=H,
                    mean=m2, rstd=r2, out_bf16=h2)
-        z, f = _e((M, I), BF, dev), _e((M, I), BF, dev)
-        ops.gemm_nt(h2, st.w(p + "intermediate.dense.weight"), f, bias=st.m(p + "intermediate.dense.bias"), act=ops.ACT_GELU, preact=z)
+        keep = bool(getattr(self, "save_for_backward", True))      # False under torch.no_grad(): backward-only outputs are skipped
+        z, f = (_e((M, I), BF, dev) if keep else None), _e((M, I), BF, dev)   # z = gelu'(intermediate.dense output)
+        ops.gemm_nt(h2, st.w(p + "intermediate.dense.weight"), f, bias=st.m(p + "intermediate.dense.bias"), act=ops.ACT_GELU, preact=z, preact_grad=keep)
         x2 = _e((M, H), F32, dev)
         x2b = _e((M, H), BF, dev) if want_bf16 else None
         ops.gemm_nt(f, st.w(p + "output.dense.weight"), x2, bias=st.m(p + "output.dense.bias"), res_f32=x1, C2=x2b)
@@ -127,7 +128,7 @@ class FlavaEngine:
             ops.gemm_tn(X, Y, g.view(g.shape[0], -1), colsum=st.g(bn))
         wgrad(dxb, s["f"], p + "output.dense.weight", p + "output.dense.bias")
         dz = _e((M, I), BF, dev)
-        ops.gemm_nt(dxb, st.wt(key + ".fc2"), dz, mulz=s["z"], mul_act=ops.ACT_GELU)
+        ops.gemm_nt(dxb, st.wt(key + ".fc2"), dz, mulz=s["z"], mul_act=ops.ACT_STORED)
         wgrad(dz, s["h2"], p + "intermediate.dense.weight", p + "intermediate.dense.bias")
         dh2 = _e((M, H), BF, dev)
         ops.gemm_nt(dz, st.wt(key + ".fc1"), dh2)

@@ -275,6 +275,7 @@ class FlavaForMaskedLM(nn.Module):
             return (out, trans) if return_dict else ((out.logits,), trans)
         self._step += 1
         holder: Dict[str, torch.Tensor] = {}
+        self._engine.save_for_backward = torch.is_grad_enabled()
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx,
                                       bool(self.training), self._step, holder)
         logits = Fn.LazyLogits(trans, holder["trans_bf16"], st, word_name="flava.text_model.embeddings.word_embeddings.weight",

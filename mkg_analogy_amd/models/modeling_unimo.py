@@ -321,6 +321,7 @@ class UnimoForMaskedLM(nn.Module):
         self._step += 1
         seed = (self.base_seed * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFF
         holder: Dict[str, torch.Tensor] = {}
+        self._engine.save_for_backward = torch.is_grad_enabled()
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
                                       image_table, image_index)
         logits = Fn.LazyLogits(trans, holder["trans_bf16"], st)

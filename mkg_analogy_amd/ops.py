@@ -12,7 +12,7 @@ import torch
 
 from . import _lib as L
 
-ACT_NONE, ACT_GELU, ACT_QGELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_QGELU, ACT_STORED = 0, 1, 2, 3      # ACT_STORED: mul_act only (mulz holds act'(z))
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -38,7 +38,8 @@ def _rows2d(t: torch.Tensor):
 
 def gemm_nt(A, B, out, *, A2=None, B2=None, a_rows=None, b_rows=None, M=None, N=None, bias=None, bias2=None,
             bias_by_brow=False, act=ACT_NONE, preact=None, mulz=None, mul_act=ACT_NONE, res_f32=None, res_bf16=None,
-            C2=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_aux=0, tile_cfg=0, b_blocked=False):
+            C2=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_aux=0, tile_cfg=0, b_blocked=False,
+            preact_grad=False):
     """out[M,N] = epi(A[M,K] @ B[N,K]^T (+ A2 @ B2^T)).  A/B are 2-D (row stride = ld) bf16; out bf16 or f32."""
     d = L.GemmNT()
     K = A.shape[-1]
@@ -60,6 +61,7 @@ def gemm_nt(A, B, out, *, A2=None, B2=None, a_rows=None, b_rows=None, M=None, N=
     d.C, d.ldc, d.c_f32 = _p(out), _rows2d(out), int(out.dtype == F32)
     d.C2, d.ldc2 = _p(C2), (_rows2d(C2) if C2 is not None else 0)
     d.tile_cfg = tile_cfg
+    d.preact_grad = int(preact_grad)
     d.b_blocked = int(b_blocked)
     L.check(L.lib().mart_gemm_nt(C.byref(d), _stream()), "mart_gemm_nt")
     return out

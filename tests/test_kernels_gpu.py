@@ -123,6 +123,35 @@ def test_gemm_nt_persistent_loop_and_general_fallback(ops, M, N):
     close(outb, y * torch.sigmoid(1.702 * y), 3e-2, 1e-2, "qgelu fast")
 
 
+@pytest.mark.parametrize("cfg", [0, 128, 2561])
+@pytest.mark.parametrize("act", ["gelu", "qgelu"])
+def test_gemm_nt_stored_activation_derivative(ops, cfg, act):
+    """preact_grad: the forward epilogue writes act'(z) next to act(z); mul_act=ACT_STORED multiplies by that buffer.
+    Fast lanes (tile_cfg 0 / 128: tail rows in the last tile), the general epilogue (2561), and the activation-only
+    forward used under no_grad; all against autograd of the same function."""
+    M, N, K = 256 * 260 + 9, 768, 128
+    A, B = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=0.06)
+    bias = rnd(N, seed=23, dtype=F32)
+    kind, fn = ((ops.ACT_GELU, torch.nn.functional.gelu) if act == "gelu" else (ops.ACT_QGELU, lambda t: t * torch.sigmoid(1.702 * t)))
+    y = (A.float() @ B.float().t() + bias).requires_grad_(True)
+    a_ref = fn(y)
+    a_ref.sum().backward()
+    out, g = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, B, out, bias=bias, act=kind, preact=g, preact_grad=True, tile_cfg=cfg)
+    close(out, a_ref.detach(), 3e-2, 1e-2, "act(z)")
+    close(g, y.grad, 3e-2, 1e-2, "act'(z)")
+    out2 = torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, B, out2, bias=bias, act=kind, tile_cfg=cfg)           # forward under no_grad: activation only
+    assert torch.equal(out, out2)
+    # backward product: dz = (dA @ W^T) * g
+    dA, W = rnd(M, K, seed=24), rnd(N, K, seed=25, scale=0.06)
+    dz = torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(dA, W, dz, mulz=g, mul_act=ops.ACT_STORED, tile_cfg=cfg)
+    close(dz, (dA.float() @ W.float().t()) * g.float(), 3e-2, 1e-2, "stored derivative product")
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(A, B, out, bias=bias, preact=g, preact_grad=True)      # no activation
+
+
 def test_gemm_nt_dual_k_gather_batch(ops):
     M, N, K = 300, 512, 128
     A, B, A2, B2 = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=.1), rnd(M, K, seed=3), rnd(N, K, seed=4, scale=.1)
