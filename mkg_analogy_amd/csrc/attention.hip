@@ -117,7 +117,7 @@ __device__ __forceinline__ float reweight(const TextCtl& c, int qi, int kj) {
 // exp-heavy VALU work of one tile overlaps the MFMAs of the other inside the wave, a workgroup covers 256 query rows, and
 // the K/V stream of a head is read by half as many workgroups.
 template <bool TEXT, int TPW>
-__global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
+__global__ __launch_bounds__(NTH, 2) void attn_fwd_k(mart_attn_fwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,7 +181,17 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
       if (u > 0 && !active[u]) continue;
       // online softmax in the log2 domain: m_run, the saved statistic and every exponent are base-2 (one v_exp_f32 each)
       float rs = 0.f;
-      if (!text && kt * 64 + 64 <= Stot) {              // fast path (vision, full tile): 4 VALU per score
+      if constexpr (!TEXT) {                            // vision: fma, exp2, add per score (packed two at a time)
+        if (kt * 64 + 64 > Stot) {
+          // last (partial) key tile -- one in seven at 393 keys: mask in place (compare + select per score), then the
+          // same fast path; -1e30 * c2 - m underflows exp2 to exactly 0
+          const int lim = Stot - kt * 64;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (t * 32 + mfma_row(r, hh) >= lim) st[u][t][r] = -1.0e30f;
+        }
         float mx = st[u][0][0];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -196,14 +206,20 @@ __global__ __launch_bounds__(NTH) void attn_fwd_k(mart_attn_fwd_desc p) {
           m_new = fmaxf(m_run[u], mx);
           alpha[u] = __builtin_amdgcn_exp2f(m_run[u] - m_new);
         }
+        // two scores per VALU instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32): a wave64 VALU
+        // instruction occupies the SIMD for 4 cycles, and this loop -- not the MFMAs -- is what bounds the kernel
+        f32x2 rs2 = {0.f, 0.f};
+        const f32x2 c22 = {c2, c2}, mn2 = {m_new, m_new};
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(st[u][t][r], c2, -m_new));
-            rs += e;
-            pv[u][t][r] = e;
+          for (int r = 0; r < 16; r += 2) {
+            const f32x2 x = f32x2{st[u][t][r], st[u][t][r + 1]} * c22 - mn2;
+            const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            rs2 += e;
+            pv[u][t][r] = e[0]; pv[u][t][r + 1] = e[1];
           }
+        rs = rs2[0] + rs2[1];
         m_run[u] = m_new;
       } else {
         float mx = -1.0e30f;
@@ -364,11 +380,20 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
           dp = mfma32(tile_frag(sV, t, ks, lo), gf[u][ks], dp);
         }
         float dsv[16];                                     // d/d(raw q.k) / scale  (scale applied once to the accumulators)
-        if (fastp) {
+        if constexpr (!TEXT) {
+          if (!fastp) {                                    // partial key tile: masked scores -> p = exp2(-huge) = 0 -> dS = 0
+            const int lim = Stot - kt * 64 - t * 32;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float pr = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -lse[u]));
-            dsv[r] = pr * (dp[r] - delta[u]);
+            for (int r = 0; r < 16; ++r)
+              if (mfma_row(r, hh) >= lim) st[r] = -1.0e30f;
+          }
+          const f32x2 c22 = {c2, c2}, l2 = {lse[u], lse[u]}, d2 = {delta[u], delta[u]};
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {                // packed fma / sub / mul: two scores per VALU instruction
+            const f32x2 x = f32x2{st[r], st[r + 1]} * c22 - l2;
+            const f32x2 pr = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            const f32x2 ds = pr * (f32x2{dp[r], dp[r + 1]} - d2);
+            dsv[r] = ds[0]; dsv[r + 1] = ds[1];
           }
         } else {
 #pragma unroll
@@ -527,23 +552,32 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
         st = mfma32(tile_frag(sQ, t, ks, lo), kf[ks], st);
         dp = mfma32(tile_frag(sG, t, ks, lo), vf[ks], dp);
       }
+      if (!TEXT && !fast) {                              // vision, partial query tile: rows past Sq masked -> p = 0, dS = 0 (dO, delta staged from clamped rows: finite)
+        const int lim = p.Sq - qt * 64 - t * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (mfma_row(r, hh) >= lim) st[r] = -1.0e30f;
+      }
       // dV^T[d][key] += dO^T Pd ; dK^T[d][key] += Q^T dS, eight q rows (one MFMA k-slice) at a time so the probabilities
       // live only as packed bf16 (dS carries no `scale`: it is applied once to dK at the end)
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         float pd8[8], ds8[8];
-        if (fast) {
+        if constexpr (!TEXT) {
 #pragma unroll
           for (int q2 = 0; q2 < 2; ++q2) {
             const int qd = 2 * a + q2;
             const f32x4 l4 = *(const f32x4*)(sLse + t * 32 + 8 * qd + 4 * hh);   // rows 4qd..4qd+3 of this lane-half
             const f32x4 d4 = *(const f32x4*)(sDel + t * 32 + 8 * qd + 4 * hh);
+            const f32x2 c22 = {c2, c2};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; e += 2) {                 // packed fma / sub / mul: two scores per VALU instruction
               const int r = 4 * qd + e;
-              const float pr = __builtin_amdgcn_exp2f(fmaf(st[r], c2, -l4[e]));
-              pd8[4 * q2 + e] = pr;
-              ds8[4 * q2 + e] = pr * (dp[r] - d4[e]);
+              const f32x2 x = f32x2{st[r], st[r + 1]} * c22 - f32x2{l4[e], l4[e + 1]};
+              const f32x2 pr = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+              const f32x2 ds = pr * (f32x2{dp[r], dp[r + 1]} - f32x2{d4[e], d4[e + 1]});
+              pd8[4 * q2 + e] = pr[0]; pd8[4 * q2 + e + 1] = pr[1];
+              ds8[4 * q2 + e] = ds[0]; ds8[4 * q2 + e + 1] = ds[1];
             }
           }
         } else {
