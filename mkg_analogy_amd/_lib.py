@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmart_hip.so")
+LIB_PATH = os.environ.get("MART_HIP_LIB") or os.path.join(_PKG, "lib", "libmart_hip.so")   # MART_HIP_LIB: A/B builds of the same ABI (tools/ab_lib.sh)
 
 vp, i32, i64, f32, u64, u8 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint64, C.c_uint8
 
