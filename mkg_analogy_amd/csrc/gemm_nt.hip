@@ -22,18 +22,23 @@ namespace {
 #ifndef MART_NT_EPILOGUE
 #define MART_NT_EPILOGUE 1
 #endif
+// The pointers are cast to the global address space explicitly: where address-space inference fails (pointers carried
+// around the persistent tile loop) the compiler emits FLAT accesses, which have no scalar-base addressing form and count
+// on lgkmcnt as well -- every LDS wait of the epilogue then also waited for the stores before it.
 template <typename T> __device__ __forceinline__ void st_stream(T* p, T v) {
+  auto* g = (__attribute__((address_space(1))) T*)p;
 #if MART_NT_EPILOGUE
-  __builtin_nontemporal_store(v, p);
+  __builtin_nontemporal_store(v, g);
 #else
-  *p = v;
+  *g = v;
 #endif
 }
 template <typename T> __device__ __forceinline__ T ld_stream(const T* p) {
+  auto* g = (const __attribute__((address_space(1))) T*)p;
 #if MART_NT_EPILOGUE
-  return __builtin_nontemporal_load(p);
+  return __builtin_nontemporal_load(g);
 #else
-  return *p;
+  return *g;
 #endif
 }
 
@@ -361,6 +366,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
         if (p.bias2) bq[j][q] += *(const f32x4*)(p.bias2 + n);
       }
     const int rr = lane >> 3, rc = (lane & 7) * 8;                // read-back: row within 8, first of 8 columns
+    // Store addresses = wave-uniform sub-tile base (SGPRs, advanced per row group by the scalar unit) + ONE 32-bit lane
+    // offset: the stores take the saddr form and the epilogue carries no per-row 64-bit VALU address arithmetic (it was
+    // a third of this lane's VALU instructions; the epilogue is VALU-bound).
+    const long long ub = cb + (long long)(em0 + wm0) * p.ldc + en0 + wn0;
+    char* const cbase = (char*)p.C + ub * 2;
+    char* const pbase = (char*)p.preact + ub * 2;
+    const unsigned loff = ((unsigned)rr * (unsigned)p.ldc + (unsigned)rc) * 2u;
+    const int mrem = p.M - (em0 + wm0);                            // rows of this sub-tile inside the matrix (wave-uniform)
+    auto run = [&](auto guard) {                                  // two straight-line arms, one wave-uniform row-guard test per sub-tile
+    constexpr bool GUARD = decltype(guard)::value;
     auto block = [&](const int i, const f32x16 (&ai)[TN]) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
@@ -386,12 +401,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + rr, m = em0 + wm0 + i * 32 + row;
+        const int row = it * 8 + rr;
         const bf16x8 o = *(const bf16x8*)(epb + row * RS + rc * 2);
-        const long long oc = cb + (long long)m * p.ldc + en0 + wn0 + rc;
-        if (m < p.M) {
-          st_stream((bf16x8*)((bf16*)p.C + oc), o);
-          if constexpr ((EPI & F_PREACT) != 0) st_stream((bf16x8*)(p.preact + oc), *(const bf16x8*)(epb + 32 * RS + row * RS + rc * 2));
+        const long long uo = (long long)(i * 32 + it * 8) * p.ldc * 2;          // wave-uniform byte offset of the row group
+        if (!GUARD || i * 32 + row < mrem) {
+          st_stream((bf16x8*)(cbase + uo + loff), o);
+          if constexpr ((EPI & F_PREACT) != 0) st_stream((bf16x8*)(pbase + uo + loff), *(const bf16x8*)(epb + 32 * RS + row * RS + rc * 2));
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -401,12 +416,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     if constexpr (TM > 1) block(1, acc[1]);
     if constexpr (TM > 2) block(2, acc[2]);
     if constexpr (TM > 3) block(3, acc[3]);
+    };
+    if (mrem >= WM) run(std::false_type{}); else run(std::true_type{});
   } else if constexpr (EPI >= 0) {
     // ---- fast lane: full-width tiles, 16-byte aligned rows (checked by the host dispatcher).  The streamed operands of a
     // 32-row block (fp32 residual, z of the activation derivative) are fetched BEFORE the LDS round trip of the
     // accumulators: NIT independent loads in flight per lane instead of one load -> compute -> store chain per quad.
     const int n = en0 + wn0 + ec;
     const long long cb = bz * p.sC, ab = bz * p.sAux;
+    // addresses = wave-uniform sub-tile base + one 32-bit lane offset per stream (saddr form, see the bf16 lane above)
+    const long long ubc = cb + (long long)(em0 + wm0) * p.ldc + en0 + wn0, ubr = ab + (long long)(em0 + wm0) * p.ldres + en0 + wn0;
+    const long long ub2 = cb + (long long)(em0 + wm0) * p.ldc2 + en0 + wn0;
+    constexpr int CS = (EPI & F_CF32) != 0 ? 4 : 2;               // bytes per output element
+    char* const cbase = (char*)p.C + ubc * CS;
+    char* const pbase = (char*)p.preact + ubc * 2;
+    char* const c2base = (char*)p.C2 + ub2 * 2;
+    const char* const rbase = (const char*)p.res_f32 + ubr * 4;
+    const char* const zbase = (const char*)p.mulz + ubr * 2;
+    const int mrem = p.M - (em0 + wm0);                            // rows of this sub-tile inside the matrix (wave-uniform)
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bv = *(const f32x4*)(p.bias + n);
     if (p.bias2) bv += *(const f32x4*)(p.bias2 + n);
@@ -421,14 +448,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       constexpr bool GUARD = decltype(guard)::value;
       f32x4 pr[NPRE][NIT];
       bf16x4 pz[NPRE][NIT];
+      // address of (row group g = i*32 + it*RPI, this lane) in a stream with row stride ld and esz-byte elements.
+      // Unguarded arm: uniform base + g*ld (scalar unit) + a zero-extended 32-bit lane constant -> saddr form.
+      // Guarded arm: the row is clamped per lane and the offset is SIGNED (a sub-tile that starts past the last row
+      // clamps to row M-1, which lies before its base).
+      const unsigned lo_c = (unsigned)(er * p.ldc + ec), lo_r = (unsigned)(er * p.ldres + ec), lo_2 = (unsigned)(er * p.ldc2 + ec);
+      auto adr = [&](const char* base, int g, int ld, int esz, unsigned lo) -> char* {
+        if constexpr (GUARD) return (char*)base + ((long long)min(g + er, mrem - 1) * ld + ec) * esz;
+        else return (char*)base + (long long)g * ld * esz + lo * (unsigned)esz;
+      };
       auto fetch = [&](const int i) {
         if constexpr (PF) {
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
-            const int m = min(em0 + wm0 + i * 32 + it * RPI + er, p.M - 1);
-            const long long orr = ab + (long long)m * p.ldres + n;
-            if constexpr ((EPI & F_RES) != 0) pr[i % NPRE][it] = ld_stream((const f32x4*)(p.res_f32 + orr));
-            if constexpr ((EPI & F_MULZ) != 0) pz[i % NPRE][it] = ld_stream((const bf16x4*)(p.mulz + orr));
+            const int g = i * 32 + it * RPI;
+            if constexpr ((EPI & F_RES) != 0) pr[i % NPRE][it] = ld_stream((const f32x4*)adr(rbase, g, p.ldres, 4, lo_r));
+            if constexpr ((EPI & F_MULZ) != 0) pz[i % NPRE][it] = ld_stream((const bf16x4*)adr(zbase, g, p.ldres, 2, lo_r));
           }
         }
       };
@@ -436,12 +471,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
         stage_block(ai);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          const int row = it * RPI + er, m = em0 + wm0 + i * 32 + row;
+          const int row = it * RPI + er, g = i * 32 + it * RPI;
           f32x4 v = *(const f32x4*)(ep + row * EP_LD + ec);
           v = v * p.alpha + bv;
-          const long long oc = cb + (long long)m * p.ldc + n;
-          const bool ok = !GUARD || m < p.M;
-          if constexpr ((EPI & F_PREACT) != 0) { if (ok) st_stream((bf16x4*)(p.preact + oc), f4_to_bf4(v)); }
+          const bool ok = !GUARD || g + er < mrem;
+          if constexpr ((EPI & F_PREACT) != 0) { if (ok) st_stream((bf16x4*)adr(pbase, g, p.ldc, 2, lo_c), f4_to_bf4(v)); }
           if constexpr ((EPI & F_ACT) != 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACTK);
@@ -453,9 +487,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
           }
           if constexpr ((EPI & F_RES) != 0) v += pr[i % NPRE][it];
           if (ok) {
-            if constexpr ((EPI & F_CF32) != 0) st_stream((f32x4*)((float*)p.C + oc), v);
-            else st_stream((bf16x4*)((bf16*)p.C + oc), f4_to_bf4(v));
-            if constexpr ((EPI & F_C2) != 0) st_stream((bf16x4*)(p.C2 + cb + (long long)m * p.ldc2 + n), f4_to_bf4(v));
+            if constexpr ((EPI & F_CF32) != 0) st_stream((f32x4*)adr(cbase, g, p.ldc, 4, lo_c), v);
+            else st_stream((bf16x4*)adr(cbase, g, p.ldc, 2, lo_c), f4_to_bf4(v));
+            if constexpr ((EPI & F_C2) != 0) st_stream((bf16x4*)adr(c2base, g, p.ldc2, 2, lo_2), f4_to_bf4(v));
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

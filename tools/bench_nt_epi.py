@@ -15,9 +15,11 @@ def run(name, N, K, mk):
         ms = timeit(lambda: ops.gemm_nt(A, W, out, tile_cfg=cfg, **kw))
         print(f"{name:34s} N={N} K={K} cfg={cfg}: {ms:.3f} ms {2*M*N*K/ms/1e9:.0f} TF/s")
 bias3072 = torch.randn(3072, device=DEV); bias768 = torch.randn(768, device=DEV)
-run("fc1 fwd bias+preact+act -> bf16", 3072, 768, lambda N: (dict(bias=bias3072, act=ops.ACT_QGELU, preact=torch.empty(M, N, device=DEV, dtype=BF)), torch.empty(M, N, device=DEV, dtype=BF)))
-run("fc2 dgrad mulz -> bf16", 3072, 768, lambda N: (dict(mulz=torch.randn(M, N, device=DEV).to(BF), mul_act=ops.ACT_QGELU), torch.empty(M, N, device=DEV, dtype=BF)))
+run("fc1 fwd bias+act+act' -> bf16 x2", 3072, 768, lambda N: (dict(bias=bias3072, act=ops.ACT_QGELU, preact=torch.empty(M, N, device=DEV, dtype=BF), preact_grad=True), torch.empty(M, N, device=DEV, dtype=BF)))
+run("fc2 dgrad * stored act' -> bf16", 3072, 768, lambda N: (dict(mulz=torch.randn(M, N, device=DEV).to(BF), mul_act=ops.ACT_STORED), torch.empty(M, N, device=DEV, dtype=BF)))
 run("qkv fwd bias -> bf16", 2304, 768, lambda N: (dict(bias=torch.randn(N, device=DEV)), torch.empty(M, N, device=DEV, dtype=BF)))
 run("out-proj bias+res_f32 -> f32", 768, 768, lambda N: (dict(bias=bias768, res_f32=torch.randn(M, N, device=DEV)), torch.empty(M, N, device=DEV)))
 run("fc2 fwd bias+res_f32 -> f32", 768, 3072, lambda N: (dict(bias=bias768, res_f32=torch.randn(M, N, device=DEV)), torch.empty(M, N, device=DEV)))
 run("plain -> bf16", 768, 768, lambda N: ({}, torch.empty(M, N, device=DEV, dtype=BF)))
+run("plain -> bf16", 768, 3072, lambda N: ({}, torch.empty(M, N, device=DEV, dtype=BF)))
+run("fc2 fwd bias+res_f32+C2 -> f32", 768, 3072, lambda N: (dict(bias=bias768, res_f32=torch.randn(M, N, device=DEV), C2=torch.empty(M, N, device=DEV, dtype=BF)), torch.empty(M, N, device=DEV)))
