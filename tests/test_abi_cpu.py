@@ -54,6 +54,33 @@ def test_descriptor_layouts_match_header(built):
         assert [norm(f) for f in fields] == [norm(g) for g in got], (cname, fields, got)
 
 
+def test_descriptor_sizes_match_a_c_compiler(built, tmp_path):
+    """sizeof / last-field offset of every descriptor as gcc sees include/mart_hip.h == the ctypes mirrors
+    (catches a field added on one side only, or a type width mismatch, without a GPU)."""
+    import ctypes
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = [("mart_gemm_nt_desc", built.GemmNT), ("mart_gemm_tn_desc", built.GemmTN), ("mart_ln_fwd_desc", built.LnFwd),
+             ("mart_ln_bwd_desc", built.LnBwd), ("mart_text_embed_desc", built.TextEmbed), ("mart_attn_fwd_desc", built.AttnFwd),
+             ("mart_attn_bwd_desc", built.AttnBwd), ("mart_adamw_desc", built.AdamW), ("mart_attn_f32_desc", built.AttnF32)]
+    src = tmp_path / "sz.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mart_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        last = cls._fields_[-1][0]
+        lines.append(f'  printf("{cname} %zu %zu\\n", sizeof({cname}), offsetof({cname}, {last}));')
+    lines += ['  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in out if l.strip()}
+    for cname, cls in pairs:
+        last = cls._fields_[-1][0]
+        assert seen[cname] == (ctypes.sizeof(cls), getattr(cls, last).offset), (cname, seen[cname], ctypes.sizeof(cls), getattr(cls, last).offset)
+
+
 def test_product_fails_loudly_without_gpu(built):
     import torch
     if torch.cuda.is_available():
