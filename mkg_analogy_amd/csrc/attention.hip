@@ -43,11 +43,27 @@ __device__ __forceinline__ void tile_barrier() {
 }
 
 // stage one 64x64 tile (rows r0..r0+63 of `s`) into LDS with the chunk swizzle c' = c ^ ((row>>1)&7)
+// Each thread copies chunk (row = tid>>3 [+32], lc) of both 32-row halves.  When a half lies entirely inside the prefix
+// or inside the own rows (prefix length a multiple of 32, half not cut by the end) its source is a wave-uniform row
+// pointer (scalar unit) plus ONE loop-invariant lane offset; the general form (per-lane clamp, prefix/own select and a
+// 64-bit multiply: ~28 VALU instructions per copy, four copies per tile iteration) is left to the cut halves.
+// (Measured and dropped, twice each: the copy as opaque assembly -- no compiler-forced vmcnt(0) in front of the
+// transposed reads -- is 2 % slower; a 4-stage ring with three tiles in flight and counted waits changes nothing:
+// the loop does not wait for the DMA)
 __device__ __forceinline__ void stage_tile(const Side& s, int b, int h, int r0, char* lds, int tid, int wave) {
+  const int rowh = tid >> 3, pc = tid & 7, lc = pc ^ ((rowh >> 1) & 7);          // (row >> 1) & 7 is the same for row and row + 32
+  const unsigned off_own = (unsigned)(rowh * s.ld_own + lc * 8), off_pre = (unsigned)(rowh * s.ld_pre + lc * 8);
+  const int n_tot = s.n_pre + s.n_own;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    const int c = r * NTH + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
-    glds16(side_row(s, b, h, r0 + row) + lc * 8, lds + (r * NTH + wave * 64) * 16);   // opaque-asm DMA (no forced vmcnt(0) before the transposed reads) measured 2 % slower here, twice
+    const int j0 = r0 + r * 32;                                                       // first row of this half (wave-uniform)
+    char* dst = lds + (r * NTH + wave * 64) * 16;
+    if ((s.n_pre & 31) == 0 && j0 + 32 <= n_tot) {
+      if (j0 < s.n_pre) glds16(s.pre + ((long long)b * s.n_pre + j0) * s.ld_pre + h * 64 + off_pre, dst);
+      else glds16(s.own + ((long long)b * s.n_own + (j0 - s.n_pre)) * s.ld_own + h * 64 + off_own, dst);
+    } else {
+      glds16(side_row(s, b, h, j0 + rowh) + lc * 8, dst);
+    }
   }
 }
 // Per-lane byte offsets of the fragment reads inside a 64x64 tile -- loop invariant, computed once per kernel so the
