@@ -81,6 +81,14 @@ def test_descriptor_sizes_match_a_c_compiler(built, tmp_path):
         assert seen[cname] == (ctypes.sizeof(cls), getattr(cls, last).offset), (cname, seen[cname], ctypes.sizeof(cls), getattr(cls, last).offset)
 
 
+def test_integration_doc_stub_matches_binding(built):
+    """The ctypes stub a maintainer would paste from INTEGRATION.md has the same fields as the shipped binding."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    body = txt[txt.index("class GemmNT(C.Structure)"):txt.index("lib.mart_gemm_nt.argtypes")]
+    names = re.findall(r'\("([A-Za-z0-9_]+)",\s*C\.c_', body)
+    assert names == [f[0] for f in built.GemmNT._fields_]
+
+
 def test_product_fails_loudly_without_gpu(built):
     import torch
     if torch.cuda.is_available():
