@@ -267,3 +267,49 @@ def test_full_size_training_steps_stay_finite():
         assert bool(torch.isfinite(model.store.grad).all()) and bool(torch.isfinite(model.store.master).all()), f"step {i}"
     print("\nfull-size losses", [round(x, 4) for x in losses])
     assert losses[-1] < losses[0]
+
+
+def test_full_size_forward_is_per_example():
+    """Size-independent properties at BASELINE configs[1] size (B=256, 393 vision tokens, L=64, eval mode): every example
+    is independent of its position in the batch and of its batch mates -- permuting the batch permutes the outputs
+    BIT-EXACTLY (no tile, workgroup or stream boundary leaks rows into each other), a half batch reproduces its rows, the
+    two evaluation passes of one batch are identical (no race), and ranks computed on the device agree with the double
+    sort of the same logits on the host."""
+    import bench
+    from mkg_analogy_amd import data_synth as D
+    dev = torch.device("cuda", 0)
+    model, lit, cfg = bench.build(16, seed=0, device=dev, backbone="mkgformer")
+    model.eval()
+    batch = D.make_batch(256, 64, seed=4321, device=dev)
+    keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
+
+    def fwd(bt):
+        with torch.no_grad():
+            out, trans = model(**{k: bt[k] for k in keys}, return_dict=True)
+        return trans.float().clone()
+    t0 = fwd(batch)
+    assert bool(torch.isfinite(t0).all())
+    assert torch.equal(t0, fwd(batch)), "two passes over the same batch differ"
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(1)).to(dev)
+    tp = fwd({k: batch[k][perm] for k in keys})
+    assert torch.equal(tp, t0[perm]), "outputs depend on the position of an example in the batch"
+    th = fwd({k: batch[k][:128] for k in keys})
+    err = float((th - t0[:128]).abs().max())
+    print("\nhalf batch vs full batch max|diff|", err)
+    assert err <= 2e-2 * float(t0.abs().max())                    # other tile shapes may be picked: same math, rounding-level differences
+    # ranks: device double-sort == host double-sort on the very same logits (bit-exact integer work)
+    ev = lit._eval({k: v for k, v in batch.items()}, 0)
+    ranks = ev["entity_ranks"] if isinstance(ev, dict) else ev
+    with torch.no_grad():
+        out, _ = model(**{k: batch[k] for k in keys}, return_dict=True)
+        mask_idx = (batch["input_ids"] == 103).nonzero()[:, 1]
+        ids = torch.tensor(cfg["analogy_entity_ids"], device=dev)
+        logits = out.logits[torch.arange(256, device=dev), mask_idx][:, ids].float().cpu()
+    order = torch.argsort(logits, dim=1, descending=True, stable=True)
+    host = (torch.argsort(order, dim=1, stable=True)[torch.arange(256), batch["label"].cpu()] + 1).numpy()
+    import numpy as np
+    # torch.sort is not stable in the reference, so only rows whose label logit is not tied with another are compared
+    lab = logits[torch.arange(256), batch["label"].cpu()]
+    untied = ((logits == lab[:, None]).sum(1) == 1).numpy()
+    assert untied.sum() > 200
+    assert np.array_equal(np.asarray(ranks)[untied], host[untied])
