@@ -313,3 +313,30 @@ def test_full_size_forward_is_per_example():
     untied = ((logits == lab[:, None]).sum(1) == 1).numpy()
     assert untied.sum() > 200
     assert np.array_equal(np.asarray(ranks)[untied], host[untied])
+
+
+def test_full_size_gradient_of_duplicated_batch():
+    """Backward at BASELINE configs[1] size through a size-independent property: the mean-loss gradient of a batch made of
+    two identical halves (B=256) equals the gradient of one half (B=128) -- every M-split reduction, atomic accumulation
+    and stream join of the backward pass at full size, checked without an oracle run (which takes minutes at this size).
+    Power-of-two loss scaling keeps the bf16 roundings aligned, so only fp32 summation order differs."""
+    import bench
+    from mkg_analogy_amd import data_synth as D
+    dev = torch.device("cuda", 0)
+    model, lit, cfg = bench.build(16, seed=0, device=dev, backbone="mkgformer")
+    model.eval()                                                   # dropout off: the two halves see the same network
+    half = D.make_batch(128, 64, seed=777, device=dev)
+    full = {k: torch.cat([v, v], 0) for k, v in half.items()}
+    grads = []
+    for bt in (half, full):
+        model.store.zero_grad()
+        loss = lit.training_step(dict(bt), 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(model.store.grad).all())
+        grads.append((float(loss.detach()), model.store.grad.clone()))
+    (l1, g1), (l2, g2) = grads
+    rel = float((g1 - g2).norm() / g1.norm())
+    print(f"\nloss half {l1:.6f} full {l2:.6f}; gradient rel-L2 difference {rel:.2e}; |g| {float(g1.norm()):.4f}")
+    assert abs(l1 - l2) < 1e-5 * max(1.0, abs(l1))
+    assert rel < 1e-3
