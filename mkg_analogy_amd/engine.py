@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Optional
 
+import collections
+
 import torch
 
 from . import ops
@@ -51,6 +53,13 @@ class UnimoEngine:
         self._side_busy = False
         self.two_stream = os.environ.get("MART_TWO_STREAM", "1") == "1"   # text layers on their own stream (+3 % step rate)
         self._tstream: Optional[torch.cuda.Stream] = None
+        # Host run-ahead bound.  Blocks that side-stream kernels touched (record_stream) return to the caching allocator only
+        # when the recorded stream has passed the point of the free; a host that enqueues many steps ahead of the GPU finds
+        # none of them reusable and reserves ~2.3 GiB more per queued step (B=256) until the 288 GB are gone and every
+        # allocation turns into free-everything-and-retry (seen as 100 -> 600 ms per step after ~60 un-synchronised steps).
+        # The pass that is about to be enqueued waits for the end of the pass two before it: the GPU queue never drains.
+        self.max_inflight = int(os.environ.get("MART_MAX_INFLIGHT", "2"))
+        self._inflight = collections.deque()
 
     # ------------------------------------------------------------------ helpers
     def _lin(self, name):
@@ -134,9 +143,20 @@ class UnimoEngine:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_busy = False
 
+    def _pass_begin(self):
+        while self.max_inflight > 0 and len(self._inflight) >= self.max_inflight:
+            self._inflight.popleft().synchronize()
+
+    def _pass_end(self):
+        if self.max_inflight > 0:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._inflight.append(ev)
+
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train: bool, seed: int,
                 image_table=None, image_index=None):
+        self._pass_begin()
         st, H, nh, I = self.st, self.H, self.nh, self.I
         dev = input_ids.device
         B, Lq = input_ids.shape
@@ -297,6 +317,8 @@ class UnimoEngine:
         if self._tstream is not None:                  # allocated on the text stream, consumed by the caller on the main stream
             trans.record_stream(torch.cuda.current_stream())
             transb.record_stream(torch.cuda.current_stream())
+        if not keep:
+            self._pass_end()                           # forward-only pass (no_grad); otherwise the backward pass closes it
         return trans.view(B, Lq, H), transb, sv
 
     # ------------------------------------------------------------------ backward
@@ -482,3 +504,4 @@ class UnimoEngine:
         self._text_done()                                             # main stream waits for the text stream
         self._join()
         notify(st.total)
+        self._pass_end()

@@ -340,3 +340,28 @@ def test_full_size_gradient_of_duplicated_batch():
     print(f"\nloss half {l1:.6f} full {l2:.6f}; gradient rel-L2 difference {rel:.2e}; |g| {float(g1.norm()):.4f}")
     assert abs(l1 - l2) < 1e-5 * max(1.0, abs(l1))
     assert rel < 1e-3
+
+
+def test_unsynchronised_steps_do_not_grow_memory():
+    """A training loop that never synchronises (what bench.py times) must not let the host run arbitrarily far ahead:
+    blocks touched by the side streams only return to the caching allocator once those streams pass the free, so an
+    unbounded run-ahead reserved ~2.3 GiB more per queued step at B=256 until the device was full and every allocation
+    became free-everything-and-retry (100 -> 600 ms per step after ~60 steps).  The engine bounds the passes in flight."""
+    import bench
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+    model, lit, cfg = bench.build(32, seed=0, device=dev, backbone="mkgformer")
+    batch = D.make_batch(64, 64, seed=99, device=dev)
+    tr = Trainer(max_epochs=1, max_steps=1000, world_size=1)
+    tr._setup(lit, [None] * 1000)
+    for i in range(6):
+        tr.train_step(lit, batch, i)
+    torch.cuda.synchronize()
+    r0 = torch.cuda.memory_reserved()
+    for i in range(60):
+        tr.train_step(lit, batch, 6 + i)
+    torch.cuda.synchronize()
+    r1 = torch.cuda.memory_reserved()
+    print(f"\nreserved after 6 steps {r0 / 2**30:.2f} GiB, after 66 steps {r1 / 2**30:.2f} GiB")
+    assert r1 <= 1.5 * r0 + (1 << 30)
