@@ -430,6 +430,25 @@ def test_softmax_transpose(ops):
     xt = torch.full((3, 768, 448), 5.0, device=DEV, dtype=BF)
     ops.transpose_bf16(x[0], xt[0], 393, 768, 448, batch=3, stride_i=393 * 768, stride_o=768 * 448)
     assert torch.equal(xt[:, :, :393], x.transpose(1, 2)) and float(xt[:, :, 393:].abs().max()) == 0
+    # unaligned shapes / leading dimensions (scalar fall-back paths of the 16-byte transpose) and an unpadded destination
+    for (R2, C2, ld2, Rp2) in ((37, 53, 61, 37), (64, 64, 64, 64), (65, 129, 136, 72), (393, 768, 2304, 393)):
+        src = rnd(R2, ld2, seed=R2 + C2)
+        dst = torch.full((C2, Rp2), 5.0, device=DEV, dtype=BF)
+        ops.transpose_bf16(src[:, :C2], dst, R2, C2, Rp2)
+        assert torch.equal(dst[:, :R2], src[:, :C2].t()), (R2, C2, ld2, Rp2)
+        if Rp2 > R2:
+            assert float(dst[:, R2:].abs().max()) == 0
+    # table form: several matrices of one flat buffer in one launch (the per-step refresh of the transposed weight copies)
+    shapes = [(768, 2304), (3072, 768), (40, 24), (100, 8)]
+    offs, tot = [], 0
+    for (r, c) in shapes:
+        offs.append(tot); tot += r * c
+    flat = rnd(tot, seed=77)
+    flat_t = torch.zeros(tot, device=DEV, dtype=BF)
+    table = torch.tensor([[o, o, r, c] for o, (r, c) in zip(offs, shapes)], dtype=torch.int64, device=DEV)
+    ops.transpose_table(flat, flat_t, table, len(shapes))
+    for o, (r, c) in zip(offs, shapes):
+        assert torch.equal(flat_t[o:o + r * c].view(c, r), flat[o:o + r * c].view(r, c).t()), (r, c)
 
 
 def test_embeddings(ops):
