@@ -209,16 +209,29 @@ __global__ __launch_bounds__(TPB) void text_embed_k(mart_text_embed_desc p) {
   }
 }
 
-__global__ void text_embed_scatter_k(const float* __restrict__ ds, const int64_t* __restrict__ ids, const int64_t* __restrict__ tt,
-                                     float* dword, float* dpos, float* dtype, int B, int L, int H) {
-  const int m = blockIdx.x;
-  const long long id = ids[m], t = tt[m];
-  const int pos = m % L;
-  for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    const float g = ds[(long long)m * H + c];
-    atomicAdd(dword + id * H + c, g);
-    atomicAdd(dpos + (long long)pos * H + c, g);
-    atomicAdd(dtype + t * H + c, g);
+// grid (L positions, batch slices): the word rows are scattered with atomics (ids are arbitrary); the position and
+// token-type rows are summed over the slice in registers first -- one atomic per (slice, position[, type], column)
+// instead of one per token (the two token-type rows used to take 8192 contended adds per column).
+__global__ __launch_bounds__(256) void text_embed_scatter_k(const float* __restrict__ ds, const int64_t* __restrict__ ids, const int64_t* __restrict__ tt,
+                                                           float* dword, float* dpos, float* dtype, int B, int L, int H) {
+  const int pos = blockIdx.x;
+  const int nsl = gridDim.y, per = (B + nsl - 1) / nsl;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {                // lane = column: every atomic instruction covers 64 consecutive floats
+    float ap = 0.f, a0 = 0.f, a1 = 0.f;
+    for (int b = b0; b < b1; ++b) {
+      const long long m = (long long)b * L + pos;
+      const float g = ds[m * H + c];
+      atomicAdd(dword + ids[m] * H + c, g);
+      ap += g;
+      const long long ty = tt[m];
+      if (ty == 0) a0 += g;
+      else if (ty == 1) a1 += g;
+      else atomicAdd(dtype + ty * H + c, g);
+    }
+    atomicAdd(dpos + (long long)pos * H + c, ap);
+    if (a0 != 0.f) atomicAdd(dtype + c, a0);
+    if (a1 != 0.f) atomicAdd(dtype + H + c, a1);
   }
 }
 
@@ -284,25 +297,31 @@ __global__ void vision_assemble_k(const bf16* __restrict__ patch, const float* _
 }
 
 // dpatch = bf16(ds rows 1..2P); dcls += sum_b ds[b,0]; dpos[t] += sum_b (ds[b,t] + ds[b,t+P])
-__global__ void vision_assemble_bwd_k(const float* __restrict__ ds, bf16* __restrict__ dpatch, float* dcls, float* dpos, int B, int P, int H, int tail_shift) {
+// grid (P+1 rows, batch slices), 16-byte accesses; the slice sums reach dcls / dpos with one atomic per (slice, row, column)
+__global__ __launch_bounds__(192) void vision_assemble_bwd_k(const float* __restrict__ ds, bf16* __restrict__ dpatch, float* dcls, float* dpos, int B, int P, int H, int tail_shift) {
   const int Nv = 1 + 2 * P;
   const int t = blockIdx.x;                          // 0..P : row of the first image (and of the class token)
-  for (int c = threadIdx.x; c < H; c += blockDim.x) {
-    float acc = 0.f, acc_cls = 0.f, acc_tail = 0.f;
-    for (int b = 0; b < B; ++b) {
+  const int nsl = gridDim.y, per = (B + nsl - 1) / nsl;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {          // H % 4 == 0 (checked by the host)
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc_tail = acc;
+    for (int b = b0; b < b1; ++b) {
       const float* base = ds + (long long)b * Nv * H;
-      if (t == 0) { float g = base[c]; acc += g; acc_cls += g; }
+      if (t == 0) acc += *(const f32x4*)(base + c);
       else {
-        float g0 = base[(long long)t * H + c], g1 = base[(long long)(t + P) * H + c];
-        acc += g0 + g1; acc_tail += g1;
-        dpatch[((long long)b * 2 * P + (t - 1)) * H + c] = f2bf(g0);
-        dpatch[((long long)b * 2 * P + (t - 1 + P)) * H + c] = f2bf(g1);
+        const f32x4 g0 = *(const f32x4*)(base + (long long)t * H + c), g1 = *(const f32x4*)(base + (long long)(t + P) * H + c);
+        acc += g0; acc_tail += g1;
+        *(bf16x4*)(dpatch + ((long long)b * 2 * P + (t - 1)) * H + c) = f4_to_bf4(g0);
+        *(bf16x4*)(dpatch + ((long long)b * 2 * P + (t - 1 + P)) * H + c) = f4_to_bf4(g1);
       }
     }
-    // acc holds the first image's row t (+ the second image's row t, whose position row is t - tail_shift)
-    atomicAdd(dpos + (long long)t * H + c, acc - acc_tail);
-    if (t > 0) atomicAdd(dpos + (long long)(t - tail_shift) * H + c, acc_tail);
-    if (t == 0) atomicAdd(dcls + c, acc_cls);
+    // acc: the first image's row t (position row t); acc_tail: the second image's row t (position row t - tail_shift)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(dpos + (long long)t * H + c + e, acc[e]);
+      if (t > 0) atomicAdd(dpos + (long long)(t - tail_shift) * H + c + e, acc_tail[e]);
+      if (t == 0) atomicAdd(dcls + c + e, acc[e]);
+    }
   }
 }
 
@@ -452,7 +471,7 @@ extern "C" int mart_text_embed_fwd(const mart_text_embed_desc* d, void* stream) 
 extern "C" int mart_text_embed_scatter(const float* ds, const int64_t* ids, const int64_t* tt, float* dword, float* dpos, float* dtype,
                                        int B, int L, int H, void* stream) {
   MART_CHECK(ds && ids && tt && dword && dpos && dtype && B > 0 && L > 0 && H > 0, "text_embed_scatter: bad args");
-  hipLaunchKernelGGL(text_embed_scatter_k, dim3(B * L), dim3(256), 0, (hipStream_t)stream, ds, ids, tt, dword, dpos, dtype, B, L, H);
+  hipLaunchKernelGGL(text_embed_scatter_k, dim3(L, B >= 64 ? 16 : 1), dim3(256), 0, (hipStream_t)stream, ds, ids, tt, dword, dpos, dtype, B, L, H);
   MART_LAUNCH_CHECK();
   return 0;
 }
@@ -483,8 +502,8 @@ extern "C" int mart_vision_assemble(const void* patch_bf16, const float* cls, co
   return 0;
 }
 extern "C" int mart_vision_assemble_bwd(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, int tail_shift, void* stream) {
-  MART_CHECK(ds && dpatch_bf16 && dcls && dpos && B > 0 && P > 0 && H > 0 && (tail_shift == 0 || tail_shift == 1), "vision_assemble_bwd: bad args");
-  hipLaunchKernelGGL(vision_assemble_bwd_k, dim3(P + 1), dim3(256), 0, (hipStream_t)stream, ds, (bf16*)dpatch_bf16, dcls, dpos, B, P, H, tail_shift);
+  MART_CHECK(ds && dpatch_bf16 && dcls && dpos && B > 0 && P > 0 && H > 0 && H % 4 == 0 && (tail_shift == 0 || tail_shift == 1), "vision_assemble_bwd: bad args (H must be a multiple of 4)");
+  hipLaunchKernelGGL(vision_assemble_bwd_k, dim3(P + 1, B >= 64 ? 16 : 1), dim3(192), 0, (hipStream_t)stream, ds, (bf16*)dpatch_bf16, dcls, dpos, B, P, H, tail_shift);
   MART_LAUNCH_CHECK();
   return 0;
 }
