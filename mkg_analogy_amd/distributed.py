@@ -22,6 +22,7 @@ class BucketedAllReduce:
         self.next = 0
         self.handles = []
         self.side: Optional[torch.cuda.Stream] = torch.cuda.Stream() if flat.is_cuda else None
+        self.on_bucket = None          # optional callback(end_offset): runs right after a bucket's all-reduce, on the stream that waits for it
 
     def begin(self) -> None:
         self.next = 0
@@ -36,9 +37,17 @@ class BucketedAllReduce:
                 ev.record(torch.cuda.current_stream())
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(ev)
-                    self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    h = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self.handles.append(h)
+                    if self.on_bucket is not None:
+                        h.wait()                                   # stream-side wait (the side stream, not the host)
+                        self.on_bucket(e)
             else:
-                self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                h = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.handles.append(h)
+                if self.on_bucket is not None:
+                    h.wait()
+                    self.on_bucket(e)
 
     def finish(self) -> None:
         self.ready(self.flat.numel())

@@ -46,6 +46,7 @@ class UnimoEngine:
         self.fuse_from = 8                     # modeling_unimo.py:616,627
         self.export_from = 7                   # modeling_unimo.py:628
         self.grad_ready: Optional[Callable[[int], None]] = None      # DDP hook: gradients below this flat offset are final
+        self.grad_ready_async: Optional[Callable] = None              # same, without joining the streams: called with (offset, events to wait for)
         self.taps: Optional[dict] = None                              # debugging: per-layer stream snapshots when set to a dict
         import os
         self.overlap_wgrad = os.environ.get("MART_OVERLAP_WGRAD", "1") == "1"   # weight-gradient GEMMs on a side stream (+2.5 % step rate)
@@ -330,7 +331,16 @@ class UnimoEngine:
         train, seed = sv["train"], sv["seed"]
         Mv, Mt = B * Nv, B * Lq
         p_h = self.p_hidden if train else 0.0
-        notify = self.grad_ready or (lambda off: None)
+        def notify(off):
+            if self.grad_ready is not None:
+                self.grad_ready(off)
+            if self.grad_ready_async is not None:                      # the consumer waits for these instead of the main stream waiting
+                evs = []
+                if self._side_busy:
+                    e = torch.cuda.Event(); e.record(self._side); evs.append(e)
+                if self._tstream is not None:
+                    e = torch.cuda.Event(); e.record(self._tstream); evs.append(e)
+                self.grad_ready_async(off, evs)
 
         # ---- head transform
         self._text_begin()                                            # text stream starts behind the main stream (dtrans is ready)

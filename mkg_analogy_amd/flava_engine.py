@@ -230,7 +230,11 @@ class FlavaEngine:
         st, H, dev = self.st, self.H, dtrans.device
         B, Lq, P, Nv, Sm = sv["B"], sv["L"], sv["P"], sv["Nv"], sv["Sm"]
         Mi, Mt, Mm = B * Nv, B * Lq, B * Sm
-        notify = self.grad_ready or (lambda off: None)
+        def notify(off):
+            if self.grad_ready is not None:
+                self.grad_ready(off)
+            if getattr(self, "grad_ready_async", None) is not None:    # single-stream engine: nothing to wait for besides the current stream
+                self.grad_ready_async(off, [])
         xm, mmean, mrstd, mm_b, rows, y, zh, hm, hr = sv["head"]
         # head transform
         dyb = _e((Mt, H), BF, dev)

@@ -17,6 +17,8 @@ class Trainer:
         self.max_epochs, self.max_steps, self.accumulate_grad_batches = max_epochs, max_steps, accumulate_grad_batches
         self.world_size = world_size
         self.log_every = log_every
+        import os
+        self.stream_optimizer = os.environ.get("MART_STREAM_OPT", "1") == "1"   # AdamW ranges launched under the backward pass
         self.num_train_batches = 0
         self.global_step = 0
         self.history: List[Dict[str, float]] = []
@@ -36,10 +38,23 @@ class Trainer:
         last = (batch_idx + 1) % self.accumulate_grad_batches == 0
         if first:
             self.optimizer.zero_grad()
+        eng = lit.model.engine
+        stream_opt = self.stream_optimizer and hasattr(self.optimizer, "begin_step")
         if last:
             self.sync.begin()
+            if self.sync.reducer is not None:
+                eng.grad_ready = self.sync.reducer.ready
+            if stream_opt:
+                # parameter ranges are updated as soon as their gradients are final (and, under DDP, all-reduced), below the
+                # rest of the backward pass
+                self.optimizer.begin_step()
+                if self.sync.reducer is not None:
+                    self.sync.reducer.on_bucket = self.optimizer.ready
+                else:
+                    eng.grad_ready_async = self.optimizer.ready
         else:
-            lit.model.engine.grad_ready = None
+            eng.grad_ready = None
+            eng.grad_ready_async = None
         loss = lit.training_step(dict(batch), batch_idx)
         loss.backward()
         if last:
@@ -48,7 +63,7 @@ class Trainer:
             self.scheduler.step()
             self.global_step += 1
             if self.sync.reducer is not None:
-                lit.model.engine.grad_ready = self.sync.reducer.ready
+                eng.grad_ready = self.sync.reducer.ready
         return loss.detach()
 
     def fit(self, lit, train_batches: Iterable, val_batches: Optional[Iterable] = None):
