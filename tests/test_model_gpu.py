@@ -365,3 +365,31 @@ def test_unsynchronised_steps_do_not_grow_memory():
     r1 = torch.cuda.memory_reserved()
     print(f"\nreserved after 6 steps {r0 / 2**30:.2f} GiB, after 66 steps {r1 / 2**30:.2f} GiB")
     assert r1 <= 1.5 * r0 + (1 << 30)
+
+
+def test_streamed_adamw_equals_one_shot():
+    """The optimizer step released range by range (as the backward pass frees gradients) == the one-launch step on the same
+    gradients, bit for bit (same kernel, same chunk table, only the launch partition differs)."""
+    import copy
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.optim import FusedAdamW
+    model, lit, cfg, vc = _product(32, seed=11, conditioned=True)
+    st = model.store
+    g = torch.Generator(device="cpu").manual_seed(3)
+    st.grad.copy_((torch.randn(st.total, generator=g) * 1e-3).cuda())
+    m0 = st.master.clone()
+    opt_a = FusedAdamW(model, lr=1e-3)
+    for _ in range(2):
+        opt_a.step()
+    ref = st.master.clone(); ref_m = opt_a.m.clone(); ref_sh = st.shadow.clone()
+    st.master.copy_(m0)
+    st.refresh_shadows()
+    opt_b = FusedAdamW(model, lr=1e-3)
+    for _ in range(2):
+        opt_b.begin_step()
+        for frac in (0.1, 0.1, 0.37, 0.9):                      # repeated / growing offsets, not aligned to chunks
+            opt_b.ready(int(st.total * frac))
+        opt_b.step()
+    torch.cuda.synchronize()
+    assert torch.equal(st.master, ref) and torch.equal(opt_b.m, ref_m) and torch.equal(st.shadow, ref_sh)
+    assert opt_a.steps == opt_b.steps == 2
