@@ -232,6 +232,14 @@ def main():
                 "avg_launch_ms_with_wgrad_overlap": round(kms_ov / max(n_ov, 1), 4)}
     # Hits@1 of the (untrained, random-init) model on the same batch -- reported to exercise the ranking eval path
     metrics = tr.validate(lit, [batch])
+    spread = None
+    if world > 1:
+        # data-parallel self-check: every replica must hold the same weights after the same all-reduced updates
+        cs = model.store.master.double().sum().reshape(1)
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        spread = float(hi - lo)
 
     if rank == 0:
         out = {"metric": "analogy examples/sec (fine-tune step)" if not pre else "link-prediction examples/sec (pre-train step)", "value": round(value, 2), "unit": "examples/s", "n_gpus": world,
@@ -243,6 +251,8 @@ def main():
                           "entity_head": 2063 if not pre else 11292, "vocab": D.VOCAB, "parallelism": f"dp{world}", "weights": "random-init N(0,0.02)"},
                "loss": round(float(loss), 4), "hits1": metrics.get("Eval_entity/hits1"),
                "train_gflop_per_example": round(train_gflop, 1)}
+        if spread is not None:
+            out["replica_param_checksum_spread"] = spread        # 0.0: all ranks hold identical weights
         if roof is not None:
             out["roofline"] = roof
         if not a.no_cpu_baseline and world == 1 and a.model == "mkgformer" and not pre:

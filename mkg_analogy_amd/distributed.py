@@ -89,6 +89,11 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, local_rank, world) from torchrun's environment; initialises the default process group when world > 1."""
     import os
     rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    # test hooks (tests/test_two_ranks_one_gpu.py): RCCL refuses two ranks on one device, so the N > 1 control flow is
+    # exercised on a 1-GPU box with every rank on MART_DEVICE_INDEX and the gloo backend moving the CUDA tensors
+    if os.environ.get("MART_DEVICE_INDEX") is not None:
+        local = int(os.environ["MART_DEVICE_INDEX"])
+    backend = backend or os.environ.get("MART_DIST_BACKEND")
     if (world > 1 or os.environ.get("MART_FORCE_PG") == "1") and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
