@@ -28,7 +28,9 @@ class BucketedAllReduce:
         self.next = 0
         self.handles = []
 
-    def ready(self, upto: int) -> None:
+    def ready(self, upto: int, events=()) -> None:
+        """Gradients below ``upto`` are final once the current stream and ``events`` (recorded on the producer's other
+        streams) have passed: the collective stream waits for them, the producer does not stall."""
         while self.next < len(self.buckets) and self.buckets[self.next][1] <= upto:
             s, e = self.buckets[self.next]
             self.next += 1
@@ -37,6 +39,8 @@ class BucketedAllReduce:
                 ev.record(torch.cuda.current_stream())
                 with torch.cuda.stream(self.side):
                     self.side.wait_event(ev)
+                    for x in events:
+                        self.side.wait_event(x)
                     h = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                     self.handles.append(h)
                     if self.on_bucket is not None:
@@ -70,7 +74,7 @@ class GradSync:
         on = self.world > 1 or (dist.is_initialized() and os.environ.get("MART_FORCE_PG") == "1")
         self.reducer = BucketedAllReduce(st.grad, st.buckets(bucket_elems), group) if on else None
         if self.reducer is not None:
-            model.engine.grad_ready = self.reducer.ready
+            model.engine.grad_ready_async = self.reducer.ready       # (offset, events): no stream joins in the backward pass
 
     def begin(self) -> None:
         if self.reducer is not None:

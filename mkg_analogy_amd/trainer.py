@@ -43,7 +43,7 @@ class Trainer:
         if last:
             self.sync.begin()
             if self.sync.reducer is not None:
-                eng.grad_ready = self.sync.reducer.ready
+                eng.grad_ready_async = self.sync.reducer.ready
             if stream_opt:
                 # parameter ranges are updated as soon as their gradients are final (and, under DDP, all-reduced), below the
                 # rest of the backward pass
@@ -52,6 +52,8 @@ class Trainer:
                     self.sync.reducer.on_bucket = self.optimizer.ready
                 else:
                     eng.grad_ready_async = self.optimizer.ready
+            elif self.sync.reducer is not None:
+                self.sync.reducer.on_bucket = None
         else:
             eng.grad_ready = None
             eng.grad_ready_async = None
@@ -63,7 +65,7 @@ class Trainer:
             self.scheduler.step()
             self.global_step += 1
             if self.sync.reducer is not None:
-                eng.grad_ready = self.sync.reducer.ready
+                eng.grad_ready_async = self.sync.reducer.ready
         return loss.detach()
 
     def fit(self, lit, train_batches: Iterable, val_batches: Optional[Iterable] = None):
