@@ -33,6 +33,28 @@ def stats(path, skip_first_fraction=0.0):
     for key, f in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         if f[2] > 1:
             out.append(f"# \"{key}\",{f[0]},{f[1]:.3f},{f[1]/f[0]:.4f},{100*f[1]/tot:.2f},{f[2]}")
+    # GPU occupancy of the training steps: between consecutive full-table AdamW / transpose_table launches (one per step) --
+    # union of the kernel intervals vs wall time, and the largest idle gaps with the kernels around them
+    marks = [st for name, st, en in rows if "transpose_table_k" in name]
+    if len(marks) >= 3:
+        lo, hi = marks[-3], marks[-1]                                 # the last two steps of the trace
+        iv = [(st, en, name) for name, st, en in rows if st >= lo and en <= hi]
+        busy, cur_s, cur_e, gaps, last_name = 0, None, None, [], ""
+        for st, en, name in iv:
+            if cur_s is None:
+                cur_s, cur_e = st, en
+            elif st <= cur_e:
+                cur_e = max(cur_e, en)
+            else:
+                busy += cur_e - cur_s
+                gaps.append(((st - cur_e) / 1e3, last_name, name))
+                cur_s, cur_e = st, en
+            last_name = name
+        busy += cur_e - cur_s
+        out.append(f"# last two steps: wall {(hi - lo) / 1e6:.2f} ms, GPU busy (union of kernel intervals) {busy / 1e6:.2f} ms, "
+                   f"{len(gaps)} idle gaps totalling {sum(g[0] for g in gaps) / 1e3:.2f} ms")
+        for g in sorted(gaps, key=lambda g: -g[0])[:8]:
+            out.append(f"#   gap {g[0]:.1f} us between {g[1][:60]} and {g[2][:60]}")
     return "\n".join(out), tot, (rows[-1][2] - rows[0][1]) / 1e6
 
 
