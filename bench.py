@@ -125,8 +125,8 @@ class GemmTimer:
             for key, sz in (("preact", 2), ("mulz", 2), ("res_f32", 4), ("res_bf16", 2), ("C2", 2)):
                 if kw.get(key) is not None:
                     byt += mn * sz
-            t256 = ((M + 255) // 256) * ((N + 255) // 256) * bz          # same rule as mart_gemm_nt's dispatcher: >= 224 tiles and M > 128 -> 256x256 kernel
-            self.rec.append((2.0 * M * N * K * bz, s, e, t256 >= 224 and M > 128 and kw.get("tile_cfg", 0) in (0, 256), byt))
+            t256 = ((M + 255) // 256) * ((N + 255) // 256) * bz          # same rule as mart_gemm_nt's dispatcher: >= 128 tiles and M > 128 -> 256x256 kernel
+            self.rec.append((2.0 * M * N * K * bz, s, e, t256 >= 128 and M > 128 and kw.get("tile_cfg", 0) in (0, 256), byt))
             return r
         self.ops.gemm_nt = timed
         return self

@@ -53,7 +53,7 @@ typedef struct {
   float alpha;
   void* C; int ldc; int c_f32;
   void* C2; int ldc2;                                             /* optional bf16 copy; 0 -> ldc */
-  int tile_cfg;                                                   /* 0 auto (256x256 tiles from 224 tiles up and M > 128, else 128x128), 128, 256.
+  int tile_cfg;                                                   /* 0 auto (256x256 tiles from 128 tiles up and M > 128, else 128x128), 128, 256.
                                                                      Measurement / test hooks, never used by the engine: 2560 BK=32 four-slot ring, 2561 256-tile with the
                                                                      general epilogue, 2562 fast epilogue without the persistent loop, 999 / 9992 / 9993 timing experiments
                                                                      (results are wrong on purpose), 70000+t start stagger of t x 10 ns per CU group */
