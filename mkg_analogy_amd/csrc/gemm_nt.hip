@@ -504,6 +504,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       if constexpr (TM > 1) block(1, acc[1]);
       if constexpr (NPRE + 1 < TM) fetch(NPRE + 1);
       if constexpr (TM > 2) block(2, acc[2]);
+      if constexpr (NPRE + 2 < TM) fetch(NPRE + 2);
       if constexpr (TM > 3) block(3, acc[3]);
     };
     if (em0 + wm0 + WM <= p.M) run(std::false_type{}); else run(std::true_type{});
@@ -630,7 +631,11 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, 
 int launch(const Args& a, int batch, hipStream_t st) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2;
-  constexpr int LDS_EPI = WAVES_M * WAVES_N * 32 * (BN / WAVES_N + 4) * 4 + (PERSIST ? (BM + BN) * 64 * 2 : 0);   // persistent: staging above buffer 0
+  // epilogue staging per wave: packed bf16 rows (one or two outputs) in the bf16-only lane, one f32 block otherwise
+  constexpr bool PACKED = EPI >= 0 && (EPI & (F_RES | F_MULZ | F_CF32 | F_C2)) == 0;
+  constexpr int EPI_WAVE = PACKED ? (((EPI & F_PREACT) != 0) ? 2 : 1) * 32 * (BN / WAVES_N * 2 + 16) : 32 * (BN / WAVES_N + 4) * 4;
+  constexpr int LDS_EPI = WAVES_M * WAVES_N * EPI_WAVE + (PERSIST ? (BM + BN) * 64 * 2 : 0);   // persistent: staging above buffer 0
+  static_assert(LDS_EPI <= 160 * 1024, "epilogue staging does not fit next to the first K-tile buffer");
   constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
   static bool attr_set = false;
   auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, EPI, ACTK, PERSIST>;
@@ -707,8 +712,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->preact_grad ? F_PGRAD : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
                    (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
   if (aligned) {
-    // persistent loop: +6-7 % where the epilogue is light (bf16 out), neutral with the fp32 residual, -11 % with two bf16
-    // outputs (the next tile's first wait also drains the stores) -> only for the light masks
+    // persistent loop: +6-7 % where the epilogue is light (bf16 out); with the fp32 residual or two bf16 outputs it is
+    // neutral at best (re-measured after the epilogue work: fc1 0.571 vs 0.572 ms, step +0.3 %) -> only for the light masks
     const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ);
 #define MART_FAST(M_, K_)                                                                   \
     if (mask == (M_) && kind == (K_)) {                                                       \
