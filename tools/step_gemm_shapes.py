@@ -7,7 +7,7 @@ from mkg_analogy_amd import ops, data_synth as D
 from mkg_analogy_amd.trainer import Trainer
 ops.require_gpu()
 dev = torch.device("cuda", 0)
-model, lit, cfg = bench.build(16, seed=0, device=dev, backbone="mkgformer")
+model, lit, cfg = bench.build(int(os.environ.get("PATCH", 16)), seed=0, device=dev, backbone="mkgformer")
 batch = D.make_batch(256, 64, seed=1234, device=dev)
 tr = Trainer(max_epochs=1, max_steps=100, world_size=1)
 tr._setup(lit, [None] * 100)
