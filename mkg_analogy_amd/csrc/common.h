@@ -75,6 +75,14 @@ __device__ __forceinline__ bf16x4 f4_to_bf4(f32x4 v) {
   bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
   return o;
 }
+// four floats -> four bf16 through two 2-element conversions (v_cvt_pk_bf16_f32 each, no repacking)
+__device__ __forceinline__ bf16x4 f2x2_to_bf4(f32x2 lo, f32x2 hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+  const bf16x2_t l = __builtin_convertvector(lo, bf16x2_t), h = __builtin_convertvector(hi, bf16x2_t);
+  const u32x2_t w = {__builtin_bit_cast(unsigned, l), __builtin_bit_cast(unsigned, h)};
+  return __builtin_bit_cast(bf16x4, w);
+}
 __device__ __forceinline__ f32x4 bf4_to_f4(bf16x4 v) {
   f32x4 o = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   return o;
@@ -105,6 +113,22 @@ __device__ __forceinline__ void act_fwd_grad(float z, int act, float& a, float& 
     const float s = qgelu_sigmoid(z);
     a = z * s; g = s * (1.0f + 1.702f * z * (1.0f - s));
   } else { a = z; g = 1.0f; }
+}
+// two elements at a time: everything but the two transcendentals per element maps to packed f32 instructions (the GEMM
+// epilogues are VALU-bound: one wave64 VALU instruction = 4 cycles of the SIMD, 128 elements per lane and tile)
+__device__ __forceinline__ void act_fwd_grad2(f32x2 z, int act, f32x2& a, f32x2& g) {
+  if (act == ACT_QGELU) {
+    const f32x2 x = z * f32x2{-1.702f * 1.44269504088896340736f, -1.702f * 1.44269504088896340736f};
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])} + f32x2{1.0f, 1.0f};
+    const f32x2 s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    a = z * s;
+    g = s * ((z * f32x2{1.702f, 1.702f}) * (f32x2{1.0f, 1.0f} - s) + f32x2{1.0f, 1.0f});
+  } else {
+    float a0, g0, a1, g1;
+    act_fwd_grad(z[0], act, a0, g0);
+    act_fwd_grad(z[1], act, a1, g1);
+    a = f32x2{a0, a1}; g = f32x2{g0, g1};
+  }
 }
 __device__ __forceinline__ float act_grad(float z, int act) {
   if (act == ACT_STORED) return z;

@@ -384,10 +384,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
           f32x4 v = f32x4{ai[j][4 * q], ai[j][4 * q + 1], ai[j][4 * q + 2], ai[j][4 * q + 3]} * p.alpha + bq[j][q];
           char* dst = epb + l31 * RS + (j * 32 + 8 * q + 4 * h) * 2;
           if constexpr ((EPI & F_PGRAD) != 0) {
-            f32x4 g;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { float a_, g_; act_fwd_grad(v[e], ACTK, a_, g_); v[e] = a_; g[e] = g_; }
-            *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(g);
+            f32x2 a0, a1, g0, g1;
+            act_fwd_grad2(f32x2{v[0], v[1]}, ACTK, a0, g0);
+            act_fwd_grad2(f32x2{v[2], v[3]}, ACTK, a1, g1);
+            *(bf16x4*)(dst + 32 * RS) = f2x2_to_bf4(g0, g1);
+            *(bf16x4*)dst = f2x2_to_bf4(a0, a1);
+            continue;
           } else {
             if constexpr ((EPI & F_PREACT) != 0) *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(v);
             if constexpr ((EPI & F_ACT) != 0) {
