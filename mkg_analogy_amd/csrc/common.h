@@ -123,11 +123,28 @@ __device__ __forceinline__ void act_fwd_grad2(f32x2 z, int act, f32x2& a, f32x2&
     const f32x2 s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
     a = z * s;
     g = s * ((z * f32x2{1.702f, 1.702f}) * (f32x2{1.0f, 1.0f} - s) + f32x2{1.0f, 1.0f});
+  } else if (act == ACT_GELU) {
+    // erf through Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the two outputs this
+    // feeds): erf(|u|) = 1 - t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-u^2), t = 1 / (1 + p |u|), u = z / sqrt(2).
+    // exp(-u^2) = exp(-z^2 / 2) is the Gaussian of the derivative as well: ONE exp2 and ONE rcp per element instead of
+    // erff() + expf() (~70 VALU instructions per element: 30 us per 256x256 tile, a third of the text FFN launches).
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 az = {__builtin_fabsf(z[0]), __builtin_fabsf(z[1])};
+    const f32x2 x = (z * z) * f32x2{-0.5f * 1.44269504088896340736f, -0.5f * 1.44269504088896340736f};
+    const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};          // exp(-z^2 / 2)
+    const f32x2 d = az * f32x2{0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f} + one;
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 pl = t * f32x2{1.061405429f, 1.061405429f} + f32x2{-1.453152027f, -1.453152027f};
+    pl = pl * t + f32x2{1.421413741f, 1.421413741f};
+    pl = pl * t + f32x2{-0.284496736f, -0.284496736f};
+    pl = pl * t + f32x2{0.254829592f, 0.254829592f};
+    const f32x2 erfa = one - (pl * t) * e;                                                    // erf(|u|) in [0, 1]
+    const f32x2 erfs = {__builtin_copysignf(erfa[0], z[0]), __builtin_copysignf(erfa[1], z[1])};
+    const f32x2 cdf = erfs * f32x2{0.5f, 0.5f} + f32x2{0.5f, 0.5f};
+    a = z * cdf;
+    g = cdf + z * (e * f32x2{0.39894228040143267794f, 0.39894228040143267794f});
   } else {
-    float a0, g0, a1, g1;
-    act_fwd_grad(z[0], act, a0, g0);
-    act_fwd_grad(z[1], act, a1, g1);
-    a = f32x2{a0, a1}; g = f32x2{g0, g1};
+    a = z; g = f32x2{1.0f, 1.0f};
   }
 }
 __device__ __forceinline__ float act_grad(float z, int act) {

@@ -393,8 +393,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
           } else {
             if constexpr ((EPI & F_PREACT) != 0) *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(v);
             if constexpr ((EPI & F_ACT) != 0) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], ACTK);
+              // bf16 outputs: the same packed fast forms as the act + act' epilogue (bit-identical activations whether or
+              // not the derivative is kept); the f32-output lanes keep the accurate erff / division forms
+              f32x2 a0, a1, g0, g1;
+              act_fwd_grad2(f32x2{v[0], v[1]}, ACTK, a0, g0);
+              act_fwd_grad2(f32x2{v[2], v[3]}, ACTK, a1, g1);
+              v = f32x4{a0[0], a0[1], a1[0], a1[1]};
             }
           }
           *(bf16x4*)dst = f4_to_bf4(v);

@@ -17,6 +17,7 @@ def run(name, N, K, mk):
 bias3072 = torch.randn(3072, device=DEV); bias768 = torch.randn(768, device=DEV)
 run("fc1 fwd bias+act+act' -> bf16 x2", 3072, 768, lambda N: (dict(bias=bias3072, act=ops.ACT_QGELU, preact=torch.empty(M, N, device=DEV, dtype=BF), preact_grad=True), torch.empty(M, N, device=DEV, dtype=BF)))
 run("fc2 dgrad * stored act' -> bf16", 3072, 768, lambda N: (dict(mulz=torch.randn(M, N, device=DEV).to(BF), mul_act=ops.ACT_STORED), torch.empty(M, N, device=DEV, dtype=BF)))
+run("text fc1 fwd erf-gelu act+act' (M=16384)", 3072, 768, lambda N: (dict(bias=bias3072, act=ops.ACT_GELU, preact=torch.empty(M, N, device=DEV, dtype=BF), preact_grad=True, M=16384), torch.empty(M, N, device=DEV, dtype=BF)))
 run("qkv fwd bias -> bf16", 2304, 768, lambda N: (dict(bias=torch.randn(N, device=DEV)), torch.empty(M, N, device=DEV, dtype=BF)))
 run("out-proj bias+res_f32 -> f32", 768, 768, lambda N: (dict(bias=bias768, res_f32=torch.randn(M, N, device=DEV)), torch.empty(M, N, device=DEV)))
 run("fc2 fwd bias+res_f32 -> f32", 768, 3072, lambda N: (dict(bias=bias768, res_f32=torch.randn(M, N, device=DEV)), torch.empty(M, N, device=DEV)))
