@@ -256,7 +256,11 @@ def main():
         if roof is not None:
             out["roofline"] = roof
         if not a.no_cpu_baseline and world == 1 and a.model == "mkgformer" and not pre:
-            out["cpu_baseline"] = cpu_baseline(a.patch, a.seq_len)
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.patch, a.seq_len)
+            except Exception as e:                      # a host-side failure of the baseline leg must not lose the GPU measurement
+                out["cpu_baseline"] = {"value": None, "unit": "examples/s", "cores": min(os.cpu_count() or 1, 32), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
