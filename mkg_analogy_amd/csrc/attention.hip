@@ -32,6 +32,22 @@ __device__ __forceinline__ const bf16* side_row(const Side& s, int b, int h, int
   return s.own + ((long long)b * s.n_own + (j - s.n_pre)) * s.ld_own + h * 64;
 }
 
+// Workgroup -> (part, head, batch).  The gridDim.x workgroups of one (batch, head) pair stream the SAME K/V (or Q/dO) rows.
+// Workgroups are dealt to the 8 XCDs round-robin by linear id, so with the natural order (x fastest) the parts of a pair
+// land on different XCDs and each pulls the rows through its own L2.  Remapped in groups of 8 * gridDim.x ids: ids j,
+// 8 + j, 16 + j, ... of a group (same XCD, dispatched together) are the parts of ONE pair -- the second reader hits L2.
+struct WgId { int part, h, b; };
+__device__ __forceinline__ WgId wg_id(int nh, int B) {
+  const int G = gridDim.x;
+  const long long L = blockIdx.x + (long long)G * (blockIdx.y + (long long)nh * blockIdx.z);
+  const long long pairs = (long long)nh * B;
+  if (G == 1 || (pairs & 7) != 0) return WgId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  const long long group = L / (8 * G);
+  const int r = (int)(L - group * (8 * G));
+  const long long pair = group * 8 + (r & 7);
+  return WgId{r >> 3, (int)(pair % nh), (int)(pair / nh)};
+}
+
 // Loop-top barrier of the double-buffered tile loops.  The explicit vmcnt(0) is REQUIRED: the LDS-DMA of the tile about
 // to be read was issued by all four waves, and waves that skip the compute body (query / key rows past the end) would
 // otherwise reach the barrier with their quarter of the tile still in flight -- the compiler only places its own wait
@@ -137,7 +153,8 @@ __global__ __launch_bounds__(NTH, 2) void attn_fwd_k(mart_attn_fwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y;
+  const WgId wg = wg_id(p.nh, p.B);
+  const int b = wg.b, h = wg.h;
   const int Stot = p.Lp + p.Sk;
   const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_fwd_k(mart_attn_fwd_desc p) {
   float m_run[TPW], l_run[TPW];
 #pragma unroll
   for (int u = 0; u < TPW; ++u) {
-    q0[u] = blockIdx.x * (128 * TPW) + (wave * TPW + u) * 32;
+    q0[u] = wg.part * (128 * TPW) + (wave * TPW + u) * 32;
     qi[u] = q0[u] + l31;
     active[u] = q0[u] < p.Sq;                          // wave-uniform
     const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + min(qi[u], p.Sq - 1)) * p.ldq + h * 64;
@@ -322,7 +339,8 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
   const mart_attn_fwd_desc& p = pb.f;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y;
+  const WgId wg = wg_id(p.nh, p.B);
+  const int b = wg.b, h = wg.h;
   const int Stot = p.Lp + p.Sk;
   const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
@@ -337,7 +355,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
   f32x16 dq[TPW][2];
 #pragma unroll
   for (int u = 0; u < TPW; ++u) {
-    q0[u] = blockIdx.x * (128 * TPW) + (wave * TPW + u) * 32;
+    q0[u] = wg.part * (128 * TPW) + (wave * TPW + u) * 32;
     qi[u] = q0[u] + l31;
     const int qc = min(qi[u], p.Sq - 1);
     qvalid[u] = qi[u] < p.Sq;
@@ -462,7 +480,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
       if (pb.dw_ws) {
         // one private slot per wave; attn_dw_reduce_k sums them.  (Every wave of every workgroup adding to the same two
         // floats = 6144 contended device-scope atomics per launch: 0.15 ms, more than the rest of the kernel.)
-        const long long slot = (((long long)b * p.nh + h) * gridDim.x + blockIdx.x) * (NTH / 64) + wave;
+        const long long slot = (((long long)b * p.nh + h) * gridDim.x + wg.part) * (NTH / 64) + wave;
         pb.dw_ws[2 * slot] = dc0; pb.dw_ws[2 * slot + 1] = dc1;
       } else {
         const float w0 = p.w0[0], w1 = p.w1[0];
@@ -471,7 +489,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
       }
     }
   } else if (TEXT && pb.dw && pb.dw_ws && lane == 0) {
-    const long long slot = (((long long)b * p.nh + h) * gridDim.x + blockIdx.x) * (NTH / 64) + wave;
+    const long long slot = (((long long)b * p.nh + h) * gridDim.x + wg.part) * (NTH / 64) + wave;
     pb.dw_ws[2 * slot] = 0.f; pb.dw_ws[2 * slot + 1] = 0.f;
   }
 }
@@ -501,8 +519,9 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
   const mart_attn_fwd_desc& p = pb.f;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const WgId wg = wg_id(p.nh, p.B);
+  const int b = wg.b, h = wg.h;
+  const int k0 = wg.part * 128 + wave * 32;
   const int Stot = p.Lp + p.Sk;
   const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
