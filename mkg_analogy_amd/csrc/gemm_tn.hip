@@ -32,9 +32,13 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(Args p) {
   const int h = lane >> 5, l31 = lane & 31, g1 = (lane >> 4) & 1, pp = lane & 15;
 
   const int tiles_y = (p.NY + BNY - 1) / BNY;
-  const int tx = blockIdx.x / tiles_y, ty = blockIdx.x % tiles_y;
+  // XCD-aware order: consecutive logical ids (= the tiles of ONE split, which share its X / Y row slabs) land on the same
+  // XCD and therefore in the same L2; with the natural order every XCD saw a few tiles of every split (+6-10 % per launch)
+  const int ntile = gridDim.x;
+  const int lid = xcd_remap((int)(blockIdx.x + ntile * blockIdx.y), (int)(ntile * gridDim.y));
+  const int tile = lid % ntile, split = lid / ntile;
+  const int tx = tile / tiles_y, ty = tile % tiles_y;
   const int nx0 = tx * BNX, ny0 = ty * BNY;
-  const int split = blockIdx.y;
   const long long bz = blockIdx.z;
   const int ms = split * p.rows_per_split;
   const int me = min(p.M, ms + p.rows_per_split);
