@@ -6,9 +6,9 @@ for mode in serial overlap; do
   rm -rf gpurun_out/prof_tmp
   timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/prof_$mode.log 2>&1
   DB=$(find gpurun_out/prof_tmp -name "*.db" | head -1)
-  python tools/rocpd_stats.py $DB > gpurun_out/r01_bench_kernel_stats_v16_$mode.csv
+  python tools/rocpd_stats.py $DB > gpurun_out/r01_bench_kernel_stats_v17_$mode.csv
   tail -1 gpurun_out/prof_$mode.log | cut -c1-300
   rm -rf gpurun_out/prof_tmp
 done
 unset MART_OVERLAP_WGRAD MART_TWO_STREAM
-timeout 400 python bench.py 2>&1 | tail -1 > gpurun_out/bench_v16.json
+timeout 400 python bench.py 2>&1 | tail -1 > gpurun_out/bench_v17.json
