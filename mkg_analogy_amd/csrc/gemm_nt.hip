@@ -144,11 +144,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     for (int r = 0; r < RB; ++r) glds16(Bp + offB[r] + kb, sB + (r * NT + wave * 64) * 16);
   };
 
-  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  // PIPE == 2 (8-phase loop): the two wave-rows interleave in 64-row slabs -- wave-row wr owns rows {ih*128 + wr*64 + [0,64)},
+  // ih = 0,1 -- so that the first 32-row block pair of EVERY wave lies in the upper half-tile of A (rows 0..127) and the
+  // second pair in the lower one: a half-tile is dead (and can be re-staged) as soon as its phase has been read.
+  constexpr bool ILV = (PIPE == 2);
+  auto ro = [](int i) constexpr { return ILV ? (i >> 1) * 128 + (i & 1) * 32 : i * 32; };   // row offset of 32-row block i inside the wave's rows
+  const int wm0 = (wave / WAVES_N) * (ILV ? 64 : WM), wn0 = (wave % WAVES_N) * WN;
   // LDS read addressing: row -> byte base and swizzle key
   int rowA[TM], rowB[TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) rowA[i] = wm0 + i * 32 + l31;
+  for (int i = 0; i < TM; ++i) rowA[i] = wm0 + ro(i) + l31;
 #pragma unroll
   for (int j = 0; j < TN; ++j) rowB[j] = wn0 + j * 32 + l31;
 
@@ -230,6 +235,134 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[u][j], af[u][i], acc[i][j]);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all fragment reads of this slot retired before the next barrier
     }
+  } else if constexpr (PIPE == 2) {
+    // ---- 8-phase main loop (four phases per 64-deep K-tile, two K-tiles per LDS ring turn).
+    //   LDS ring: 2 K-tile buffers x 4 half-tiles of 16 KB -- A rows 0..127 (A0), A rows 128..255 (A1), B rows 0..127 (B0),
+    //   B rows 128..255 (B1).  One half-tile = 2 LDS-DMA instructions per thread: the unit of issue and of the vmcnt count.
+    //   A phase = [ fragment reads (+ ONE half-tile of LDS-DMA) | s_barrier | 8 MFMAs = one 64x32 quadrant x K=64 | s_barrier ].
+    //   The two wave-rows run ONE barrier apart (the lower one executes an extra s_barrier up front): while one wave of a
+    //   SIMD issues MFMAs its partner reads fragments / issues DMA, so the matrix pipe never waits for LDS.
+    //   Quadrant order (ih0,j0) (ih0,j1) (ih1,j1) (ih1,j0): P1 reads A(ih0) + B(j0), P2 reads B(j1), P3 reads A(ih1), P4 reads
+    //   nothing; both B fragments stay in registers.  With the interleaved row ownership (ILV) every wave's ih0 rows lie in
+    //   A0 and its ih1 rows in A1, so A0 is dead after P1, B0/B1 after P2, A1 after P3, and the half-tiles of K-tile t+2 are
+    //   issued into the buffer of K-tile t while t is still being computed:
+    //        P1(t): A1(t+1)      P2(t): A0(t+2)      P3(t): B0(t+2)      P4(t): B1(t+2), then s_waitcnt vmcnt(6)
+    //   i.e. ONE counted wait per K-tile that leaves the three newest half-tiles (48 KB per CU) in flight across the
+    //   barriers and never drains the queue; every half-tile has at least three phases to land.
+    //   RAW: the wait sits before P4's first barrier; K-tile t+1 is first read in P1(t+1), behind P4's second barrier, which
+    //        every wave of the other (one barrier apart) wave-row reaches only after its own wait.
+    //   WAR: a half-tile is re-staged one phase after its last read, and those reads are retired by an lgkmcnt wait BEFORE the
+    //        reading phase's first barrier (P1: lgkmcnt(4) = the 8 A reads, issued first; P2: lgkmcnt(0)); A1 is re-staged
+    //        two phases after P3.
+    static_assert(BM == 256 && BN == 256 && WAVES_M == 2 && WAVES_N == 4, "the 8-phase loop is laid out for 256x256 tiles, 2x4 waves");
+    const int grp = wave >> 2;
+    int keyA[TM], keyB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) keyA[i] = h ^ ((rowA[i] >> 1) & 7);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) keyB[j] = h ^ ((rowB[j] >> 1) & 7);
+    bf16x8 af[2][4], bfr[2][4];                            // A fragments [block of the pair][k-step], B fragments [j][k-step]
+    auto issueA = [&](int t, auto HALF) {
+      constexpr int hf = decltype(HALF)::value;
+      const bf16* Ap = A; int k0 = t * BK;
+      if (t >= nk1) { Ap = A2; k0 = (t - nk1) * BK; }
+      char* sA = smem + (t & 1) * STAGE;
+#pragma unroll
+      for (int r = 2 * hf; r < 2 * hf + 2; ++r) glds16(Ap + offA[r] + k0, sA + (r * NT + wave * 64) * 16);
+    };
+    auto issueB = [&](int t, auto HALF) {
+      constexpr int hf = decltype(HALF)::value;
+      const bf16* Bp = B + blkB1; int k0 = t * BK;
+      if (t >= nk1) { Bp = B2 + blkB2; k0 = (t - nk1) * BK; }
+      const long long kb = p.b_blocked ? (long long)(k0 >> 6) * 16384 : k0;
+      char* sB = smem + (t & 1) * STAGE + A_BYTES;
+#pragma unroll
+      for (int r = 2 * hf; r < 2 * hf + 2; ++r) glds16(Bp + offB[r] + kb, sB + (r * NT + wave * 64) * 16);
+    };
+    auto readA = [&](const char* sA_, auto IH) {
+      constexpr int ih = decltype(IH)::value;
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          af[ii][ks] = *(const bf16x8*)(sA_ + rowA[2 * ih + ii] * 128 + (((ks * 2) ^ keyA[2 * ih + ii]) << 4));
+    };
+    auto readB = [&](const char* sB_, auto J) {
+      constexpr int j = decltype(J)::value;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bfr[j][ks] = *(const bf16x8*)(sB_ + rowB[j] * 128 + (((ks * 2) ^ keyB[j]) << 4));
+    };
+    auto mma = [&](auto IH, auto J) {
+      constexpr int ih = decltype(IH)::value, j = decltype(J)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) acc[2 * ih + ii][j] = mfma32(bfr[j][ks], af[ii][ks], acc[2 * ih + ii][j]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto lgkm0 = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight
+    if (!have0) { issueA(0, I0{}); issueB(0, I0{}); issueB(0, I1{}); issueA(0, I1{}); }
+    else bar();                                            // persistent loop: the epilogue staging region overlaps buffer 1
+    if (nk > 1 && !(p.dbg & 1)) {
+      issueA(1, I0{}); issueB(1, I0{}); issueB(1, I1{});
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    if (grp == 1) bar();                                   // the lower wave-row runs one barrier behind
+    for (int t = 0; t < nk; ++t) {
+      const char* sA = smem + (t & 1) * STAGE;
+      const char* sB = sA + A_BYTES;
+      const bool more1 = t + 1 < nk && !(p.dbg & 1), more2 = t + 2 < nk && !(p.dbg & 1);
+      // P1
+      readA(sA, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      readB(sB, I0{});
+      if (more1) issueA(t + 1, I1{});
+      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // the 8 A reads (issued first) are retired: A0 may be re-staged in P2
+      bar();
+      lgkm0();
+      mma(I0{}, I0{});
+      bar();
+      // P2
+      readB(sB, I1{});
+      if (more2) issueA(t + 2, I0{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all B reads retired: B0 / B1 may be re-staged in P3 / P4
+      bar();
+      mma(I0{}, I1{});
+      bar();
+      // P3
+      readA(sA, I1{});
+      if (more2) issueB(t + 2, I0{});
+      bar();
+      lgkm0();
+      mma(I1{}, I1{});
+      bar();
+      // P4
+      if (more2) {
+        issueB(t + 2, I1{});
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // everything but the three half-tiles of K-tile t+2: K-tile t+1 has landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      bar();
+      mma(I1{}, I0{});
+      bar();
+    }
+    if (grp == 0) bar();                                   // balance the barrier count
   } else if constexpr (WAVES_M == 2 && WAVES_N == 4) {
     // ---- ping-pong main loop (8 waves).  The two wave-rows of the tile (waves 0-3 / 4-7; waves w and w+4 share a
     // SIMD) run the same 4-phase K-tile sequence  R0 | M0 | R1 | M1  (R = fragment reads of two k-steps (+ LDS-DMA
@@ -276,7 +409,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       const char* sA = smem + (t & 1) * STAGE;
       const char* sB = sA + A_BYTES;
       read2(sA, sB, 0);                                   // R0
-      if (t + 1 < nk && !p.dbg) stage(t + 1, (t + 1) & 1);
+      if (t + 1 < nk && !(p.dbg & 1)) stage(t + 1, (t + 1) & 1);
       phase_end();
       mma2();                                             // M0
       phase_end();
@@ -319,7 +452,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   // 16-byte reads with WN/4 lanes covering one row), so that ALL global epilogue traffic (bias, residual,
   // pre-activation, output) is coalesced: a row segment of WN columns = 128 B of bf16 / 256 B of f32 per request.
   // No block-level barrier after the first one, and all waves (both SIMD halves of the LDS store path) stay busy.
-  if (p.dbg == 2) return;                                        // timing experiment: no epilogue (non-persistent only)
+  if (p.dbg & 2) return;                                         // timing experiment: no epilogue (non-persistent only)
   constexpr int EP_LD = WN + 4;
   constexpr int LPR = WN / 4, RPI = 64 / LPR;                    // lanes per row, rows per wave-instruction
   constexpr int NIT = 32 / RPI;
@@ -409,8 +542,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + rr;
         const bf16x8 o = *(const bf16x8*)(epb + row * RS + rc * 2);
-        const long long uo = (long long)(i * 32 + it * 8) * p.ldc * 2;          // wave-uniform byte offset of the row group
-        if (!GUARD || i * 32 + row < mrem) {
+        const long long uo = (long long)(ro(i) + it * 8) * p.ldc * 2;          // wave-uniform byte offset of the row group
+        if (!GUARD || ro(i) + row < mrem) {
           st_stream((bf16x8*)(cbase + uo + loff), o);
           if constexpr ((EPI & F_PREACT) != 0) st_stream((bf16x8*)(pbase + uo + loff), *(const bf16x8*)(epb + 32 * RS + row * RS + rc * 2));
         }
@@ -423,7 +556,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     if constexpr (TM > 2) block(2, acc[2]);
     if constexpr (TM > 3) block(3, acc[3]);
     };
-    if (mrem >= WM) run(std::false_type{}); else run(std::true_type{});
+    if (mrem >= ro(TM - 1) + 32) run(std::false_type{}); else run(std::true_type{});
   } else if constexpr (EPI >= 0) {
     // ---- fast lane: full-width tiles, 16-byte aligned rows (checked by the host dispatcher).  The streamed operands of a
     // 32-row block (fp32 residual, z of the activation derivative) are fetched BEFORE the LDS round trip of the
@@ -467,7 +600,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
         if constexpr (PF) {
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
-            const int g = i * 32 + it * RPI;
+            const int g = ro(i) + it * RPI;
             if constexpr ((EPI & F_RES) != 0) pr[i % NPRE][it] = ld_stream((const f32x4*)adr(rbase, g, p.ldres, 4, lo_r));
             if constexpr ((EPI & F_MULZ) != 0) pz[i % NPRE][it] = ld_stream((const bf16x4*)adr(zbase, g, p.ldres, 2, lo_r));
           }
@@ -477,7 +610,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
         stage_block(ai);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-          const int row = it * RPI + er, g = i * 32 + it * RPI;
+          const int row = it * RPI + er, g = ro(i) + it * RPI;
           f32x4 v = *(const f32x4*)(ep + row * EP_LD + ec);
           v = v * p.alpha + bv;
           const bool ok = !GUARD || g + er < mrem;
@@ -513,7 +646,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       if constexpr (NPRE + 2 < TM) fetch(NPRE + 2);
       if constexpr (TM > 3) block(3, acc[3]);
     };
-    if (em0 + wm0 + WM <= p.M) run(std::false_type{}); else run(std::true_type{});
+    if (em0 + wm0 + ro(TM - 1) + 32 <= p.M) run(std::false_type{}); else run(std::true_type{});
     static_assert(TM <= 4, "epilogue blocks are written out for TM <= 4");
   } else {
   // ---- general lane: lane owns row m, 4 consecutive n per register quad
@@ -615,10 +748,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll 2
     for (int it = 0; it < NIT; ++it) {
       const int row = it * RPI + er;
-      const int m = em0 + wm0 + i * 32 + row, n = en0 + wn0 + ec;
+      const int m = em0 + wm0 + ro(i) + row, n = en0 + wn0 + ec;
       const f32x4 a = *(const f32x4*)(ep + row * EP_LD + ec);
-      if (p.dbg == 3) { if (a[0] == 1.2345f) *(float*)p.C = a[1]; }             // timing experiment: LDS staging only
-      else if (m < p.M && n < p.N) emit(m, n, a[0], a[1], a[2], a[3]);
+      if (m < p.M && n < p.N) emit(m, n, a[0], a[1], a[2], a[3]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -693,15 +825,19 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
   int cfg = d->tile_cfg;
+  bool old_loop = false;
   a.dbg = 0;
   a.stagger_ticks = 0;
   a.b_blocked = d->b_blocked;
   if (cfg == 999) { a.dbg = 1; cfg = 256; }
   if (cfg >= 70000 && cfg < 80000) { a.stagger_ticks = cfg - 70000; cfg = 256; }
-  if (cfg == 9992 || cfg == 9993) { a.dbg = cfg - 9990; cfg = 256; }
+  if (cfg == 9992 || cfg == 9993) { a.dbg = cfg - 9990; cfg = 256; }           // 9992: no epilogue, 9993: no LDS-DMA and no epilogue
+  if (cfg >= 99900 && cfg <= 99903) { a.dbg = cfg - 99900; old_loop = true; cfg = 256; }   // the same experiments on the round-1 loop
   // 256x256 tiles from half a round of workgroups up (128 tiles): the 192-tile text products (16384 x 768) run 7-15 % faster on
   // the large tile than on four times as many 128x128 tiles (step -0.6 %); below that the small tile fills the CUs better
   if (cfg == 0) cfg = ((t256 >= 128 && d->M > 128) || d->b_blocked) ? 256 : 128;   // short-M batched products (fusion, M = L = 64): 128-row tiles waste less
+  // 2563 / 2564: the round-1 ping-pong K loop (one vmcnt(0) per K-tile), fast / general epilogue (A/B + bit-identity tests)
+  if (cfg == 2563 || cfg == 2564) { old_loop = true; cfg = cfg == 2563 ? 256 : 2561; }
   if (cfg == 2561 || cfg == 2562) { /* 256x256 tile: 2561 general epilogue, 2562 fast epilogue without the persistent loop (A/B) */ if (cfg == 2562) cfg = 256; }
   MART_CHECK(!d->b_blocked || cfg == 256 || cfg == 999, "gemm_nt: b_blocked requires the 256x256 tile");
   if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
@@ -709,7 +845,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   const int tile = cfg == 256 ? 256 : 128;
   const bool aligned = (d->ldc % (d->c_f32 ? 4 : 8) == 0) && ((uintptr_t)d->preact % 16 == 0) && (d->stride_c % 8 == 0 || d->c_f32) &&
                        (d->ldc % 4 == 0) && (a.ldres % 4 == 0) && (a.ldc2 % 4 == 0) && (d->N % tile == 0) && !d->res_bf16 &&
-                       !d->bias_by_brow && a.dbg == 0 && d->tile_cfg != 2561 &&
+                       !d->bias_by_brow && d->tile_cfg != 2561 && d->tile_cfg != 2564 &&
                       
                        ((uintptr_t)d->C % 16 == 0) && ((uintptr_t)d->res_f32 % 16 == 0) && ((uintptr_t)d->mulz % 8 == 0) &&
                        ((uintptr_t)d->preact % 8 == 0) && ((uintptr_t)d->C2 % 8 == 0) && ((uintptr_t)d->bias % 16 == 0) &&
@@ -720,9 +856,10 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (aligned) {
     // persistent loop: +6-7 % where the epilogue is light (bf16 out); with the fp32 residual or two bf16 outputs it is
     // neutral at best (re-measured after the epilogue work: fc1 0.571 vs 0.572 ms, step +0.3 %) -> only for the light masks
-    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ);
+    const bool persist = d->tile_cfg != 2562 && (int)d->tile_cfg != 25620 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;
 #define MART_FAST(M_, K_)                                                                   \
     if (mask == (M_) && kind == (K_)) {                                                       \
+      if (tile == 256 && !old_loop) return persist ? launch<256, 256, 2, 4, 2, (M_), (K_), true>(a, batch, st) : launch<256, 256, 2, 4, 2, (M_), (K_)>(a, batch, st); \
       if (persist) return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_), true>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_), true>(a, batch, st); \
       return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_)>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st); }
     const int kind = d->mulz ? d->mul_act : d->act;
@@ -741,6 +878,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
     MART_FAST(F_CF32 | F_ACT, ACT_QGELU)
 #undef MART_FAST
   }
+  if ((cfg == 256 || cfg == 2561) && !old_loop) return launch<256, 256, 2, 4, 2>(a, batch, st);
   if (cfg == 256 || cfg == 2561) return launch<256, 256, 2, 4>(a, batch, st);
   return launch<128, 128, 2, 2>(a, batch, st);
 }

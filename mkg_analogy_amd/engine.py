@@ -48,6 +48,12 @@ class UnimoEngine:
         self.grad_ready: Optional[Callable[[int], None]] = None      # DDP hook: gradients below this flat offset are final
         self.grad_ready_async: Optional[Callable] = None              # same, without joining the streams: called with (offset, events to wait for)
         self.taps: Optional[dict] = None                              # debugging: per-layer stream snapshots when set to a dict
+        # Teacher forcing (tests only, single-stream schedule): ``inject[name]`` replaces the stream that ``taps[name]`` would have
+        # recorded ("vis_emb", "txt_emb", "vis{l}", "txt{l}": the INPUT of the next layer), ``inject_grad["vis{l}" / "txt{l}"]``
+        # replaces the gradient w.r.t. that stream in the backward pass (the engine's own value is tapped as "dvis{l}" / "dtxt{l}"
+        # first).  Every layer then sees exact inputs and exact upstream gradients, so a per-layer error is that layer's own.
+        self.inject: Optional[dict] = None
+        self.inject_grad: Optional[dict] = None
         import os
         self.overlap_wgrad = os.environ.get("MART_OVERLAP_WGRAD", "1") == "1"   # weight-gradient GEMMs on a side stream (+2.5 % step rate)
         self._side: Optional[torch.cuda.Stream] = None
@@ -207,6 +213,13 @@ class UnimoEngine:
         if self.taps is not None:
             self.taps["vis_emb"] = xv.view(B, Nv, H).clone()
             self.taps["txt_emb"] = xt.view(B, Lq, H).clone()
+        if self.inject is not None:
+            assert not self.two_stream and not self.overlap_wgrad, "teacher forcing runs on the single-stream schedule"
+            if "vis_emb" in self.inject:
+                xv = self.inject["vis_emb"].reshape(Mv, H).to(device=dev, dtype=F32).contiguous()
+            if "txt_emb" in self.inject:
+                xt = self.inject["txt_emb"].reshape(Mt, H).to(device=dev, dtype=F32).contiguous()
+                xtb = xt.to(BF)
 
         t_qkv_prev = None
         ev_tqkv = ev_vis = None
@@ -302,6 +315,12 @@ class UnimoEngine:
             if self.taps is not None:
                 self.taps[f"vis{l}"] = xv.view(B, Nv, H).clone()
                 self.taps[f"txt{l}"] = xt.view(B, Lq, H).clone()
+            if self.inject is not None:
+                if f"vis{l}" in self.inject:
+                    xv = self.inject[f"vis{l}"].reshape(Mv, H).to(device=dev, dtype=F32).contiguous()
+                if f"txt{l}" in self.inject:
+                    xt = self.inject[f"txt{l}"].reshape(Mt, H).to(device=dev, dtype=F32).contiguous()
+                    xtb = xt.to(BF)
 
         # ---- MLM head transform (BertPredictionHeadTransform.forward, modeling_unimo.py:972-975)
         with self._text_ctx():
@@ -369,6 +388,10 @@ class UnimoEngine:
         for l in reversed(range(self.n_layers)):
             # ================= text layer l
             dxvb_fresh = False
+            if self.taps is not None:
+                self.taps[f"dtxt{l}"] = (d_f32 + d_b16.float() if d_b16 is not None else d_f32.clone()).view(B, Lq, H)
+            if self.inject_grad is not None and f"txt{l}" in self.inject_grad:
+                d_f32, d_b16 = self.inject_grad[f"txt{l}"].reshape(Mt, H).to(device=dev, dtype=F32).contiguous(), None
             with self._text_ctx():
                 t = f"unimo.encoder.text_layer.{l}."
                 s = sv[f"t{l}"]
@@ -444,7 +467,13 @@ class UnimoEngine:
                 self._main_wait(ev_tfus)                                   # text layer l added d(vis) into dxv
             v = f"unimo.encoder.vision_layers.{l}."
             s = sv[f"v{l}"]
-            if (l >= self.fuse_from or l == self.n_layers - 1) and not dxvb_fresh:   # fusion of text layer l added d(vis) into dxv
+            if self.taps is not None:
+                self.taps[f"dvis{l}"] = dxv.view(B, Nv, H).clone()
+            if self.inject_grad is not None and f"vis{l}" in self.inject_grad:
+                dxv.copy_(self.inject_grad[f"vis{l}"].reshape(Mv, H))
+                dxvb_fresh = False
+                ops.add_f32_bf16(dxv, None, None, dxvb)
+            elif (l >= self.fuse_from or l == self.n_layers - 1) and not dxvb_fresh:   # fusion of text layer l added d(vis) into dxv
                 ops.add_f32_bf16(dxv, None, None, dxvb)                # -> refresh the bf16 copy (otherwise ln1 bwd wrote it)
             self._wgrad(dxvb, s["f"], v + "mlp.fc2.weight", v + "mlp.fc2.bias")
             dz = _e((Mv, I), BF, dev)

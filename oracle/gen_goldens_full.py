@@ -1,0 +1,185 @@
+"""G7 / G8: golden vectors of the UNMODIFIED reference at the benchmark's own shapes.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python oracle/gen_goldens_full.py            # writes tests/golden/g7_*.npz, g8_*.npz
+
+TEST INFRASTRUCTURE ONLY (same rules as gen_goldens.py: the reference modules are imported in place, no reference
+source is copied, only inputs + outputs are stored).
+
+G7  BASELINE configs[1] shape: the first 32 examples of bench.py's rank-0 batch (data_synth.make_batch(256, 64,
+    seed=1234)), ViT-B/16 patches (P=196, 393 vision tokens), L=64, V=42007, eval mode (dropout off), fp32.
+    Two weight sets regenerated from a numpy seed on every side: "plain" (N(0,0.02), what bench.py's network looks
+    like: chaotic in the unscaled fusion softmax) and "cond" (oracle.condition_weights: same network, smooth map).
+    Stored: mask logits [32,2063], trans_hidden at the five rows the loss reads, loss, ranks, metrics, all 451
+    gradient norms, strided samples of ~45 gradient tensors, and per-layer hidden states (reference forward hooks)
+    of layers 0, 7, 8, 11 for examples 0-1 (pins the oracle's per-layer taps at real dimensions).
+G8  BASELINE configs[4] shape: MarKG pre-train step, L=96, no sep_idx, mixed pre_type, B=8, CLIP-B/32 patches
+    (P=49, the geometry of the reference's pre-train script), full E=11292 / R=192 heads: loss, entity and relation
+    ranks, gradient norms and samples (incl. the tied word-embedding rows of the entity slice and cls.predictions.bias).
+"""
+from __future__ import annotations
+
+import argparse as ap
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import mkgformer_oracle as O  # noqa: E402
+from oracle.gen_goldens import FakeTokenizer, hf_configs, load_into, load_reference  # noqa: E402
+from mkg_analogy_amd import data_synth as D  # noqa: E402  (synthetic batch generator shared with bench.py)
+
+BASE, NE, NR = D.BASE_VOCAB, D.N_ENT, D.N_REL
+TAP_LAYERS = (0, 7, 8, 11)
+
+
+def sample_names():
+    names = ["cls.predictions.transform.dense.weight", "cls.predictions.transform.LayerNorm.weight", "cls.predictions.bias",
+             "unimo.text_embeddings.word_embeddings.weight", "unimo.text_embeddings.position_embeddings.weight",
+             "unimo.text_embeddings.token_type_embeddings.weight", "unimo.text_embeddings.LayerNorm.weight",
+             "unimo.vision_embeddings.patch_embedding.weight", "unimo.vision_embeddings.class_embedding",
+             "unimo.vision_embeddings.position_embedding.weight", "unimo.vision_pre_layrnorm.bias"]
+    for l in (0, 7, 8, 11):
+        t, v = f"unimo.encoder.text_layer.{l}.", f"unimo.encoder.vision_layers.{l}."
+        names += [t + "attention.self.query.weight", t + "attention.self.key.weight", t + "attention.self.value.bias",
+                  t + "attention.self.adaptive_weight.0", t + "attention.self.adaptive_weight.1",
+                  t + "attention.output.dense.weight", t + "intermediate.dense.weight", t + "output.dense.weight",
+                  t + "output.LayerNorm.weight",
+                  v + "self_attn.q_proj.weight", v + "self_attn.v_proj.weight", v + "self_attn.out_proj.bias",
+                  v + "layer_norm1.weight", v + "mlp.fc1.weight", v + "mlp.fc2.weight", v + "layer_norm2.bias"]
+        if l >= 8:
+            names += [t + "intermediate.fusion_dense.weight"]
+    return names
+
+
+def grad_sample(g: torch.Tensor, n: int = 1024) -> np.ndarray:
+    """A strided sample of a gradient tensor (the same rule is applied to the HIP gradients in the tests)."""
+    f = g.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().copy()
+
+
+def build_reference(lit, unimo, patch, sd0, pretrain, cfg):
+    vc, tc0 = O.VisionCfg(patch_size=patch), O.TextCfg(vocab_size=BASE)
+    hv, ht = hf_configs(vc, tc0)
+    torch.manual_seed(0)
+    model = unimo.UnimoForMaskedLM(hv, ht)
+    tok = FakeTokenizer(BASE + NE + NR)
+    args = ap.Namespace(label_smoothing=0.1, alpha=0.43, pretrain=int(pretrain), lr=5e-5, weight_decay=0.01, optimizer="AdamW",
+                        warm_up_radio=0.1)
+    lm = lit.TransformerLitModel(model=model, args=args, tokenizer=tok, data_config=cfg)      # resize -> 42006
+    load_into(model, sd0)
+    lm._init_relation_word()                                                                   # -> 42007
+    assert model.get_input_embeddings().weight.shape[0] == D.VOCAB and tok.extra["[R]"] == D.R_TOKEN
+    model.eval()
+    return model, lm
+
+
+def run(lit, unimo, out_dir, tag, patch, B, L, pretrain, conditioned, weight_seed, batch_seed, batch_total, taps):
+    t0 = time.time()
+    cfg = D.data_config(seed=1234)
+    vc = O.VisionCfg(patch_size=patch)
+    sd0 = O.init_params(vc, O.TextCfg(vocab_size=BASE + NE + NR), seed=weight_seed)
+    if conditioned:
+        sd0 = O.condition_weights(sd0)
+    model, lm = build_reference(lit, unimo, patch, sd0, pretrain, cfg)
+    full = D.make_batch(batch_total, L, seed=batch_seed, pretrain=pretrain)
+    batch = {k: v[:B].clone() for k, v in full.items()}
+    del full
+
+    hooks, tapped = [], {}
+    if taps:
+        enc = model.unimo.encoder
+        for l in TAP_LAYERS:
+            hooks.append(enc.vision_layers[l].register_forward_hook(
+                lambda m, i, o, l=l: tapped.__setitem__(f"vis{l}", o[0].detach()[:2, ::8].clone())))
+            hooks.append(enc.text_layer[l].register_forward_hook(
+                lambda m, i, o, l=l: tapped.__setitem__(f"txt{l}", o[0].detach()[:2, ::2].clone())))
+
+    def clone_batch():
+        return {k: v.clone() for k, v in batch.items()}
+
+    model.zero_grad()
+    loss = lm.training_step(clone_batch(), 1)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    named = dict(model.named_parameters())
+    none_grad = sorted(n for n, p in named.items() if p.grad is None)
+    norms = {n: float(p.grad.double().norm()) for n, p in named.items() if p.grad is not None}
+    samples = {"gs::" + n: grad_sample(named[n].grad) for n in sample_names() if named[n].grad is not None}
+    extra = {}
+    if pretrain:
+        # rows of the tied word embedding inside the entity slice that received decoder gradient only (never an input token)
+        g = named["unimo.text_embeddings.word_embeddings.weight"].grad
+        extra["wordemb_entity_rows"] = g[BASE + 17:BASE + NE:997].numpy().copy()
+        extra["wordemb_relation_rows"] = g[BASE + NE:BASE + NE + NR:13].numpy().copy()
+        extra["decoder_bias_grad"] = named["cls.predictions.bias"].grad[BASE:BASE + NE + NR].numpy().copy()
+
+    # forward outputs the trainer reads (no_grad second pass, full logits as the reference builds them)
+    fb = clone_batch()
+    for k in ("label", "rel_label", "rel_idx", "q_head_idx", "a_head_idx", "pre_type"):
+        fb.pop(k, None)
+    with torch.no_grad():
+        out, trans = model(**fb, return_dict=True)
+    ar = torch.arange(B)
+    _, mask_idx = (batch["input_ids"] == 103).nonzero(as_tuple=True)
+    mask_rows = out.logits[ar, mask_idx]
+    if pretrain:
+        outs = dict(entity_logits=mask_rows[:, BASE:BASE + NE].numpy(), relation_logits=mask_rows[:, BASE + NE:BASE + NE + NR].numpy(),
+                    trans_mask=trans[ar, mask_idx].numpy())
+    else:
+        ids = torch.tensor(cfg["analogy_entity_ids"])
+        rows = torch.stack([mask_idx, batch["q_head_idx"], batch["a_head_idx"], batch["rel_idx"][:, 0], batch["rel_idx"][:, 1]], 1)
+        outs = dict(mask_logits=mask_rows[:, ids].numpy(), trans_rows=trans[ar[:, None], rows].numpy(), trans_row_index=rows.numpy())
+    del out
+    ev = lm._eval(clone_batch(), 0)
+    ranks = {k: np.asarray(v) for k, v in ev.items()}
+    if not pretrain:
+        lm.validation_epoch_end([ev])
+        mets = dict(lm.__dict__["_logged"])
+        extra["metric_names"] = np.array(sorted(mets))
+        extra["metric_vals"] = np.array([mets[k] for k in sorted(mets)])
+
+    ints = {"in::" + k: v.numpy() for k, v in batch.items() if k != "pixel_values"}
+    pix = batch["pixel_values"]
+    np.savez_compressed(
+        os.path.join(out_dir, f"{tag}.npz"),
+        patch=np.int64(patch), B=np.int64(B), L=np.int64(L), pretrain=np.int64(pretrain), conditioned=np.int64(conditioned),
+        weight_seed=np.int64(weight_seed), batch_seed=np.int64(batch_seed), batch_total=np.int64(batch_total),
+        pixel_sum=np.float64(float(pix.double().sum())), pixel_abs_sum=np.float64(float(pix.double().abs().sum())),
+        loss=np.float64(float(loss)), none_grad=np.array(none_grad),
+        grad_norm_names=np.array(sorted(norms)), grad_norm_vals=np.array([norms[k] for k in sorted(norms)]),
+        **{"ranks::" + k: v for k, v in ranks.items()}, **{"tap::" + k: v.numpy() for k, v in tapped.items()},
+        **ints, **outs, **samples, **extra)
+    print(f"{tag}: loss {float(loss):.6f} ranks {ranks} ({time.time() - t0:.1f} s)", flush=True)
+
+
+def main():
+    p = ap.ArgumentParser()
+    p.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    p.add_argument("--only", default="")
+    a = p.parse_args()
+    torch.set_num_threads(os.cpu_count() or 8)
+    lit, unimo = load_reference()
+    jobs = [
+        dict(tag="g7_bench_plain", patch=16, B=32, L=64, pretrain=False, conditioned=False, weight_seed=0, batch_seed=1234, batch_total=256, taps=True),
+        dict(tag="g7_bench_cond", patch=16, B=32, L=64, pretrain=False, conditioned=True, weight_seed=0, batch_seed=1234, batch_total=256, taps=False),
+        dict(tag="g8_pretrain_cond", patch=32, B=8, L=96, pretrain=True, conditioned=True, weight_seed=0, batch_seed=1234, batch_total=8, taps=False),
+        dict(tag="g8_pretrain_plain", patch=32, B=8, L=96, pretrain=True, conditioned=False, weight_seed=0, batch_seed=1234, batch_total=8, taps=False),
+    ]
+    for j in jobs:
+        if a.only and a.only not in j["tag"]:
+            continue
+        run(lit, unimo, a.out, **j)
+
+
+if __name__ == "__main__":
+    main()

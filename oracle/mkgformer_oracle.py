@@ -152,6 +152,20 @@ def init_params(vc: VisionCfg, tc: TextCfg, seed: int = 0, dtype=torch.float32) 
     return out
 
 
+def condition_weights(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """Well-conditioned variant of the synthetic weights (test infrastructure; shared by the golden generators and the tests).
+    With plain N(0,0.02) weights the UNSCALED fusion softmax softmax(ctx vis^T) of text layers 8-11 (modeling_unimo.py:405-410)
+    is nearly one-hot (score std ~15) and the network is chaotic there: rounding only the weight matrices to bf16 inside the
+    fp32 math already moves trans_hidden by ~5 %.  Shrinking the text value projection of those layers keeps every code path
+    live and makes the map smooth, so bf16 implementations can be held to the 1e-2 logit tolerance.  Returns a new dict."""
+    out = dict(sd)
+    for l in range(8, 12):
+        for k in ("weight", "bias"):
+            n = f"unimo.encoder.text_layer.{l}.attention.self.value.{k}"
+            out[n] = sd[n] * 0.05
+    return out
+
+
 # --------------------------------------------------------------------------- small pieces
 def gelu_erf(x: Tensor) -> Tensor:
     """transformers ACT2FN['gelu'] = exact erf GELU (call sites modeling_unimo.py:454,967)."""

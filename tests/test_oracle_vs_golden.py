@@ -8,6 +8,8 @@ import torch
 
 from oracle import mkgformer_oracle as O
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 TINY_V = O.VisionCfg(hidden_size=64, num_hidden_layers=12, num_attention_heads=4, intermediate_size=128,
                      image_size=64, patch_size=32)
 
@@ -194,3 +196,101 @@ def test_g5_flava_oracle_matches_reference(golden_dir):
             np.testing.assert_allclose(sd[k[6:]].grad.numpy(), g[k], atol=3e-6, rtol=3e-4, err_msg=k)
     for k, v in zip(g["grad_norm_names"].tolist(), g["grad_norm_vals"].tolist()):
         assert abs(float(sd[k].grad.norm()) - v) <= 1e-6 + 3e-4 * v, k
+
+
+# ----------------------------------------------------------------------------- G7 / G8: the benchmark's own shapes
+def _g78_setup(tag):
+    import os
+    from mkg_analogy_amd import data_synth as D
+    g = dict(np.load(os.path.join(GOLDEN, tag + ".npz"), allow_pickle=False))
+    pre = bool(int(g["pretrain"]))
+    vc = O.VisionCfg(patch_size=int(g["patch"]))
+    sd = O.init_params(vc, O.TextCfg(vocab_size=D.BASE_VOCAB + D.N_ENT + D.N_REL), seed=int(g["weight_seed"]))
+    if int(g["conditioned"]):
+        sd = O.condition_weights(sd)
+    cfg = D.data_config(seed=1234)
+    sd = O.init_relation_word(sd, cfg["analogy_relation_ids"])
+    B = int(g["B"])
+    full = D.make_batch(int(g["batch_total"]), int(g["L"]), seed=int(g["batch_seed"]), pretrain=pre)
+    batch = {k: v[:B].clone() for k, v in full.items()}
+    for k, v in batch.items():
+        if k != "pixel_values":
+            assert np.array_equal(v.numpy(), g["in::" + k]), k
+    assert abs(float(batch["pixel_values"].double().sum()) - float(g["pixel_sum"])) < 1e-6 * float(g["pixel_abs_sum"])
+    return g, vc, O.TextCfg(vocab_size=D.VOCAB), sd, cfg, batch
+
+
+def _sample(t, n=1024):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy()
+
+
+def test_g7_oracle_matches_reference_at_bench_shape():
+    """The oracle against the UNMODIFIED reference on BASELINE configs[1]'s shape (first 32 examples of bench.py's batch, P=196,
+    L=64, V=42007, plain N(0,0.02) weights): logits, trans rows, per-layer hidden states of layers 0/7/8/11, loss, ranks,
+    all 451 gradient norms and strided gradient samples."""
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8))))
+    g, vc, tc, sd, cfg, batch = _g78_setup("g7_bench_plain")
+    B = int(g["B"])
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    taps = {}
+    _, trans = O.forward(sdg, vc, tc, batch["input_ids"], batch["attention_mask"], batch["token_type_ids"], batch["pixel_values"],
+                         batch["sep_idx"], train=False, taps=taps)
+    ids = torch.tensor(cfg["analogy_entity_ids"])
+    loss, ml = O.finetune_loss(sdg, trans, batch["input_ids"], batch["label"], batch["rel_idx"], batch["q_head_idx"], batch["a_head_idx"], ids, alpha=0.43)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    np.testing.assert_allclose(ml.detach().numpy(), g["mask_logits"], atol=2e-4)
+    rows = torch.from_numpy(g["trans_row_index"])
+    np.testing.assert_allclose(trans.detach()[torch.arange(B)[:, None], rows].numpy(), g["trans_rows"], atol=2e-4)
+    for l in (0, 7, 8, 11):
+        np.testing.assert_allclose(taps[f"vis{l}"].detach()[:2, ::8].numpy(), g[f"tap::vis{l}"], atol=5e-4, rtol=1e-4)
+        np.testing.assert_allclose(taps[f"txt{l}"].detach()[:2, ::2].numpy(), g[f"tap::txt{l}"], atol=5e-4, rtol=1e-4)
+    assert np.array_equal(O.ranks_double_sort(ml.detach(), batch["label"]), g["ranks::entity_ranks"])
+    norms = dict(zip(g["grad_norm_names"].tolist(), g["grad_norm_vals"].tolist()))
+    for n, ref in norms.items():
+        if n.endswith("decoder.weight"):
+            continue
+        got = float(sdg[n].grad.double().norm()) if sdg[n].grad is not None else 0.0
+        assert abs(got - ref) <= 2e-3 * ref + 1e-7, (n, got, ref)       # 1e-7: mathematically zero gradients (e.g. CLIP k_proj.bias) are rounding noise
+    for k in [k for k in g if k.startswith("gs::")]:
+        ref = g[k]
+        got = _sample(sdg[k[4:]].grad)
+        assert np.linalg.norm(got - ref) <= 2e-3 * np.linalg.norm(ref) + 1e-9, k
+    for n in g["none_grad"].tolist():
+        if n in sdg and not n.endswith("decoder.weight"):
+            assert sdg[n].grad is None or float(sdg[n].grad.abs().max()) == 0.0, n
+
+
+@pytest.mark.parametrize("tag", ["g8_pretrain_cond", "g8_pretrain_plain"])
+def test_g8_oracle_matches_reference_pretrain_step(tag):
+    """BASELINE configs[4] shape: L=96, sep_idx=None, mixed pre_type, full entity / relation heads (lit_models/transformer.py:72-90)."""
+    from mkg_analogy_amd import data_synth as D
+    g, vc, tc, sd, cfg, batch = _g78_setup(tag)
+    B = int(g["B"])
+    E0, E1, R1 = D.BASE_VOCAB, D.BASE_VOCAB + D.N_ENT, D.BASE_VOCAB + D.N_ENT + D.N_REL
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    _, trans = O.forward(sdg, vc, tc, batch["input_ids"], batch["attention_mask"], batch["token_type_ids"], batch["pixel_values"], None, train=False)
+    loss = O.pretrain_loss(sdg, trans, batch["input_ids"], batch["label"], batch["pre_type"], (E0, E1), (E1, R1))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 3e-5
+    _, mask_idx = (batch["input_ids"] == 103).nonzero(as_tuple=True)
+    rows = trans.detach()[torch.arange(B), mask_idx]
+    ent, rel = O.score(sd, rows, slice(E0, E1)), O.score(sd, rows, slice(E1, R1))
+    np.testing.assert_allclose(ent.numpy(), g["entity_logits"], atol=2e-4)
+    np.testing.assert_allclose(rel.numpy(), g["relation_logits"], atol=2e-4)
+    pt = batch["pre_type"]
+    assert np.array_equal(O.ranks_double_sort(ent[pt != 2], batch["label"][pt != 2]), g["ranks::entity_ranks"])
+    assert np.array_equal(O.ranks_double_sort(rel[pt == 2], batch["label"][pt == 2]), g["ranks::relation_ranks"])
+    gw = sdg["unimo.text_embeddings.word_embeddings.weight"].grad
+    np.testing.assert_allclose(gw[E0 + 17:E1:997].numpy(), g["wordemb_entity_rows"], atol=1e-6, rtol=2e-3)
+    np.testing.assert_allclose(sdg["cls.predictions.bias"].grad[E0:R1].numpy(), g["decoder_bias_grad"], atol=1e-7, rtol=2e-3)
+    norms = dict(zip(g["grad_norm_names"].tolist(), g["grad_norm_vals"].tolist()))
+    for n, ref in norms.items():
+        if n.endswith("decoder.weight"):
+            continue
+        got = float(sdg[n].grad.double().norm()) if sdg[n].grad is not None else 0.0
+        assert abs(got - ref) <= 2e-3 * ref + 1e-7, (n, got, ref)       # 1e-7: mathematically zero gradients (e.g. CLIP k_proj.bias) are rounding noise
+    none = set(g["none_grad"].tolist())
+    assert {n for n in sdg if "adaptive_weight" in n} <= none
