@@ -10,7 +10,9 @@
  *   - plain pointers + sizes; the CALLER owns every buffer (incl. workspaces); kernels never allocate or free
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no internal synchronisation
  *   - return 0 on success, <0 on error (-1 bad argument, -2 launch failure); mart_last_error() has the text
- *   - stateless and re-entrant; one host thread per GPU process
+ *   - stateless apart from a per-device "dynamic-LDS attribute set" flag per kernel; one host thread per GPU process is the
+ *     supported model (two threads racing on a kernel's first launch both set the attribute: harmless); several devices per
+ *     process are fine (the flag is kept per device)
  *   - bf16 tensors are raw uint16 storage; "ld*" are leading dimensions in ELEMENTS
  */
 #ifndef MART_HIP_H

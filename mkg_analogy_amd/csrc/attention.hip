@@ -677,9 +677,10 @@ int check_fwd(const mart_attn_fwd_desc* d) {
   MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "attn: bad dropout p");
   return 0;
 }
-bool g_attr_set = false;
+MartAttrOnce g_attr_once;
 int set_attrs() {
-  if (g_attr_set) return 0;
+  bool* g_attr_set = g_attr_once.slot();
+  if (*g_attr_set) return 0;
   const void* ks[8] = {(const void*)attn_fwd_k<false, 1>, (const void*)attn_fwd_k<false, 2>, (const void*)attn_fwd_k<true, 1>,
                        (const void*)attn_bwd_dq_k<false, 1>, (const void*)attn_bwd_dq_k<false, 2>, (const void*)attn_bwd_dq_k<true, 1>, (const void*)attn_bwd_dkv_k<false>,
                        (const void*)attn_bwd_dkv_k<true>};
@@ -689,7 +690,7 @@ int set_attrs() {
     mart_set_error("attn: hipFuncSetAttribute failed");
     return -2;
   }
-  g_attr_set = true;
+  *g_attr_set = true;
   return 0;
 }
 }  // namespace

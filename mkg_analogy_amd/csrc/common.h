@@ -34,6 +34,13 @@ extern "C" void mart_set_error(const char* msg);
     }                                                     \
   } while (0)
 
+// ---- per-DEVICE "kernel attribute already set" flags (hipFuncSetAttribute is per device): a process that drives several GPUs
+// sets the dynamic-LDS attribute once on each of them.  Two host threads racing on a first call both set it: harmless.
+struct MartAttrOnce {
+  bool done[64] = {};
+  bool* slot() { int dev = 0; (void)hipGetDevice(&dev); return &done[dev & 63]; }
+};
+
 // ---- MFMA 32x32x16 bf16.  D[i][j] += sum_k A[i][k] B[k][j].
 // Operand layout (wave64): lane l holds A[i = l&31][k = 8*(l>>5) + 0..7] and B[k = 8*(l>>5)+0..7][j = l&31].
 // Result layout: lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].

@@ -775,14 +775,15 @@ int launch(const Args& a, int batch, hipStream_t st) {
   constexpr int LDS_EPI = WAVES_M * WAVES_N * EPI_WAVE + (PERSIST ? (BM + BN) * 64 * 2 : 0);   // persistent: staging above buffer 0
   static_assert(LDS_EPI <= 160 * 1024, "epilogue staging does not fit next to the first K-tile buffer");
   constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
-  static bool attr_set = false;
+  static MartAttrOnce once;
+  bool* attr_set = once.slot();
   auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, EPI, ACTK, PERSIST>;
-  if (!attr_set) {
+  if (!*attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       mart_set_error("gemm_nt: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
       return -2;
     }
-    attr_set = true;
+    *attr_set = true;
   }
   int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   if (PERSIST) {                                                 // one workgroup per CU slot (256 CUs; LDS allows 1 / 2 per CU)

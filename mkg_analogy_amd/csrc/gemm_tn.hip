@@ -189,14 +189,15 @@ extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
   MART_CHECK(((uintptr_t)d->X & 15) == 0 && ((uintptr_t)d->Y & 15) == 0, "gemm_tn: X/Y must be 16-byte aligned");
   MART_CHECK(d->out != nullptr && d->ldo >= d->NY, "gemm_tn: bad out/ldo");
   MART_CHECK(!d->colsum_by_row || d->out_rows, "gemm_tn: colsum_by_row needs out_rows");
-  static bool attr_set = false;
+  static MartAttrOnce once;
+  bool* attr_set = once.slot();
   constexpr int LDS = 2 * STAGE;
-  if (!attr_set) {
+  if (!*attr_set) {
     if (hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       mart_set_error("gemm_tn: hipFuncSetAttribute failed");
       return -2;
     }
-    attr_set = true;
+    *attr_set = true;
   }
   Args a;
   a.X = (const bf16*)d->X; a.Y = (const bf16*)d->Y; a.ldx = d->ldx; a.ldy = d->ldy;

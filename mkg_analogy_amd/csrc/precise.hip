@@ -158,14 +158,15 @@ int launch_attn(const mart_attn_f32_desc* d, hipStream_t st) {
   const int Stot = d->Lp + d->Sk;
   const size_t lds = (size_t)(QT * D + QT * Stot) * sizeof(float);
   MART_CHECK(lds <= 160 * 1024, "attn_f32: keys do not fit the LDS score tile");
-  static bool attr_set = false;
+  static MartAttrOnce once;
+  bool* attr_set = once.slot();
   auto kern = attn_f32_k<D>;
-  if (!attr_set) {
+  if (!*attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       mart_set_error("attn_f32: hipFuncSetAttribute failed");
       return -2;
     }
-    attr_set = true;
+    *attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((d->Sq + QT - 1) / QT, d->nh, d->B), dim3(256), lds, st, *d);
   MART_LAUNCH_CHECK();

@@ -99,6 +99,16 @@ class DataCollatorForSeq2Seq:
             else:
                 batch["image_index"] = slots
         batch["label"] = torch.tensor(col["label"])
+        # The reference fails loudly on a prompt without exactly one [MASK] (transformer.py:74-75 assert / shape mismatch at :95)
+        # and torch raises on an out-of-range label; the device kernels index without checks, so both are validated here, on
+        # the host, where the batch is built (a prompt truncated by max_seq_length loses its trailing [MASK]).
+        mask_id = getattr(self.tokenizer, "mask_token_id", None)
+        if mask_id is not None and "input_ids" in batch and torch.is_tensor(batch["input_ids"]):
+            n_mask = (batch["input_ids"] == mask_id).sum(1)
+            if not bool((n_mask == 1).all()):
+                raise ValueError(f"every prompt needs exactly one [MASK]; rows {torch.nonzero(n_mask != 1).flatten().tolist()} have {n_mask[n_mask != 1].tolist()}")
+        if bool((batch["label"] < 0).any()) or (self.num_labels and bool((batch["label"] >= self.num_labels).any())):
+            raise ValueError("label out of range (ignore_index / negative labels are not supported by the fused loss)")
         for k in ("pre_type", "rel_idx", "sep_idx", "rel_label", "q_head_idx", "a_head_idx"):
             if col.get(k):
                 batch[k] = torch.tensor(col[k])
@@ -189,6 +199,14 @@ class KGC(BaseDataModule):
         return self.tokenizer
 
     def _loader(self, data, batch_size, shuffle):
+        """One process per GPU: under an initialised process group every rank reads its own shard (what PL injects into the
+        reference's loaders under DDP: DistributedSampler, padded to equal length); Trainer.fit calls set_epoch per epoch."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.utils.data.distributed import DistributedSampler
+            ds = DistributedSampler(data, shuffle=shuffle)
+            return DataLoader(data, num_workers=self.num_workers, pin_memory=False, collate_fn=self.sampler,
+                              batch_size=batch_size, sampler=ds)
         return DataLoader(data, num_workers=self.num_workers, pin_memory=False, collate_fn=self.sampler,
                           batch_size=batch_size, shuffle=shuffle)
 

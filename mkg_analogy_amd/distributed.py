@@ -75,6 +75,32 @@ class GradSync:
         self.reducer = BucketedAllReduce(st.grad, st.buckets(bucket_elems), group) if on else None
         if self.reducer is not None:
             model.engine.grad_ready_async = self.reducer.ready       # (offset, events): no stream joins in the backward pass
+        self.group = group
+        if dist.is_initialized() and (self.world > 1 or on):
+            # Replicas start from rank 0's weights (what PL-DDP's module broadcast does): resize_token_embeddings draws the new
+            # [ENTITY_i] / [RELATION_j] rows from the per-process RNG, so without this the ranks would train different networks
+            # that never re-synchronise (only gradients are all-reduced).
+            dist.broadcast(st.master, src=0, group=group)
+            st.refresh_shadows()
+            # ... and draw DIFFERENT dropout masks: the counter-based dropout seed is derived from base_seed, identical on
+            # every rank by construction; mix the rank in (rank 0 keeps the single-process stream)
+            rank = dist.get_rank(group)
+            if rank and hasattr(model, "base_seed") and not getattr(model, "_rank_seeded", False):
+                model.base_seed = (int(model.base_seed) ^ (rank * 0x9E3779B1)) & 0x7FFFFFFF
+                model._rank_seeded = True
+
+    def broadcast_optimizer(self, optimizer) -> None:
+        """Resume path: AdamW moments and the step count follow rank 0 as well."""
+        if not dist.is_initialized() or self.world == 1:
+            return
+        for name in ("m", "v"):
+            t = getattr(optimizer, name, None)
+            if torch.is_tensor(t):
+                dist.broadcast(t, src=0, group=self.group)
+        steps = torch.tensor([int(getattr(optimizer, "steps", 0))], device=self.model.store.master.device, dtype=torch.int64)
+        dist.broadcast(steps, src=0, group=self.group)
+        if hasattr(optimizer, "steps"):
+            optimizer.steps = int(steps)
 
     def begin(self) -> None:
         if self.reducer is not None:

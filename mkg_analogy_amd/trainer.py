@@ -12,9 +12,12 @@ from .distributed import GradSync, all_gather_ranks
 
 
 class Trainer:
-    def __init__(self, max_epochs: int = 1, max_steps: Optional[int] = None, accumulate_grad_batches: int = 1, world_size: int = 1,
-                 log_every: int = 0):
+    def __init__(self, max_epochs: int = 1, max_steps: Optional[int] = None, accumulate_grad_batches: int = 1,
+                 world_size: Optional[int] = None, log_every: int = 0):
         self.max_epochs, self.max_steps, self.accumulate_grad_batches = max_epochs, max_steps, accumulate_grad_batches
+        if world_size is None:                                      # one process per GPU under torchrun: the process group says how many
+            import torch.distributed as dist
+            world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.world_size = world_size
         self.log_every = log_every
         import os
@@ -25,17 +28,25 @@ class Trainer:
 
     def _setup(self, lit, train_batches):
         lit.trainer = self
-        self.num_train_batches = len(train_batches)
+        # num_training_steps (lit_models/base.py:74-95) divides the UNSHARDED loader length by the device count: a loader that is
+        # already sharded by a DistributedSampler (data_module.KGC._loader) reports its per-rank length
+        self.num_train_batches = len(train_batches) * self._shards(train_batches)
         lit.model.finalize()
         oc = lit.configure_optimizers()
         self.optimizer, self.scheduler = oc["optimizer"], oc["lr_scheduler"]["scheduler"]
         self.sync = GradSync(lit.model)
+        self.sync.broadcast_optimizer(self.optimizer)
         self.optimizer.grad_scale = self.sync.grad_scale / max(1, self.accumulate_grad_batches)
 
-    def train_step(self, lit, batch, batch_idx: int) -> torch.Tensor:
+    @staticmethod
+    def _shards(loader) -> int:
+        sampler = getattr(loader, "sampler", None)
+        return int(getattr(sampler, "num_replicas", 1) or 1) if sampler is not None and hasattr(sampler, "set_epoch") else 1
+
+    def train_step(self, lit, batch, batch_idx: int, end_of_epoch: bool = False) -> torch.Tensor:
         lit.model.train()
         first = batch_idx % self.accumulate_grad_batches == 0
-        last = (batch_idx + 1) % self.accumulate_grad_batches == 0
+        last = (batch_idx + 1) % self.accumulate_grad_batches == 0 or end_of_epoch    # PL steps on an epoch's last (partial) window too
         if first:
             self.optimizer.zero_grad()
         eng = lit.model.engine
@@ -73,8 +84,12 @@ class Trainer:
         self._setup(lit, train_batches)
         for epoch in range(self.max_epochs):
             t0 = time.time()
+            sampler = getattr(train_batches, "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)                              # a different shuffle per epoch, the same on every rank
+            n = len(train_batches)
             for i, batch in enumerate(train_batches):
-                loss = self.train_step(lit, batch, i)
+                loss = self.train_step(lit, batch, i, end_of_epoch=(i == n - 1))
                 if self.log_every and (i + 1) % self.log_every == 0:
                     print(f"epoch {epoch} step {i + 1}: loss {float(loss):.4f} lr {self.optimizer.param_groups[0]['lr']:.3e}")
                 if self.max_steps and self.global_step >= self.max_steps:
@@ -91,11 +106,12 @@ class Trainer:
         lit.model.eval()
         outs = [step_fn(dict(b), i) for i, b in enumerate(batches)]
         merged = {}
+        sharded = self._shards(batches) > 1 or getattr(batches, "sharded", False)   # every rank saw the whole set otherwise: no gather
         for key in ("entity_ranks", "relation_ranks"):
             parts = [o[key] for o in outs if key in o]
             if parts:
                 import numpy as np
-                merged[key] = all_gather_ranks(np.concatenate(parts))
+                merged[key] = all_gather_ranks(np.concatenate(parts)) if sharded else np.concatenate(parts)
         lit.logged = {}
         end_fn([merged])
         return dict(lit.logged)

@@ -184,3 +184,82 @@ def test_flava_parameter_names_and_layout():
     assert m.get_input_embeddings().weight is m.get_output_embeddings().weight
     m.resize_token_embeddings(125)
     assert m.cls.bias.shape == (125,) and m.get_output_embeddings().weight.shape == (125, 768)
+
+
+def test_trainer_world_size_shards_and_tail_window():
+    """Trainer host logic (no GPU): world size defaults to the process group's, a DistributedSampler-sharded loader is counted at
+    its unsharded length for num_training_steps (lit_models/base.py:86-91 divides by the device count itself), and the last
+    partial accumulation window of an epoch still steps the optimizer (as PL does)."""
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+    from torch.utils.data.distributed import DistributedSampler
+    from mkg_analogy_amd.trainer import Trainer
+    t = Trainer(max_epochs=2, accumulate_grad_batches=4)
+    assert t.world_size == 1                                            # no process group here
+    ds = TensorDataset(torch.arange(40))
+    plain = DataLoader(ds, batch_size=4)
+    sharded = DataLoader(ds, batch_size=4, sampler=DistributedSampler(ds, num_replicas=2, rank=0, shuffle=False))
+    assert Trainer._shards(plain) == 1 and Trainer._shards(sharded) == 2
+    assert len(sharded) * Trainer._shards(sharded) == len(plain)
+
+    class _Opt:
+        def __init__(self):
+            self.steps, self.zeroed, self.param_groups, self.grad_scale = 0, 0, [{"lr": 0.0}], 1.0
+
+        def zero_grad(self):
+            self.zeroed += 1
+
+        def step(self):
+            self.steps += 1
+
+    class _Sync:
+        reducer, grad_scale = None, 1.0
+
+        def begin(self):
+            pass
+
+        def finish(self):
+            pass
+
+    class _Eng:
+        grad_ready = grad_ready_async = None
+
+    class _Model:
+        engine = _Eng()
+
+        def train(self):
+            pass
+
+    class _Lit:
+        model = _Model()
+
+        def training_step(self, batch, i):
+            return torch.zeros((), requires_grad=True)
+
+    t.optimizer, t.scheduler, t.sync, t.stream_optimizer = _Opt(), type("S", (), {"step": lambda self: None})(), _Sync(), False
+    n = 10                                                              # 10 batches, windows of 4: two full windows + a tail of 2
+    for i in range(n):
+        t.train_step(_Lit(), {}, i, end_of_epoch=(i == n - 1))
+    assert t.optimizer.steps == 3 and t.global_step == 3
+
+
+def test_collator_rejects_prompts_without_exactly_one_mask():
+    import pytest
+    import torch
+    from mkg_analogy_amd.data.data_module import DataCollatorForSeq2Seq
+
+    class _Tok:
+        mask_token_id = 103
+
+        def pad(self, feats, **kw):
+            return {k: torch.tensor([f[k] for f in feats]) for k in feats[0]}
+
+    col = DataCollatorForSeq2Seq(_Tok(), num_labels=10)
+    ok = [dict(input_ids=[101, 5, 103, 102], attention_mask=[1] * 4, token_type_ids=[0] * 4, label=3)]
+    assert col(ok)["label"].tolist() == [3]
+    with pytest.raises(ValueError):
+        col([dict(input_ids=[101, 5, 6, 102], attention_mask=[1] * 4, token_type_ids=[0] * 4, label=3)])      # [MASK] truncated away
+    with pytest.raises(ValueError):
+        col([dict(input_ids=[101, 103, 103, 102], attention_mask=[1] * 4, token_type_ids=[0] * 4, label=3)])
+    with pytest.raises(ValueError):
+        col([dict(input_ids=[101, 5, 103, 102], attention_mask=[1] * 4, token_type_ids=[0] * 4, label=-100)])  # ignore_index unsupported
