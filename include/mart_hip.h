@@ -76,8 +76,12 @@ typedef struct {
   int batch; long long stride_x, stride_y, stride_o;
   int splits;                                                     /* 0 auto */
   float alpha;
+  void* workspace; long long workspace_bytes;                     /* optional, caller-owned (mart_gemm_tn_workspace_bytes): when given (and batch <= 1,
+                                                                     M % 64 == 0) the split reduction is DETERMINISTIC -- partial tiles go to the workspace and
+                                                                     an ordered second kernel adds them into out / colsum; without it: f32 atomics */
 } mart_gemm_tn_desc;
 int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream);
+long long mart_gemm_tn_workspace_bytes(int M, int NX, int NY, int splits);
 
 /* ---------------------------------------------------------------- layer norm family
  * s = x_f32 (+ dropout(y_bf16, p)) ; out = LN(s) * gamma + beta.  nn.LayerNorm call sites
@@ -105,6 +109,8 @@ typedef struct {
   float p_drop; uint64_t seed;
   float* dgamma; float* dbeta;
   int bf16_total;                                                  /* 1: ds_bf16 = bf16(ds + add_f32) (no dropout mask) */
+  float* ws; long long ws_bytes;                                   /* optional caller-owned workspace (768 * 2 * H floats suffice): per-workgroup dgamma / dbeta
+                                                                      partials, added in workgroup order by a second kernel (deterministic); NULL: f32 atomics */
 } mart_ln_bwd_desc;
 int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream);
 

@@ -30,7 +30,8 @@ class GemmNT(C.Structure):
 class GemmTN(C.Structure):
     _fields_ = [("X", vp), ("Y", vp), ("ldx", i32), ("ldy", i32), ("M", i32), ("NX", i32), ("NY", i32),
                 ("out", vp), ("ldo", i32), ("out_rows", vp), ("colsum", vp), ("colsum_by_row", i32),
-                ("batch", i32), ("stride_x", i64), ("stride_y", i64), ("stride_o", i64), ("splits", i32), ("alpha", f32)]
+                ("batch", i32), ("stride_x", i64), ("stride_y", i64), ("stride_o", i64), ("splits", i32), ("alpha", f32),
+                ("workspace", vp), ("workspace_bytes", i64)]
 
 
 class LnFwd(C.Structure):
@@ -41,7 +42,7 @@ class LnFwd(C.Structure):
 class LnBwd(C.Structure):
     _fields_ = [("dy_f32", vp), ("dy_bf16", vp), ("s", vp), ("mean", vp), ("rstd", vp), ("gamma", vp), ("add_f32", vp),
                 ("M", i32), ("H", i32), ("ds_f32", vp), ("ds_bf16", vp), ("p_drop", f32), ("seed", u64),
-                ("dgamma", vp), ("dbeta", vp), ("bf16_total", i32)]
+                ("dgamma", vp), ("dbeta", vp), ("bf16_total", i32), ("ws", vp), ("ws_bytes", i64)]
 
 
 class TextEmbed(C.Structure):
@@ -84,6 +85,7 @@ _SIGS = {
     "mart_check_device": (i32, []),
     "mart_gemm_nt": (i32, [C.POINTER(GemmNT), vp]),
     "mart_gemm_tn": (i32, [C.POINTER(GemmTN), vp]),
+    "mart_gemm_tn_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "mart_ln_fwd": (i32, [C.POINTER(LnFwd), vp]),
     "mart_ln_bwd": (i32, [C.POINTER(LnBwd), vp]),
     "mart_patchify": (i32, [vp, vp, i32, i32, i32, vp]),

@@ -7,6 +7,7 @@
 // The contraction (M) is split across workgroups; partial tiles are combined with f32 atomics.
 // Optional fused column sums of X (bias gradients): VALU sums of the fragments the MFMAs consume anyway.
 #include "common.h"
+#include <type_traits>
 #include "mart_hip.h"
 
 namespace {
@@ -179,6 +180,257 @@ __global__ __launch_bounds__(NT) void gemm_tn_kernel(Args p) {
   }
 }
 
+// ============================================================================================================================
+// Deterministic variant: 8-phase K loop + two-stage split reduction (no atomics on the output).
+//   * K loop: the structure of gemm_nt's 8-phase loop (gemm_nt.hip) on transposed fragment reads.  A 64-row contraction step is
+//     staged as FOUR half-tiles of 16 KB -- X columns 0..127 (Xl), 128..255 (Xr), Y columns 0..127 (Yl), 128..255 (Yr) --
+//     each [64 m][256 B] with the 16-byte-chunk swizzle chunk ^ ((m & 3) << 2) (the four rows of a transposed 4x16 read land in
+//     four different 64-byte bank groups); two steps fit the 128 KB ring.  Four phases per step, each = [ transposed fragment
+//     reads (+ ONE half-tile of LDS-DMA) | s_barrier | 8 MFMAs | s_barrier ], the two wave-rows one barrier apart.  Wave-row wr
+//     owns the X columns {ih*128 + wr*64 + [0,64)}: Xl is dead after phase 1, Yl/Yr after phase 2, Xr after phase 3, so the
+//     half-tiles of step t+2 are issued while step t computes, behind ONE counted s_waitcnt vmcnt(6) per step.
+//   * split reduction: every (tile, split) workgroup writes its 256x256 f32 partial to a workspace slab in FRAGMENT-MAJOR order
+//     (16 bytes per lane, 1 KB per store instruction); tn_reduce_k sums the slabs of a tile in split order and adds the result
+//     into the output (and the column sums into the bias gradient): run-to-run identical gradients, no contended atomics.
+constexpr int HALF_BYTES = 64 * 256;               // one half-tile
+constexpr int SLAB = 256 * 256;                    // floats per (tile, split) partial
+
+struct Args2 {
+  const bf16* X; const bf16* Y; int ldx, ldy;
+  int M, NX, NY;
+  float* out; int ldo; const int* out_rows;
+  float* colsum; int colsum_by_row;
+  int splits, rows_per_split, tiles_y, ntile;
+  float alpha;
+  float* ws;                                       // [split][tile][SLAB] partial tiles, then [split][tiles_x][256] column sums
+  float* ws_col;
+};
+
+__global__ __launch_bounds__(NT) void gemm_tn8_kernel(Args2 p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31, g1 = (lane >> 4) & 1, pp = lane & 15;
+  const int wr = wave >> 2, wq = wave & 3;
+  const int ntile = p.ntile;
+  const int lid = xcd_remap((int)(blockIdx.x + ntile * blockIdx.y), (int)(ntile * gridDim.y));
+  const int tile = lid % ntile, split = lid / ntile;
+  const int tx = tile / p.tiles_y, ty = tile % p.tiles_y;
+  const int nx0 = tx * BNX, ny0 = ty * BNY;
+  const int ms = split * p.rows_per_split;
+  const int me = min(p.M, ms + p.rows_per_split);
+  const int nsteps = (me - ms) / BKM;                // host guarantees whole steps (M % 64 == 0) and >= 1 step per split
+
+  // staging: a half-tile = 1024 chunks of 16 B, two per thread: chunk c -> row c>>4, physical chunk c&15,
+  // logical chunk = physical ^ ((row & 3) << 2)
+  long long srcX[2][2], srcY[2][2];                  // [half][r]: element offset of this thread's chunk at contraction row 0
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int c = r * NT + tid, row = c >> 4, pc = c & 15, lc = pc ^ ((row & 3) << 2);
+      srcX[hf][r] = (long long)row * p.ldx + min(nx0 + hf * 128 + lc * 8, p.ldx - 8);
+      srcY[hf][r] = (long long)row * p.ldy + min(ny0 + hf * 128 + lc * 8, p.ldy - 8);
+    }
+  auto issueX = [&](int t, auto HALF) {
+    constexpr int hf = decltype(HALF)::value;
+    const bf16* base = p.X + (long long)(ms + t * BKM) * p.ldx;
+    char* dst = smem + (t & 1) * STAGE + hf * HALF_BYTES;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) glds16_raw(base + srcX[hf][r], dst + (r * NT + wave * 64) * 16);
+  };
+  auto issueY = [&](int t, auto HALF) {
+    constexpr int hf = decltype(HALF)::value;
+    const bf16* base = p.Y + (long long)(ms + t * BKM) * p.ldy;
+    char* dst = smem + (t & 1) * STAGE + X_BYTES + hf * HALF_BYTES;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) glds16_raw(base + srcY[hf][r], dst + (r * NT + wave * 64) * 16);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = p.colsum && ty == 0;
+
+  // transposed fragment of a half-tile: 32 columns starting at col0 (inside the half), contraction rows 16a + 8h + {0..7}
+  const int prow = pp >> 2, key = prow << 2;
+  auto frag = [&](const char* half, int col0, int a) -> bf16x8 {
+    const int col = col0 + g1 * 16 + (pp & 3) * 4;
+    const int boff = (((col >> 3) ^ key) << 4) + (col & 7) * 2;
+    const int r0 = a * 16 + 8 * h + prow;
+    s16x4 lo = lds_tr_read(half + r0 * 256 + boff);
+    s16x4 hi = lds_tr_read(half + (r0 + 4) * 256 + boff);
+    return join_tr(lo, hi);
+  };
+  bf16x8 xf[2][4], yf[2][4];                         // X fragments [block of the pair][k-step], Y fragments [j][k-step]
+  auto readX = [&](const char* st, auto IH) {
+    constexpr int ih = decltype(IH)::value;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xf[ii][a] = frag(st + ih * HALF_BYTES, wr * 64 + ii * 32, a);
+  };
+  auto readY = [&](const char* st, auto J) {
+    constexpr int j = decltype(J)::value;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) yf[j][a] = frag(st + X_BYTES + (wq >> 1) * HALF_BYTES, (wq & 1) * 64 + j * 32, a);
+  };
+  auto colsum_step = [&](auto IH) {                   // k-step a == wave column: VALU sums of fragments the MFMAs consume anyway
+    constexpr int ih = decltype(IH)::value;
+    if (do_colsum) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        if (wq == a) {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {
+            const u32x4 w = __builtin_bit_cast(u32x4, xf[ii][a]);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s0 += __builtin_bit_cast(float, w[e] << 16);
+              s1 += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+            }
+            cs[2 * ih + ii] += s0 + s1;
+          }
+        }
+    }
+  };
+  auto mma = [&](auto IH, auto J) {
+    constexpr int ih = decltype(IH)::value, j = decltype(J)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) acc[2 * ih + ii][j] = mfma32(xf[ii][a], yf[j][a], acc[2 * ih + ii][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto lgkm0 = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // prologue: step 0 complete, three half-tiles of step 1 in flight
+  issueX(0, I0{}); issueY(0, I0{}); issueY(0, I1{}); issueX(0, I1{});
+  if (nsteps > 1) {
+    issueX(1, I0{}); issueY(1, I0{}); issueY(1, I1{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  bar();
+  if (wr == 1) bar();                                 // the lower wave-row runs one barrier behind
+  for (int t = 0; t < nsteps; ++t) {
+    const char* st = smem + (t & 1) * STAGE;
+    const bool more1 = t + 1 < nsteps, more2 = t + 2 < nsteps;
+    // P1
+    readX(st, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    readY(st, I0{});
+    if (more1) issueX(t + 1, I1{});
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); // the 16 X reads (issued first) are retired: Xl may be re-staged in P2
+    bar();
+    lgkm0();
+    mma(I0{}, I0{});
+    colsum_step(I0{});
+    bar();
+    // P2
+    readY(st, I1{});
+    if (more2) issueX(t + 2, I0{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // all Y reads retired: Yl / Yr may be re-staged in P3 / P4
+    bar();
+    mma(I0{}, I1{});
+    bar();
+    // P3
+    readX(st, I1{});
+    if (more2) issueY(t + 2, I0{});
+    bar();
+    lgkm0();
+    mma(I1{}, I1{});
+    colsum_step(I1{});
+    bar();
+    // P4
+    if (more2) {
+      issueY(t + 2, I1{});
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); // everything but the three half-tiles of step t+2: step t+1 has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    mma(I1{}, I0{});
+    bar();
+  }
+  if (wr == 0) bar();                                 // balance the barrier count
+
+  // ---- partial tile -> workspace slab, fragment-major: ((((wave*4 + i)*2 + j)*4 + q)*64 + lane)*4 + e  <->  acc[i][j][4q + e]
+  float* slab = p.ws + ((long long)split * ntile + tile) * SLAB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(slab + ((((wave * 4 + i) * 2 + j) * 4 + q) * 64 + lane) * 4) =
+            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+  if (do_colsum) {                                   // workgroup-uniform
+    __syncthreads();                                 // K-loop buffers are free
+    float* red = (float*)smem;                       // [4 wave columns][256 nx]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float tot = cs[i] + __shfl_xor(cs[i], 32);
+      if (h == 0) red[wq * BNX + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + l31] = tot;
+    }
+    __syncthreads();
+    if (tid < BNX) p.ws_col[((long long)split * (ntile / p.tiles_y) + tx) * BNX + tid] = red[tid] + red[BNX + tid] + red[2 * BNX + tid] + red[3 * BNX + tid];
+  }
+}
+
+// out[nx][ny] += alpha * sum_{split} slab[split][tile](nx, ny), splits in order; colsum likewise.  One thread = one register quad
+// of one fragment (4 consecutive nx at one ny); the 32 lanes of a half-wave cover 32 consecutive ny (128-byte segments).
+__global__ __launch_bounds__(256) void tn_reduce_k(Args2 p) {
+  const int ntile = p.ntile, tiles_x = ntile / p.tiles_y;
+  const int nblk_tiles = ntile * (SLAB / 4 / 256);
+  if ((int)blockIdx.x >= nblk_tiles) {               // bias-gradient part: one thread per nx
+    const int idx = ((int)blockIdx.x - nblk_tiles) * 256 + threadIdx.x;
+    if (!p.colsum || idx >= tiles_x * BNX) return;
+    const int tx = idx / BNX, nx = tx * BNX + (idx % BNX);
+    if (nx >= p.NX) return;
+    float tot = 0.f;
+    for (int s = 0; s < p.splits; ++s) tot += p.ws_col[((long long)s * tiles_x + tx) * BNX + (idx % BNX)];
+    float* dst = p.colsum + (p.colsum_by_row ? (long long)p.out_rows[nx] : (long long)nx);
+    *dst += tot * p.alpha;
+    return;
+  }
+  const int g = blockIdx.x * 256 + threadIdx.x;      // quad index over all tiles
+  const int tile = g / (SLAB / 4), qi = g % (SLAB / 4);
+  const int lane = qi & 63, q = (qi >> 6) & 3, j = (qi >> 8) & 1, i = (qi >> 9) & 3, wave = qi >> 11;
+  const int h = lane >> 5, l31 = lane & 31, wr = wave >> 2, wq = wave & 3;
+  f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+  const float* src = p.ws + (long long)tile * SLAB + (long long)qi * 4;
+  for (int s = 0; s < p.splits; ++s) tot += *(const f32x4*)(src + (long long)s * ntile * SLAB);
+  const int tx = tile / p.tiles_y, ty = tile % p.tiles_y;
+  const int ny = ty * BNY + wq * 64 + j * 32 + l31;
+  const int nxb = tx * BNX + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + 8 * q + 4 * h;
+  if (ny >= p.NY) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int nx = nxb + e;
+    if (nx < p.NX) {
+      const long long orow = p.out_rows ? p.out_rows[nx] : nx;
+      float* dst = p.out + orow * p.ldo + ny;
+      *dst += tot[e] * p.alpha;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
@@ -218,7 +470,48 @@ extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
   rps = ((rps + BKM - 1) / BKM) * BKM;
   splits = (d->M + rps - 1) / rps;
   a.splits = splits; a.rows_per_split = rps;
+  if (d->workspace && batch == 1 && d->M % BKM == 0) {
+    // deterministic path: 8-phase loop, partial tiles to the caller's workspace, ordered reduction kernel
+    const int tiles_x = (d->NX + BNX - 1) / BNX, tiles_y = (d->NY + BNY - 1) / BNY;
+    const size_t need = ((size_t)splits * tiles * SLAB + (size_t)splits * tiles_x * BNX) * sizeof(float);
+    MART_CHECK(d->workspace_bytes >= need, "gemm_tn: workspace too small (mart_gemm_tn_workspace_bytes)");
+    MART_CHECK(((uintptr_t)d->workspace & 15) == 0, "gemm_tn: workspace must be 16-byte aligned");
+    static MartAttrOnce once8;
+    bool* set8 = once8.slot();
+    if (!*set8) {
+      if (hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        mart_set_error("gemm_tn: hipFuncSetAttribute failed");
+        return -2;
+      }
+      *set8 = true;
+    }
+    Args2 b;
+    b.X = a.X; b.Y = a.Y; b.ldx = a.ldx; b.ldy = a.ldy; b.M = a.M; b.NX = a.NX; b.NY = a.NY; b.out = a.out; b.ldo = a.ldo;
+    b.out_rows = a.out_rows; b.colsum = a.colsum; b.colsum_by_row = a.colsum_by_row; b.splits = splits; b.rows_per_split = rps;
+    b.tiles_y = tiles_y; b.ntile = tiles; b.alpha = a.alpha;
+    b.ws = (float*)d->workspace; b.ws_col = b.ws + (size_t)splits * tiles * SLAB;
+    hipLaunchKernelGGL(gemm_tn8_kernel, dim3(tiles, splits, 1), dim3(NT), LDS, (hipStream_t)stream, b);
+    MART_LAUNCH_CHECK();
+    const int nblk = tiles * (SLAB / 4 / 256) + (d->colsum ? (tiles_x * BNX + 255) / 256 : 0);
+    hipLaunchKernelGGL(tn_reduce_k, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b);
+    MART_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits, batch), dim3(NT), LDS, (hipStream_t)stream, a);
   MART_LAUNCH_CHECK();
   return 0;
+}
+
+/* bytes of workspace the deterministic path of mart_gemm_tn needs for this problem (same split rule as the launcher) */
+extern "C" long long mart_gemm_tn_workspace_bytes(int M, int NX, int NY, int splits_req) {
+  const int tiles_x = (NX + BNX - 1) / BNX, tiles = tiles_x * ((NY + BNY - 1) / BNY);
+  int splits = splits_req;
+  const int max_splits = (M + 4 * BKM - 1) / (4 * BKM);
+  if (splits <= 0) splits = 256 / tiles;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rps = (M + splits - 1) / splits;
+  rps = ((rps + BKM - 1) / BKM) * BKM;
+  splits = (M + rps - 1) / rps;
+  return (long long)(((size_t)splits * tiles * SLAB + (size_t)splits * tiles_x * BNX) * sizeof(float));
 }

@@ -153,9 +153,25 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int ww = 0; ww < WPB; ++ww) { a += red[ww][0][c]; b += red[ww][1][c]; }
-    if (p.dgamma) atomicAdd(p.dgamma + c, a);
-    if (p.dbeta) atomicAdd(p.dbeta + c, b);
+    if (p.ws) {                                     // deterministic: this workgroup's partial row, summed in workgroup order by ln_dgb_reduce_k
+      p.ws[((long long)blockIdx.x * 2 + 0) * p.H + c] = a;
+      p.ws[((long long)blockIdx.x * 2 + 1) * p.H + c] = b;
+    } else {
+      if (p.dgamma) atomicAdd(p.dgamma + c, a);
+      if (p.dbeta) atomicAdd(p.dbeta + c, b);
+    }
   }
+}
+
+// dgamma[c] += sum_g ws[g][0][c], dbeta[c] += sum_g ws[g][1][c], workgroups in index order (run-to-run identical)
+__global__ __launch_bounds__(256) void ln_dgb_reduce_k(const float* __restrict__ ws, int nwg, int H, float* dgamma, float* dbeta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * H) return;
+  float* dst = i < H ? dgamma : dbeta;
+  if (!dst) return;
+  float tot = 0.f;
+  for (int g = 0; g < nwg; ++g) tot += ws[(long long)g * 2 * H + i];
+  dst[i < H ? i : i - H] += tot;
 }
 
 // ------------------------------------------------------------------ text embeddings (gather + LN + dropout)
@@ -455,9 +471,14 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   // grid = 3 per CU in ONE round measured best (768: 257 us; 1536: 262 us; 2048, i.e. 1.33 rounds: 288 us at M = 100608)
   static int cap = getenv("MART_LN_BWD_GRID") ? atoi(getenv("MART_LN_BWD_GRID")) : 768;
   if (g > cap) g = cap;
+  MART_CHECK(!d->ws || d->ws_bytes >= (long long)g * 2 * d->H * (long long)sizeof(float), "ln_bwd: workspace too small (768 * 2 * H floats always suffice)");
   if (d->H <= 768) hipLaunchKernelGGL(ln_bwd_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(ln_bwd_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
+  if (d->ws && (d->dgamma || d->dbeta)) {
+    hipLaunchKernelGGL(ln_dgb_reduce_k, dim3((2 * d->H + 255) / 256), dim3(256), 0, (hipStream_t)stream, d->ws, g, d->H, d->dgamma, d->dbeta);
+    MART_LAUNCH_CHECK();
+  }
   return 0;
 }
 extern "C" int mart_text_embed_fwd(const mart_text_embed_desc* d, void* stream) {

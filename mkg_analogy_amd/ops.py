@@ -6,6 +6,7 @@ device memory only.  bf16 tensors are torch.bfloat16; index tensors for gathers 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -67,9 +68,14 @@ def gemm_nt(A, B, out, *, A2=None, B2=None, a_rows=None, b_rows=None, M=None, N=
     return out
 
 
+TN_DETERMINISTIC = os.environ.get("MART_DETERMINISTIC", "1") == "1"   # ordered (atomic-free) split reductions of gemm_tn and ln_bwd; 0 = f32 atomics
+
+
 def gemm_tn(X, Y, out, *, M=None, NX=None, NY=None, out_rows=None, colsum=None, colsum_by_row=False, batch=1,
-            stride_x=0, stride_y=0, stride_o=0, splits=0, alpha=1.0):
-    """out[NX,NY] (f32) += X[M,NX]^T @ Y[M,NY]; colsum[NX] += column sums of X."""
+            stride_x=0, stride_y=0, stride_o=0, splits=0, alpha=1.0, deterministic=None):
+    """out[NX,NY] (f32) += X[M,NX]^T @ Y[M,NY]; colsum[NX] += column sums of X.
+    Deterministic by default (batch 1, M % 64 == 0): the split-M partial tiles go through a workspace (allocated here from
+    torch's caching allocator on the current stream) and are added in split order; otherwise f32 atomics."""
     d = L.GemmTN()
     d.X, d.Y, d.ldx, d.ldy = _p(X), _p(Y), _rows2d(X), _rows2d(Y)
     d.M = M if M is not None else X.shape[-2]
@@ -79,6 +85,12 @@ def gemm_tn(X, Y, out, *, M=None, NX=None, NY=None, out_rows=None, colsum=None, 
     d.colsum, d.colsum_by_row = _p(colsum), int(colsum_by_row)
     d.batch, d.stride_x, d.stride_y, d.stride_o = batch, stride_x, stride_y, stride_o
     d.splits, d.alpha = splits, alpha
+    det = TN_DETERMINISTIC if deterministic is None else deterministic
+    ws = None
+    if det and batch == 1 and d.M % 64 == 0:
+        nb = int(L.lib().mart_gemm_tn_workspace_bytes(d.M, d.NX, d.NY, splits))
+        ws = torch.empty(nb // 4, device=X.device, dtype=F32)
+        d.workspace, d.workspace_bytes = _p(ws), nb
     L.check(L.lib().mart_gemm_tn(C.byref(d), _stream()), "mart_gemm_tn")
     return out
 
@@ -99,6 +111,10 @@ def ln_bwd(*, dy_f32=None, dy_bf16=None, s, mean, rstd, gamma, M, H, add_f32=Non
     d.add_f32, d.M, d.H, d.ds_f32, d.ds_bf16 = _p(add_f32), M, H, _p(ds_f32), _p(ds_bf16)
     d.p_drop, d.seed, d.dgamma, d.dbeta = p_drop, seed, _p(dgamma), _p(dbeta)
     d.bf16_total = int(bf16_total)
+    ws = None
+    if TN_DETERMINISTIC and (dgamma is not None or dbeta is not None):     # ordered reduction of the per-workgroup dgamma / dbeta partials
+        ws = torch.empty(768 * 2 * H, device=s.device, dtype=F32)
+        d.ws, d.ws_bytes = _p(ws), ws.numel() * 4
     L.check(L.lib().mart_ln_bwd(C.byref(d), _stream()), "mart_ln_bwd")
 
 

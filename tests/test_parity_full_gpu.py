@@ -114,18 +114,26 @@ def _grad_report(st, g, tol_rel, tol_cos, tol_norm, skip=(), ctl_mult=0.0):
         worst_n = max(worst_n, r)
         if r > lim:
             bad.append(("norm", n, got, ref, lim))
-    for k in [k for k in g if k.startswith("gs::")]:
+    keys = [k for k in g if k.startswith("gs::") and np.linalg.norm(g[k]) >= 1e-7 and k[4:] not in skip]
+    # the control displaces different tensors by very different amounts (chaotic regime: 0.04 ... 2.0 on the same batch), so a
+    # tensor is held to the larger of its own and the median control displacement
+    med_c = float(np.median([_rel(g["ctl::" + k], g[k]) for k in keys])) if ctl_mult else 0.0
+    rels = []
+    for k in keys:
         n = k[4:]
         ref = g[k]
-        if np.linalg.norm(ref) < 1e-7 or n in skip:
-            continue
         got = _sample(st.g(n))
         r, c = _rel(got, ref), _cos(got, ref)
-        rc = _rel(g["ctl::" + k], ref) if ctl_mult else 0.0
+        rc = max(_rel(g["ctl::" + k], ref), med_c) if ctl_mult else 0.0
         worst_s = max(worst_s, r)
-        print(f"   grad sample {n}: rel-L2 {r:.3e} cos {c:.5f}" + (f"   (control {rc:.3e})" if ctl_mult else ""))
+        rels.append(r)
+        print(f"   grad sample {n}: rel-L2 {r:.3e} cos {c:.5f}" + (f"   (control {_rel(g['ctl::' + k], ref):.3e})" if ctl_mult else ""))
         if r > tol_rel + ctl_mult * rc or (not ctl_mult and c < tol_cos):
             bad.append(("sample", n, r, c, rc))
+    if ctl_mult:
+        print(f"   median gradient displacement: HIP bf16 path {float(np.median(rels)):.3e}, control (reference, bf16-rounded weights) {med_c:.3e}")
+        if float(np.median(rels)) > med_c + tol_rel:             # as a whole no further from the reference than its own one-rounding control
+            bad.append(("median", float(np.median(rels)), med_c))
     for n in g["none_grad"].tolist():                       # tensors the reference never touches stay at zero
         if n in st.slots and not n.endswith("decoder.weight"):
             assert float(st.g(n).abs().max()) == 0.0, n
