@@ -53,7 +53,8 @@ def data_config(seed: int = 1234) -> Dict[str, object]:
                 relation_id_ed=BASE_VOCAB + N_ENT + N_REL, analogy_entity_ids=ent.tolist(), analogy_relation_ids=rel.tolist())
 
 
-def make_batch(B: int, L: int, image_size: int = 224, seed: int = 1234, device="cpu", pretrain: bool = False) -> Dict[str, torch.Tensor]:
+def make_batch(B: int, L: int, image_size: int = 224, seed: int = 1234, device="cpu", pretrain: bool = False,
+               n_labels: int = N_ANALOGY) -> Dict[str, torch.Tensor]:
     rng = np.random.default_rng(seed)
     ids = np.zeros((B, L), np.int64)
     am = np.zeros((B, L), np.int64)
@@ -81,7 +82,7 @@ def make_batch(B: int, L: int, image_size: int = 224, seed: int = 1234, device="
     drop = torch.from_numpy(rng.random(B) < 0.4)
     pix[drop, 1] = 0.0
     out = dict(input_ids=ids, attention_mask=am, token_type_ids=tt, sep_idx=sep, rel_idx=rel, q_head_idx=qh, a_head_idx=ah,
-               label=rng.integers(0, N_ANALOGY, size=B), rel_label=rng.integers(0, 27, size=B))
+               label=rng.integers(0, n_labels, size=B), rel_label=rng.integers(0, 27, size=B))
     out = {k: torch.from_numpy(np.asarray(v)) for k, v in out.items()}
     out["pixel_values"] = pix
     if pretrain:
