@@ -89,7 +89,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     // epilogue at the same instant -- a 33 MB write burst that the memory side absorbs at ~4.4 TB/s while every
     // matrix core idles.  Starting eighths of the CUs an eighth of a tile period apart spreads the bursts.
     const long long t0 = wall_clock64();
-    const long long d = (long long)((blockIdx.x >> 3) & 7) * p.stagger_ticks;
+    // phase group: tiles that share an A panel (tiles_n consecutive logical ids of one XCD) start together, so that the second and
+    // third reader of the panel still find it in L2
+    const int tn_ = (p.N + BN - 1) / BN;
+    const long long d = (long long)((((int)blockIdx.x >> 3) / tn_) & 7) * p.stagger_ticks;
     while (wall_clock64() - t0 < d) __builtin_amdgcn_s_sleep(32);
   }
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -247,13 +250,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     //   A0 and its ih1 rows in A1, so A0 is dead after P1, B0/B1 after P2, A1 after P3, and the half-tiles of K-tile t+2 are
     //   issued into the buffer of K-tile t while t is still being computed:
     //        P1(t): A1(t+1)      P2(t): A0(t+2)      P3(t): B0(t+2)      P4(t): B1(t+2), then s_waitcnt vmcnt(6)
+    //   (each issued from inside the phase's MFMA cluster, see mma())
     //   i.e. ONE counted wait per K-tile that leaves the three newest half-tiles (48 KB per CU) in flight across the
     //   barriers and never drains the queue; every half-tile has at least three phases to land.
-    //   RAW: the wait sits before P4's first barrier; K-tile t+1 is first read in P1(t+1), behind P4's second barrier, which
-    //        every wave of the other (one barrier apart) wave-row reaches only after its own wait.
-    //   WAR: a half-tile is re-staged one phase after its last read, and those reads are retired by an lgkmcnt wait BEFORE the
-    //        reading phase's first barrier (P1: lgkmcnt(4) = the 8 A reads, issued first; P2: lgkmcnt(0)); A1 is re-staged
-    //        two phases after P3.
+    //   RAW: the wait sits at the end of P4's MFMA cluster, before P4's second barrier; K-tile t+1 is first read in P1(t+1), and a
+    //        wave of the other (one barrier apart) wave-row starts those reads only behind a barrier that every wave passed
+    //        after its own wait.
+    //   WAR: a half-tile is re-staged from the MFMA cluster of the phase AFTER its last read: every reader has retired those reads
+    //        (lgkmcnt(0) behind the reading phase's first barrier) at least one barrier before any wave reaches that cluster.
     static_assert(BM == 256 && BN == 256 && WAVES_M == 2 && WAVES_N == 4, "the 8-phase loop is laid out for 256x256 tiles, 2x4 waves");
     const int grp = wave >> 2;
     int keyA[TM], keyB[TN];
@@ -262,22 +266,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
     for (int j = 0; j < TN; ++j) keyB[j] = h ^ ((rowB[j] >> 1) & 7);
     bf16x8 af[2][4], bfr[2][4];                            // A fragments [block of the pair][k-step], B fragments [j][k-step]
-    auto issueA = [&](int t, auto HALF) {
-      constexpr int hf = decltype(HALF)::value;
-      const bf16* Ap = A; int k0 = t * BK;
-      if (t >= nk1) { Ap = A2; k0 = (t - nk1) * BK; }
-      char* sA = smem + (t & 1) * STAGE;
-#pragma unroll
-      for (int r = 2 * hf; r < 2 * hf + 2; ++r) glds16(Ap + offA[r] + k0, sA + (r * NT + wave * 64) * 16);
-    };
-    auto issueB = [&](int t, auto HALF) {
-      constexpr int hf = decltype(HALF)::value;
+    // operand pointers of a K-tile (dual-K switch, tile-blocked weights) are resolved ONCE per loop iteration on the scalar unit and
+    // handed to the issue lambdas: computed inside every issue they were ~20 SALU instructions per phase in the DMA-issuing wave
+    auto tileA = [&](int t) -> const bf16* { return t >= nk1 ? A2 + (t - nk1) * BK : A + t * BK; };
+    auto tileB = [&](int t) -> const bf16* {
       const bf16* Bp = B + blkB1; int k0 = t * BK;
       if (t >= nk1) { Bp = B2 + blkB2; k0 = (t - nk1) * BK; }
-      const long long kb = p.b_blocked ? (long long)(k0 >> 6) * 16384 : k0;
+      return Bp + (p.b_blocked ? (long long)(k0 >> 6) * 16384 : (long long)k0);
+    };
+    auto issueA = [&](const bf16* Ap, int t, auto HALF) {
+      constexpr int hf = decltype(HALF)::value;
+      char* sA = smem + (t & 1) * STAGE;
+#pragma unroll
+      for (int r = 2 * hf; r < 2 * hf + 2; ++r) glds16(Ap + offA[r], sA + (r * NT + wave * 64) * 16);
+    };
+    auto issueB = [&](const bf16* Bp, int t, auto HALF) {
+      constexpr int hf = decltype(HALF)::value;
       char* sB = smem + (t & 1) * STAGE + A_BYTES;
 #pragma unroll
-      for (int r = 2 * hf; r < 2 * hf + 2; ++r) glds16(Bp + offB[r] + kb, sB + (r * NT + wave * 64) * 16);
+      for (int r = 2 * hf; r < 2 * hf + 2; ++r) glds16(Bp + offB[r], sB + (r * NT + wave * 64) * 16);
     };
     auto readA = [&](const char* sA_, auto IH) {
       constexpr int ih = decltype(IH)::value;
@@ -292,11 +299,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) bfr[j][ks] = *(const bf16x8*)(sB_ + rowB[j] * 128 + (((ks * 2) ^ keyB[j]) << 4));
     };
-    auto mma = [&](auto IH, auto J) {
+    // the phase's half-tile of LDS-DMA is issued from INSIDE the MFMA cluster (after the first two MFMAs): next to matrix
+    // instructions a DMA piece costs the wave ~60 cycles of issue, inside the fragment-read interval (LDS queue busy) 100-185
+    auto mma = [&](auto IH, auto J, auto&& dma) {
       constexpr int ih = decltype(IH)::value, j = decltype(J)::value;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ii = 0; ii < 2; ++ii) acc[2 * ih + ii][j] = mfma32(bfr[j][0], af[ii][0], acc[2 * ih + ii][j]);
+      __builtin_amdgcn_sched_barrier(0);
+      dma();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks)
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) acc[2 * ih + ii][j] = mfma32(bfr[j][ks], af[ii][ks], acc[2 * ih + ii][j]);
       __builtin_amdgcn_s_setprio(0);
@@ -313,16 +327,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight
-    if (!have0) { issueA(0, I0{}); issueB(0, I0{}); issueB(0, I1{}); issueA(0, I1{}); }
+    if (!have0) { issueA(tileA(0), 0, I0{}); issueB(tileB(0), 0, I0{}); issueB(tileB(0), 0, I1{}); issueA(tileA(0), 0, I1{}); }
     else bar();                                            // persistent loop: the epilogue staging region overlaps buffer 1
     if (nk > 1 && !(p.dbg & 1)) {
-      issueA(1, I0{}); issueB(1, I0{}); issueB(1, I1{});
+      issueA(tileA(1), 1, I0{}); issueB(tileB(1), 1, I0{}); issueB(tileB(1), 1, I1{});
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     bar();
     if (grp == 1) bar();                                   // the lower wave-row runs one barrier behind
+    const bf16* A_t1 = tileA(min(1, nk - 1));              // operands of the K-tiles the coming iteration will issue; refreshed in P4,
+    const bf16* A_t2 = tileA(min(2, nk - 1));              // the phase without fragment reads
+    const bf16* B_t2 = tileB(min(2, nk - 1));
     for (int t = 0; t < nk; ++t) {
       const char* sA = smem + (t & 1) * STAGE;
       const char* sB = sA + A_BYTES;
@@ -331,35 +348,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       readA(sA, I0{});
       __builtin_amdgcn_sched_barrier(0);
       readB(sB, I0{});
-      if (more1) issueA(t + 1, I1{});
-      asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // the 8 A reads (issued first) are retired: A0 may be re-staged in P2
       bar();
       lgkm0();
-      mma(I0{}, I0{});
+      mma(I0{}, I0{}, [&] { if (more1) issueA(A_t1, t + 1, I1{}); });
       bar();
       // P2
       readB(sB, I1{});
-      if (more2) issueA(t + 2, I0{});
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all B reads retired: B0 / B1 may be re-staged in P3 / P4
       bar();
-      mma(I0{}, I1{});
+      lgkm0();
+      mma(I0{}, I1{}, [&] { if (more2) issueA(A_t2, t + 2, I0{}); });
       bar();
       // P3
       readA(sA, I1{});
-      if (more2) issueB(t + 2, I0{});
       bar();
       lgkm0();
-      mma(I1{}, I1{});
+      mma(I1{}, I1{}, [&] { if (more2) issueB(B_t2, t + 2, I0{}); });
       bar();
       // P4
-      if (more2) {
-        issueB(t + 2, I1{});
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // everything but the three half-tiles of K-tile t+2: K-tile t+1 has landed
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      const bf16* nA1 = tileA(min(t + 2, nk - 1));
+      const bf16* nA2 = tileA(min(t + 3, nk - 1));
+      const bf16* nB2 = tileB(min(t + 3, nk - 1));
       bar();
-      mma(I1{}, I0{});
+      mma(I1{}, I0{}, [&] { if (more2) issueB(B_t2, t + 2, I1{}); });
+      if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // everything but the three half-tiles of K-tile t+2: K-tile t+1 has landed
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      A_t1 = nA1; A_t2 = nA2; B_t2 = nB2;
       bar();
     }
     if (grp == 0) bar();                                   // balance the barrier count
@@ -854,6 +867,11 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   const bool two_acts = d->mulz && d->act != ACT_NONE;               // not a fast combination
   const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->preact_grad ? F_PGRAD : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
                    (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
+  // Start stagger for the f32-residual epilogues (out-proj, fc2: 512 KB of HBM traffic per tile against a 12-48 K-tile loop):
+  // every CU runs the same loop, so all 256 reach their epilogue together and the memory side sees a 134 MB burst per round
+  // while the matrix cores idle.  Groups of workgroups that share an A panel start 3 us apart (8 phases): +15 % on the
+  // out-proj shape, +2-3 % on fc2 (tools/nt_harness time 5 0 70300); only where there are rounds enough to pay for the delay.
+  if (d->res_f32 && d->c_f32 && cfg == 256 && a.stagger_ticks == 0 && t256 >= 4 * 256 && batch == 1) a.stagger_ticks = 300;
   if (aligned) {
     // persistent loop: +6-7 % where the epilogue is light (bf16 out); with the fp32 residual or two bf16 outputs it is
     // neutral at best (re-measured after the epilogue work: fc1 0.571 vs 0.572 ms, step +0.3 %) -> only for the light masks

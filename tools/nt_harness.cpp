@@ -10,6 +10,7 @@
 #include <vector>
 #include <algorithm>
 #include <math.h>
+#include <dlfcn.h>
 #include "mart_hip.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -164,6 +165,36 @@ int main(int argc, char** argv) {
       double m0 = ms[0][ms[0].size() / 2], m1 = ms[1][ms[1].size() / 2];
       printf("time %-40s old %.4f ms (%6.1f TF/s)   new %.4f ms (%6.1f TF/s)   x%.3f\n", c.name, m0, fl / m0 * 1e-9, m1, fl / m1 * 1e-9, m0 / m1);
     }
+  }
+  if (!strcmp(mode, "ab")) {
+    // interleaved A/B of two BUILDS of the library in one process:  nt_harness ab <rounds> <libA.so> <libB.so> [cfgA cfgB]
+    typedef int (*fn_t)(const mart_gemm_nt_desc*, void*);
+    void* ha = dlopen(argv[3], RTLD_NOW | RTLD_LOCAL); void* hb = dlopen(argv[4], RTLD_NOW | RTLD_LOCAL);
+    if (!ha || !hb) { printf("dlopen failed: %s\n", dlerror()); return 1; }
+    fn_t fns[2] = {(fn_t)dlsym(ha, "mart_gemm_nt"), (fn_t)dlsym(hb, "mart_gemm_nt")};
+    const int cfgs[2] = {argc > 5 ? atoi(argv[5]) : 0, argc > 6 ? atoi(argv[6]) : 0};
+    printf("A = %s (cfg %d)   B = %s (cfg %d)\n", argv[3], cfgs[0], argv[4], cfgs[1]);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int NIT = 12;
+    double tot[2] = {0, 0};
+    for (const Case& c : timing) {
+      std::vector<float> ms[2];
+      mart_gemm_nt_desc d;
+      for (int w = 0; w < 2; ++w) for (int k = 0; k < 2; ++k) { make_desc(d, c, b, w, 0, cfgs[k]); fns[k](&d, st); }
+      for (int r = 0; r < rounds; ++r)
+        for (int k = 0; k < 2; ++k) {
+          CK(hipEventRecord(e0, st));
+          for (int it = 0; it < NIT; ++it) { make_desc(d, c, b, it, 0, cfgs[k]); if (fns[k](&d, st)) { printf("launch failed\n"); return 1; } }
+          CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+          float t; CK(hipEventElapsedTime(&t, e0, e1)); ms[k].push_back(t / NIT);
+        }
+      double fl = 2.0 * c.M * c.N * (double)(c.K + c.K2);
+      for (int k = 0; k < 2; ++k) std::sort(ms[k].begin(), ms[k].end());
+      double m0 = ms[0][ms[0].size() / 2], m1 = ms[1][ms[1].size() / 2];
+      tot[0] += m0; tot[1] += m1;
+      printf("ab   %-40s A %.4f ms (%6.1f TF/s)   B %.4f ms (%6.1f TF/s)   A/B x%.3f\n", c.name, m0, fl / m0 * 1e-9, m1, fl / m1 * 1e-9, m0 / m1);
+    }
+    printf("ab   sum over the shapes: A %.4f ms, B %.4f ms, A/B x%.3f\n", tot[0], tot[1], tot[0] / tot[1]);
   }
   printf(bad ? "HARNESS: %d FAILED\n" : "HARNESS: all checks passed\n", bad);
   return bad ? 1 : 0;
