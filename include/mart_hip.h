@@ -76,9 +76,10 @@ typedef struct {
   int batch; long long stride_x, stride_y, stride_o;
   int splits;                                                     /* 0 auto */
   float alpha;
-  void* workspace; long long workspace_bytes;                     /* optional, caller-owned (mart_gemm_tn_workspace_bytes): when given (and batch <= 1,
-                                                                     M % 64 == 0) the split reduction is DETERMINISTIC -- partial tiles go to the workspace and
-                                                                     an ordered second kernel adds them into out / colsum; without it: f32 atomics */
+  void* workspace; long long workspace_bytes;                     /* optional, caller-owned (mart_gemm_tn_workspace_bytes): when given (and batch <= 1) the
+                                                                     split reduction is DETERMINISTIC -- partial tiles go to the workspace and an ordered second
+                                                                     kernel adds them into out / colsum (an M % 64 tail is added by one workgroup per tile);
+                                                                     without it: f32 atomics */
 } mart_gemm_tn_desc;
 int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream);
 long long mart_gemm_tn_workspace_bytes(int M, int NX, int NY, int splits);

@@ -58,7 +58,16 @@ __device__ __forceinline__ void tile_barrier() {
   __syncthreads();
 }
 
-// stage one 64x64 tile (rows r0..r0+63 of `s`) into LDS with the chunk swizzle c' = c ^ ((row>>1)&7)
+// Swizzle key of a 128-byte tile row: the 16-byte chunk index is XORed with the BIT-REVERSED pair index (row >> 1) & 7.
+// Plain fragment reads (ds_read_b128, lane = row) only need the key to be a bijection of the pair index; the transposed reads
+// (ds_read_b64_tr_b16: 4 consecutive rows x two 16-column halves per 32-lane pass) need rows r and r + 2 in different 64-byte
+// halves of the row -- with the plain key (row >> 1) & 7 they differed by ONE chunk, inside the same 32 bytes: a 2-way conflict
+// on every transposed read (SQ_LDS_BANK_CONFLICT = 25 % of the LDS cycles of the dK/dV pass in round 1).
+__device__ __forceinline__ int swz_key(int row) {
+  const int k = (row >> 1) & 7;
+  return ((k & 1) << 2) | (k & 2) | (k >> 2);
+}
+// stage one 64x64 tile (rows r0..r0+63 of `s`) into LDS with the chunk swizzle c' = c ^ swz_key(row)
 // Each thread copies chunk (row = tid>>3 [+32], lc) of both 32-row halves.  When a half lies entirely inside the prefix
 // or inside the own rows (prefix length a multiple of 32, half not cut by the end) its source is a wave-uniform row
 // pointer (scalar unit) plus ONE loop-invariant lane offset; the general form (per-lane clamp, prefix/own select and a
@@ -67,7 +76,7 @@ __device__ __forceinline__ void tile_barrier() {
 // transposed reads -- is 2 % slower; a 4-stage ring with three tiles in flight and counted waits changes nothing:
 // the loop does not wait for the DMA)
 __device__ __forceinline__ void stage_tile(const Side& s, int b, int h, int r0, char* lds, int tid, int wave) {
-  const int rowh = tid >> 3, pc = tid & 7, lc = pc ^ ((rowh >> 1) & 7);          // (row >> 1) & 7 is the same for row and row + 32
+  const int rowh = tid >> 3, pc = tid & 7, lc = pc ^ swz_key(rowh);               // the key is the same for row and row + 32
   const unsigned off_own = (unsigned)(rowh * s.ld_own + lc * 8), off_pre = (unsigned)(rowh * s.ld_pre + lc * 8);
   const int n_tot = s.n_pre + s.n_own;
 #pragma unroll
@@ -91,15 +100,15 @@ struct LaneOffs {
 __device__ __forceinline__ LaneOffs make_offs(int lane) {
   LaneOffs o;
   const int l31 = lane & 31, hh = lane >> 5, pp = lane & 15, g1 = (lane >> 4) & 1;
-  const int key = (l31 >> 1) & 7;
+  const int key = swz_key(l31);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) o.pf[ks] = l31 * 128 + (((ks * 2 + hh) ^ key) << 4);
-  const int rr = 4 * hh + (pp >> 2), k1 = (rr >> 1) & 7;           // k1 <= 3, key(rr + 8 + 16n) == k1 ^ 4
+  const int rr = 4 * hh + (pp >> 2), k1 = swz_key(rr), k2 = swz_key(rr + 8);   // keys repeat every 16 rows
 #pragma unroll
   for (int dt = 0; dt < 2; ++dt) {
     const int col = dt * 32 + g1 * 16 + (pp & 3) * 4, lc = col >> 3, bo = (col & 7) * 2;
     o.tr1[dt] = rr * 128 + ((lc ^ k1) << 4) + bo;
-    o.tr2[dt] = (rr + 8) * 128 + ((lc ^ k1 ^ 4) << 4) + bo;
+    o.tr2[dt] = (rr + 8) * 128 + ((lc ^ k2) << 4) + bo;
   }
   return o;
 }
@@ -666,6 +675,244 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
     }
 }
 
+
+// =========================================================================== backward, fused (vision: no mask / reweight / dropout)
+// ONE 8-wave workgroup per (batch, head), all keys of the head at once (<= 512): S, P and dS are computed ONCE (the two-pass
+// kernels above recompute S and the exponentials in the dK/dV pass: 7 GEMM passes and 2 exp per score for 5 and 1).
+//   * wave w OWNS the keys [64w, 64w+64) (two 32-key blocks): its V fragments and its dK / dV accumulators (128 VGPRs) stay in
+//     registers for the whole kernel; the head's K sits in LDS (64 KB image, swizzled) for the S fragments and for dQ
+//   * queries stream through LDS in 32-row tiles (Q, dO: 4 KB each, double-buffered LDS-DMA); per tile and key block:
+//     S = Q k^T, dP = dO v^T (lane = key), P = exp2(S c - lse), dS = P (dP - delta), dV += dO^T P, dK += Q^T dS
+//   * dQ needs the contraction over KEYS, i.e. dS with the keys along the MFMA k dimension: every wave writes its dS block
+//     transposed-ready into an LDS image [key][32 q] (bf16, 8-byte chunks XOR-swizzled by key), and after one barrier wave
+//     (db, qb) computes the 16(d) x 16(q) sub-block of dQ^T = K^T dS^T over ALL keys with v_mfma_f32_16x16x32_bf16, both
+//     operands by transposed LDS reads: no cross-wave reduction, no atomics, results independent of scheduling.
+//     The dQ of tile t-1 is computed at the start of iteration t (dS image double-buffered): one barrier per tile.
+constexpr int FQ = 32;                        // query rows per tile
+constexpr int F_KIMG = 512 * 128;             // K image
+constexpr int F_QT = FQ * 128;                // one 32-row tile
+constexpr int F_DS = 512 * 64;                // dS image of one tile: [512 keys][32 q] bf16
+constexpr int F_OFF_Q = F_KIMG;               // Q tiles [2], dO tiles [2]
+constexpr int F_OFF_DS = F_OFF_Q + 4 * F_QT;
+constexpr int F_OFF_STAT = F_OFF_DS + 2 * F_DS;   // lse[512], delta[512]
+constexpr int F_LDS = F_OFF_STAT + 2 * 512 * 4;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// dS image [key][32 q] (64-byte rows, 8-byte chunks).  Writers: lane = key row, one chunk per ds_write_b64 -- 16 consecutive rows
+// per pass, 8 of them in each 64-byte half of the 128-byte bank window: the key must be a bijection of (row >> 1) & 7.  Readers:
+// transposed reads of rows r..r+7 per 32-lane pass, 32 bytes each: rows r and r + 4 must use different 32-byte halves: bit 2 of
+// the key = bit 2 of the row.
+__device__ __forceinline__ int ds_swz(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 1) & 1); }
+
+__global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const mart_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int Stot = p.Lp + p.Sk;
+  const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
+  const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
+  const LaneOffs lo = make_offs(lane);
+  char* sK = smem;
+  float* sLse = (float*)(smem + F_OFF_STAT);
+  float* sDel = sLse + 512;
+
+  // ---- prologue: K image, lse / delta of every query row, first Q / dO tile
+  const int nkrows = 512;                            // ALL 512 image rows (rows past the last key: clamped copies, finite): the dQ
+                                                     // contraction multiplies them by the zero rows of the dS image, and 0 x garbage could be NaN
+  for (int r0 = 0; r0 < nkrows; r0 += 64) {
+    const int row = r0 + (tid >> 3), pc = tid & 7, lc = pc ^ swz_key(row);
+    glds16(side_row(K, b, h, row) + lc * 8, sK + (size_t)(r0 * 8 + wave * 64) * 16);
+  }
+  auto stage_q = [&](int t, int buf) {               // waves 0-3: Q tile, waves 4-7: dO tile (one 16-byte chunk per thread)
+    const int c = tid & 255, row = c >> 3, pc = c & 7, lc = pc ^ swz_key(row);
+    const int q = min(t * FQ + row, p.Sq - 1);
+    const bf16* src = wave < 4 ? (const bf16*)p.q + ((long long)b * p.Sq + q) * p.ldq + h * 64 + lc * 8
+                               : (const bf16*)pb.dctx + ((long long)b * p.Sq + q) * pb.lddctx + h * 64 + lc * 8;
+    glds16(src, smem + F_OFF_Q + ((wave < 4 ? 0 : 2) + buf) * F_QT + ((wave & 3) * 64) * 16);
+  };
+  stage_q(0, 0);
+  {
+    f32x4* z = (f32x4*)(smem + F_OFF_DS);            // dS images start as zeros: key chunks past the last key contribute nothing to dQ
+#pragma unroll
+    for (int i = 0; i < (2 * F_DS / 16) / 512; ++i) z[i * 512 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  {
+    const int q = tid;                               // 512 threads >= Sq rows (host checks Sq <= 512)
+    float l = 1.0e30f, dsum = 0.f;                   // rows past Sq: p = exp2(x - 1e30) = 0, so they contribute nothing
+    if (q < p.Sq) {
+      l = p.lse[((long long)b * p.nh + h) * p.Sq + q];
+      const bf16* op = (const bf16*)p.ctx + ((long long)b * p.Sq + q) * p.ldctx + h * 64;
+      const bf16* gp = (const bf16*)pb.dctx + ((long long)b * p.Sq + q) * pb.lddctx + h * 64;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bf16x8 o = *(const bf16x8*)(op + c * 8), g = *(const bf16x8*)(gp + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)o[e] * (float)g[e];
+      }
+      if (pb.delta) pb.delta[((long long)b * p.nh + h) * p.Sq + q] = dsum;
+    }
+    sLse[q] = l; sDel[q] = dsum;
+  }
+  // own keys: V fragments in registers, validity
+  bf16x8 vf[2][4];
+  int nval[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int kbase = wave * 64 + kb * 32;
+    nval[kb] = min(max(Stot - kbase, 0), 32);
+    const bf16* vp = side_row(V, b, h, kbase + l31);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) vf[kb][ks] = *(const bf16x8*)(vp + ks * 16 + hh * 8);
+  }
+  f32x16 dk[2][2], dv[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[kb][dt][r] = 0.f; dv[kb][dt][r] = 0.f; }
+  const float c2 = p.scale * LOG2E;
+  const int ntiles = (p.Sq + FQ - 1) / FQ;
+  const int nkc = (Stot + 31) / 32;                   // 32-key chunks of the dQ contraction
+  // dQ sub-block of this wave: d rows db*16.., q columns qb*16..
+  const int db = wave & 3, qb = wave >> 2;
+  const int g16 = lane >> 4, p16 = lane & 15;
+  tile_barrier();
+
+  // dQ of one tile: contraction over 16 chunks of 32 keys, four chunks (16 transposed reads, then 4 MFMAs) at a time so that one
+  // LDS latency is exposed per group instead of per chunk; chunks past the last key multiply zeros (dS image zero-filled once).
+  // Key order inside a 32-key chunk (the contraction index is a dummy: A and B only have to agree): element e of lane group g16
+  // is key 4 g16 + e for e < 4 and 16 + 4 g16 + (e - 4) for e >= 4, so that the two lane groups of a 32-lane pass read rows
+  // r..r+7 (conflict-free with both swizzles).  Every swizzle term depends on the row only through row mod 32, so the four
+  // per-lane byte offsets are loop invariant and a chunk is an immediate offset (no per-read address arithmetic).
+  const int rb = 4 * g16 + (p16 >> 2);
+  const int kchunk = db * 2 + ((p16 & 3) >> 1), kbo = (p16 & 1) * 8, dchunk = qb * 4 + (p16 & 3);
+  const int ka1 = rb * 128 + ((kchunk ^ swz_key(rb)) << 4) + kbo, ka2 = (rb + 16) * 128 + ((kchunk ^ swz_key(rb + 16)) << 4) + kbo;
+  const int da1 = rb * 64 + ((dchunk ^ ds_swz(rb)) << 3), da2 = (rb + 16) * 64 + ((dchunk ^ ds_swz(rb + 16)) << 3);
+  auto dq_tile = [&](int tq) {
+    const char* sD = smem + F_OFF_DS + (tq & 1) * F_DS;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int ngrp = (nkc + 3) >> 2;
+    for (int g = 0; g < ngrp; ++g) {
+      const char* kg = sK + g * (4 * 32 * 128);
+      const char* dg = sD + g * (4 * 32 * 64);
+      bf16x8 af[4], bfv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        af[u] = join_tr(lds_tr_read(kg + u * 4096 + ka1), lds_tr_read(kg + u * 4096 + ka2));
+        bfv[u] = join_tr(lds_tr_read(dg + u * 2048 + da1), lds_tr_read(dg + u * 2048 + da2));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = mfma16(af[u], bfv[u], acc);
+    }
+    const int q = tq * FQ + qb * 16 + p16;
+    if (q < p.Sq) {
+      bf16* op = (bf16*)pb.dq + ((long long)b * p.Sq + q) * pb.lddq + h * 64 + db * 16 + 4 * g16;
+      *(bf16x4*)op = f4_to_bf4(f32x4{acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale});
+    }
+  };
+  // S, P, dS of tile t for the wave's key blocks; dV, dK accumulate; dS goes to the image of tile t
+  auto s_tile = [&](int t) {
+    const char* sQ = smem + F_OFF_Q + (t & 1) * F_QT;
+    const char* sG = smem + F_OFF_Q + (2 + (t & 1)) * F_QT;
+    char* sD = smem + F_OFF_DS + (t & 1) * F_DS;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (nval[kb] == 0) continue;                   // wave-uniform: key block past the end
+      const int key = wave * 64 + kb * 32 + l31;
+      const char* krow = sK + key * 128;
+      const int kkey = swz_key(key);
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(krow + (((ks * 2 + hh) ^ kkey) << 4));
+        st = mfma32(tile_frag(sQ, 0, ks, lo), kf, st);
+        dp = mfma32(tile_frag(sG, 0, ks, lo), vf[kb][ks], dp);
+      }
+      if (nval[kb] < 32) {                           // partially valid block: masked keys get p = 0, dS = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (l31 >= nval[kb]) st[r] = -1.0e30f;
+      }
+      const int swz = ds_swz(key);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        float pd8[8], ds8[8];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+          const int qd = 2 * a + q2;
+          const f32x4 l4 = *(const f32x4*)(sLse + t * FQ + 8 * qd + 4 * hh);
+          const f32x4 d4 = *(const f32x4*)(sDel + t * FQ + 8 * qd + 4 * hh);
+          const f32x2 c22 = {c2, c2};
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const int r = 4 * qd + e;
+            const f32x2 x = f32x2{st[r], st[r + 1]} * c22 - f32x2{l4[e], l4[e + 1]};
+            const f32x2 pr = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            const f32x2 ds = pr * (f32x2{dp[r], dp[r + 1]} - f32x2{d4[e], d4[e + 1]});
+            pd8[4 * q2 + e] = pr[0]; pd8[4 * q2 + e + 1] = pr[1];
+            ds8[4 * q2 + e] = ds[0]; ds8[4 * q2 + e + 1] = ds[1];
+          }
+        }
+        const bf16x8 pf = pack8(pd8);
+        const bf16x8 df = pack8(ds8);
+        // dS, transposed-ready: row = key, 8-byte chunk (4a [+2] + hh) holds the four q rows 16a [+8] + 4hh + 0..3
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        const u32x4_t dw = __builtin_bit_cast(u32x4_t, df);
+        *(u32x2_t*)(sD + key * 64 + (((4 * a + hh) ^ swz) << 3)) = u32x2_t{dw[0], dw[1]};
+        *(u32x2_t*)(sD + key * 64 + (((4 * a + 2 + hh) ^ swz) << 3)) = u32x2_t{dw[2], dw[3]};
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[kb][dt] = mfma32(tile_frag_tr(sG, 16 * a, dt, lo), pf, dv[kb][dt]);
+          dk[kb][dt] = mfma32(tile_frag_tr(sQ, 16 * a, dt, lo), df, dk[kb][dt]);
+        }
+      }
+    }
+  };
+  // Iteration t: the dQ of tile t-1 (LDS-read heavy) and the S / dV / dK work of tile t (MFMA + exp heavy) are independent, so
+  // the two waves of a SIMD (w and w + 4) run them in OPPOSITE order: one reads while the other computes.
+  for (int t = 0; t <= ntiles; ++t) {
+    if (t + 1 < ntiles) stage_q(t + 1, (t + 1) & 1);
+    if (wave < 4 && t > 0) dq_tile(t - 1);
+    if (t < ntiles) s_tile(t);
+    if (wave >= 4 && t > 0) dq_tile(t - 1);
+    tile_barrier();                                    // dS image of tile t complete, Q / dO tile t+1 landed, tile t's buffers free
+  }
+
+  // ---- dK, dV of the wave's keys
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int kj = wave * 64 + kb * 32 + l31;
+    if (kj >= Stot) continue;
+    bf16* okp; bf16* ovp; bool acc = false;
+    if (kj < p.Lp) {
+      okp = (bf16*)pb.dpk + ((long long)b * p.Lp + kj) * pb.lddp + h * 64;
+      ovp = (bf16*)pb.dpv + ((long long)b * p.Lp + kj) * pb.lddp + h * 64;
+    } else {
+      okp = (bf16*)pb.dk + ((long long)b * p.Sk + (kj - p.Lp)) * pb.lddk + h * 64;
+      ovp = (bf16*)pb.dv + ((long long)b * p.Sk + (kj - p.Lp)) * pb.lddv + h * 64;
+      acc = pb.accum_dkv != 0;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int off = dt * 32 + 8 * qd + 4 * hh;
+        f32x4 a = {dk[kb][dt][4 * qd] * p.scale, dk[kb][dt][4 * qd + 1] * p.scale, dk[kb][dt][4 * qd + 2] * p.scale, dk[kb][dt][4 * qd + 3] * p.scale};
+        f32x4 c = {dv[kb][dt][4 * qd], dv[kb][dt][4 * qd + 1], dv[kb][dt][4 * qd + 2], dv[kb][dt][4 * qd + 3]};
+        if (acc) { a += bf4_to_f4(*(const bf16x4*)(okp + off)); c += bf4_to_f4(*(const bf16x4*)(ovp + off)); }
+        *(bf16x4*)(okp + off) = f4_to_bf4(a);
+        *(bf16x4*)(ovp + off) = f4_to_bf4(c);
+      }
+  }
+}
+
 int check_fwd(const mart_attn_fwd_desc* d) {
   MART_CHECK(d && d->q && d->k && d->v && d->ctx, "attn: null pointer");
   MART_CHECK(d->B > 0 && d->nh > 0 && d->Sq > 0 && d->Sk > 0 && d->Lp >= 0, "attn: bad shape");
@@ -686,6 +933,7 @@ int set_attrs() {
                        (const void*)attn_bwd_dkv_k<true>};
   bool ok = true;
   for (int i = 0; i < 8; ++i) ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+  ok = ok && hipFuncSetAttribute((const void*)attn_bwd_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) == hipSuccess;
   if (!ok) {
     mart_set_error("attn: hipFuncSetAttribute failed");
     return -2;
@@ -718,6 +966,12 @@ extern "C" int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream) {
   const mart_attn_fwd_desc& f = d->f;
   const bool text = f.attn_mask || f.sep || f.p_drop > 0.f;
   static const int tpw = getenv("MART_ATTN_TPW_DQ") ? atoi(getenv("MART_ATTN_TPW_DQ")) : 2;
+  static const int fused = getenv("MART_ATTN_FUSED") ? atoi(getenv("MART_ATTN_FUSED")) : 1;
+  if (!text && fused && f.Lp + f.Sk <= 512 && f.Sq <= 512 && f.Sq > 128) {      // one workgroup per head: every key and query row fits
+    hipLaunchKernelGGL(attn_bwd_fused_k, dim3(f.nh, f.B), dim3(512), F_LDS, st, *d);
+    MART_LAUNCH_CHECK();
+    return 0;
+  }
   if (text) hipLaunchKernelGGL((attn_bwd_dq_k<true, 1>), dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   else if (tpw == 2 && f.Sq > 128) hipLaunchKernelGGL((attn_bwd_dq_k<false, 2>), dim3((f.Sq + 255) / 256, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);
   else hipLaunchKernelGGL((attn_bwd_dq_k<false, 1>), dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);

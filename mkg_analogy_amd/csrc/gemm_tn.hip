@@ -470,31 +470,51 @@ extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
   rps = ((rps + BKM - 1) / BKM) * BKM;
   splits = (d->M + rps - 1) / rps;
   a.splits = splits; a.rows_per_split = rps;
-  if (d->workspace && batch == 1 && d->M % BKM == 0) {
-    // deterministic path: 8-phase loop, partial tiles to the caller's workspace, ordered reduction kernel
-    const int tiles_x = (d->NX + BNX - 1) / BNX, tiles_y = (d->NY + BNY - 1) / BNY;
-    const size_t need = ((size_t)splits * tiles * SLAB + (size_t)splits * tiles_x * BNX) * sizeof(float);
-    MART_CHECK(d->workspace_bytes >= need, "gemm_tn: workspace too small (mart_gemm_tn_workspace_bytes)");
-    MART_CHECK(((uintptr_t)d->workspace & 15) == 0, "gemm_tn: workspace must be 16-byte aligned");
-    static MartAttrOnce once8;
-    bool* set8 = once8.slot();
-    if (!*set8) {
-      if (hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-        mart_set_error("gemm_tn: hipFuncSetAttribute failed");
-        return -2;
+  if (d->workspace && batch == 1) {
+    // deterministic path: 8-phase loop over the whole 64-row steps, partial tiles to the caller's workspace, ordered reduction
+    // kernel; a contraction tail (M % 64 rows) is added by ONE workgroup per tile of the single-split kernel below (one
+    // contribution per output element, stream-ordered behind the reduction: still run-to-run identical)
+    const int Mmain = d->M - d->M % BKM;
+    if (Mmain > 0) {
+      const int tiles_x = (d->NX + BNX - 1) / BNX, tiles_y = (d->NY + BNY - 1) / BNY;
+      int sp = d->splits;
+      const int max_sp = (Mmain + 4 * BKM - 1) / (4 * BKM);
+      if (sp <= 0) sp = 256 / tiles;
+      if (sp > max_sp) sp = max_sp;
+      if (sp < 1) sp = 1;
+      int r = (Mmain + sp - 1) / sp;
+      r = ((r + BKM - 1) / BKM) * BKM;
+      sp = (Mmain + r - 1) / r;
+      const size_t need = ((size_t)sp * tiles * SLAB + (size_t)sp * tiles_x * BNX) * sizeof(float);
+      MART_CHECK(d->workspace_bytes >= (long long)need, "gemm_tn: workspace too small (mart_gemm_tn_workspace_bytes)");
+      MART_CHECK(((uintptr_t)d->workspace & 15) == 0, "gemm_tn: workspace must be 16-byte aligned");
+      static MartAttrOnce once8;
+      bool* set8 = once8.slot();
+      if (!*set8) {
+        if (hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+          mart_set_error("gemm_tn: hipFuncSetAttribute failed");
+          return -2;
+        }
+        *set8 = true;
       }
-      *set8 = true;
+      Args2 b;
+      b.X = a.X; b.Y = a.Y; b.ldx = a.ldx; b.ldy = a.ldy; b.M = Mmain; b.NX = a.NX; b.NY = a.NY; b.out = a.out; b.ldo = a.ldo;
+      b.out_rows = a.out_rows; b.colsum = a.colsum; b.colsum_by_row = a.colsum_by_row; b.splits = sp; b.rows_per_split = r;
+      b.tiles_y = tiles_y; b.ntile = tiles; b.alpha = a.alpha;
+      b.ws = (float*)d->workspace; b.ws_col = b.ws + (size_t)sp * tiles * SLAB;
+      hipLaunchKernelGGL(gemm_tn8_kernel, dim3(tiles, sp, 1), dim3(NT), LDS, (hipStream_t)stream, b);
+      MART_LAUNCH_CHECK();
+      const int nblk = tiles * (SLAB / 4 / 256) + (d->colsum ? (tiles_x * BNX + 255) / 256 : 0);
+      hipLaunchKernelGGL(tn_reduce_k, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b);
+      MART_LAUNCH_CHECK();
     }
-    Args2 b;
-    b.X = a.X; b.Y = a.Y; b.ldx = a.ldx; b.ldy = a.ldy; b.M = a.M; b.NX = a.NX; b.NY = a.NY; b.out = a.out; b.ldo = a.ldo;
-    b.out_rows = a.out_rows; b.colsum = a.colsum; b.colsum_by_row = a.colsum_by_row; b.splits = splits; b.rows_per_split = rps;
-    b.tiles_y = tiles_y; b.ntile = tiles; b.alpha = a.alpha;
-    b.ws = (float*)d->workspace; b.ws_col = b.ws + (size_t)splits * tiles * SLAB;
-    hipLaunchKernelGGL(gemm_tn8_kernel, dim3(tiles, splits, 1), dim3(NT), LDS, (hipStream_t)stream, b);
-    MART_LAUNCH_CHECK();
-    const int nblk = tiles * (SLAB / 4 / 256) + (d->colsum ? (tiles_x * BNX + 255) / 256 : 0);
-    hipLaunchKernelGGL(tn_reduce_k, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b);
-    MART_LAUNCH_CHECK();
+    if (d->M > Mmain) {
+      Args t = a;
+      t.X = a.X + (long long)Mmain * a.ldx; t.Y = a.Y + (long long)Mmain * a.ldy; t.M = d->M - Mmain;
+      t.splits = 1; t.rows_per_split = BKM;
+      hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, 1, 1), dim3(NT), LDS, (hipStream_t)stream, t);
+      MART_LAUNCH_CHECK();
+    }
     return 0;
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits, batch), dim3(NT), LDS, (hipStream_t)stream, a);
@@ -504,6 +524,8 @@ extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
 
 /* bytes of workspace the deterministic path of mart_gemm_tn needs for this problem (same split rule as the launcher) */
 extern "C" long long mart_gemm_tn_workspace_bytes(int M, int NX, int NY, int splits_req) {
+  M -= M % BKM;                                        // the tail rows go through the single-split kernel, no workspace
+  if (M <= 0) return 16;
   const int tiles_x = (NX + BNX - 1) / BNX, tiles = tiles_x * ((NY + BNY - 1) / BNY);
   int splits = splits_req;
   const int max_splits = (M + 4 * BKM - 1) / (4 * BKM);

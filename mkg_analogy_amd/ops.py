@@ -74,7 +74,7 @@ TN_DETERMINISTIC = os.environ.get("MART_DETERMINISTIC", "1") == "1"   # ordered 
 def gemm_tn(X, Y, out, *, M=None, NX=None, NY=None, out_rows=None, colsum=None, colsum_by_row=False, batch=1,
             stride_x=0, stride_y=0, stride_o=0, splits=0, alpha=1.0, deterministic=None):
     """out[NX,NY] (f32) += X[M,NX]^T @ Y[M,NY]; colsum[NX] += column sums of X.
-    Deterministic by default (batch 1, M % 64 == 0): the split-M partial tiles go through a workspace (allocated here from
+    Deterministic by default (batch 1): the split-M partial tiles go through a workspace (allocated here from
     torch's caching allocator on the current stream) and are added in split order; otherwise f32 atomics."""
     d = L.GemmTN()
     d.X, d.Y, d.ldx, d.ldy = _p(X), _p(Y), _rows2d(X), _rows2d(Y)
@@ -87,7 +87,7 @@ def gemm_tn(X, Y, out, *, M=None, NX=None, NY=None, out_rows=None, colsum=None, 
     d.splits, d.alpha = splits, alpha
     det = TN_DETERMINISTIC if deterministic is None else deterministic
     ws = None
-    if det and batch == 1 and d.M % 64 == 0:
+    if det and batch == 1:
         nb = int(L.lib().mart_gemm_tn_workspace_bytes(d.M, d.NX, d.NY, splits))
         ws = torch.empty(nb // 4, device=X.device, dtype=F32)
         d.workspace, d.workspace_bytes = _p(ws), nb

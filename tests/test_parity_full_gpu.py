@@ -102,6 +102,7 @@ def _grad_report(st, g, tol_rel, tol_cos, tol_norm, skip=(), ctl_mult=0.0):
         if r > 0.15 + ctl_mult * rc:
             bad.append(("adaptive", r, rc))
     skip = tuple(skip) + tuple(n for n in norms if "adaptive_weight" in n)
+    med_cn = float(np.median([abs(cnorms[n] - r) / r for n, r in norms.items() if r >= 1e-7])) if ctl_mult else 0.0
     for n, ref in norms.items():
         if n.endswith("decoder.weight") or n in skip:
             continue
@@ -110,7 +111,7 @@ def _grad_report(st, g, tol_rel, tol_cos, tol_norm, skip=(), ctl_mult=0.0):
             assert got < 1e-3, (n, got, ref)
             continue
         r = abs(got - ref) / ref
-        lim = tol_norm + (ctl_mult * abs(cnorms[n] - ref) / ref if ctl_mult else 0.0)
+        lim = tol_norm + (ctl_mult * max(abs(cnorms[n] - ref) / ref, med_cn) if ctl_mult else 0.0)   # own or median control displacement
         worst_n = max(worst_n, r)
         if r > lim:
             bad.append(("norm", n, got, ref, lim))

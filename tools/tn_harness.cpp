@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     {"v.qkv  dW [2304,768]  M=100608", MV, 2304, 768}, {"v.out  dW [768,768]   M=100608", MV, 768, 768},
     {"t.fc2  dW [768,3072]  M=16384", MT, 768, 3072},  {"t.qkv  dW [2304,768]  M=16384", MT, 2304, 768},
     {"t.out  dW [768,768]   M=16384", MT, 768, 768},   {"ragged    [2063,768]  M=256", 256, 2063, 768},
-    {"ragged    [700,1000]  M=1216", 1216, 700, 1000},
+    {"ragged    [700,1000]  M=1216", 1216, 700, 1000}, {"ragged M  [768,768]   M=1584", 1584, 768, 768}, {"tiny M    [768,2304]  M=40", 40, 768, 2304},
   };
   const size_t maxX = (size_t)MV * 3072;
   uint16_t* X[6]; uint16_t* Y[6];
