@@ -794,20 +794,28 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
   const int da1 = rb * 64 + ((dchunk ^ ds_swz(rb)) << 3), da2 = (rb + 16) * 64 + ((dchunk ^ ds_swz(rb + 16)) << 3);
   auto dq_tile = [&](int tq) {
     const char* sD = smem + F_OFF_DS + (tq & 1) * F_DS;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int ngrp = (nkc + 3) >> 2;
-    for (int g = 0; g < ngrp; ++g) {
-      const char* kg = sK + g * (4 * 32 * 128);
-      const char* dg = sD + g * (4 * 32 * 64);
-      bf16x8 af[4], bfv[4];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;       // two accumulation chains (even / odd chunks)
+    const int ngrp = (nkc + 1) >> 1;                      // groups of two 32-key chunks
+    bf16x8 af[2][2], bfv[2][2];
+    auto load = [&](int g, int slot) {
+      const char* kg = sK + g * (2 * 32 * 128);
+      const char* dg = sD + g * (2 * 32 * 64);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        af[u] = join_tr(lds_tr_read(kg + u * 4096 + ka1), lds_tr_read(kg + u * 4096 + ka2));
-        bfv[u] = join_tr(lds_tr_read(dg + u * 2048 + da1), lds_tr_read(dg + u * 2048 + da2));
+      for (int u = 0; u < 2; ++u) {
+        af[slot][u] = join_tr(lds_tr_read(kg + u * 4096 + ka1), lds_tr_read(kg + u * 4096 + ka2));
+        bfv[slot][u] = join_tr(lds_tr_read(dg + u * 2048 + da1), lds_tr_read(dg + u * 2048 + da2));
       }
+    };
+    load(0, 0);                                            // software pipeline: the reads of group g + 1 are in flight under the MFMAs of group g
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = mfma16(af[u], bfv[u], acc);
+    for (int g = 0; g < 8; ++g) {
+      if (g < ngrp) {
+        if (g + 1 < ngrp) load(g + 1, (g + 1) & 1);
+        acc0 = mfma16(af[g & 1][0], bfv[g & 1][0], acc0);
+        acc1 = mfma16(af[g & 1][1], bfv[g & 1][1], acc1);
+      }
     }
+    const f32x4 acc = acc0 + acc1;
     const int q = tq * FQ + qb * 16 + p16;
     if (q < p.Sq) {
       bf16* op = (bf16*)pb.dq + ((long long)b * p.Sq + q) * pb.lddq + h * 64 + db * 16 + 4 * g16;
@@ -879,9 +887,12 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
   // the two waves of a SIMD (w and w + 4) run them in OPPOSITE order: one reads while the other computes.
   for (int t = 0; t <= ntiles; ++t) {
     if (t + 1 < ntiles) stage_q(t + 1, (t + 1) & 1);
-    if (wave < 4 && t > 0) dq_tile(t - 1);
-    if (t < ntiles) s_tile(t);
-    if (wave >= 4 && t > 0) dq_tile(t - 1);
+#ifndef FUSED_KO
+#define FUSED_KO 0
+#endif
+    if (wave < 4 && t > 0 && !(FUSED_KO & 1)) dq_tile(t - 1);
+    if (t < ntiles && !(FUSED_KO & 2)) s_tile(t);
+    if (wave >= 4 && t > 0 && !(FUSED_KO & 1)) dq_tile(t - 1);
     tile_barrier();                                    // dS image of tile t complete, Q / dO tile t+1 landed, tile t's buffers free
   }
 
