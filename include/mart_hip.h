@@ -131,6 +131,9 @@ int mart_gather_images(const float* table, const int32_t* index, float* out, int
 int mart_vision_assemble(const void* patch_bf16, const float* cls, const float* pos, float* s, int B, int P, int H, int tail_shift, void* stream);
 /* backward of the assemble: dpatch (bf16) and atomically accumulated dcls, dpos */
 int mart_vision_assemble_bwd(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, int tail_shift, void* stream);
+/* same result, deterministic: slice partials through a caller-owned workspace ((P+1) * 16 * 2 * H floats), reduced in slice order */
+int mart_vision_assemble_bwd_det(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, int tail_shift,
+                                 float* ws, long long ws_bytes, void* stream);
 /* BertEmbeddings.forward (modeling_unimo.py:152-186): word[ids]+type[tt]+pos[:L] -> LN(eps) -> dropout */
 typedef struct {
   const int64_t* ids; const int64_t* tt;
@@ -147,6 +150,10 @@ int mart_dropout_bwd_f32(const float* dy_f32, const void* dy_bf16, float* out, l
 /* scatter ds [B*L,H] into dword[ids], dpos[0..L), dtype[tt] (atomic) */
 int mart_text_embed_scatter(const float* ds, const int64_t* ids, const int64_t* tt, float* dword, float* dpos, float* dtype,
                             int B, int L, int H, void* stream);
+/* same result, deterministic (no float atomics).  order[B*L]: the flat token positions sorted by id (stable sort of ids; index
+ * preparation on the host side); ws: (ceil(B*L/64) * 2 + L * 16 * 2) * H floats; meta: ceil(B*L/64) int32.  Token types 0 / 1. */
+int mart_text_embed_scatter_det(const float* ds, const int64_t* ids, const int64_t* tt, const int64_t* order, float* dword, float* dpos, float* dtype,
+                                int B, int L, int H, float* ws, long long ws_bytes, int32_t* meta, void* stream);
 
 /* ---------------------------------------------------------------- attention (head_dim 64)
  * Flash-style multi-head attention, K/V tiles staged in LDS, wave-level online softmax.

@@ -96,6 +96,8 @@ _SIGS = {
     "mart_text_embed_fwd": (i32, [C.POINTER(TextEmbed), vp]),
     "mart_dropout_bwd_f32": (i32, [vp, vp, vp, i64, f32, u64, vp]),
     "mart_text_embed_scatter": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "mart_text_embed_scatter_det": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, i64, vp, vp]),
+    "mart_vision_assemble_bwd_det": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp]),
     "mart_attn_fwd": (i32, [C.POINTER(AttnFwd), vp]),
     "mart_attn_bwd": (i32, [C.POINTER(AttnBwd), vp]),
     "mart_softmax_fwd": (i32, [vp, i32, vp, i32, i32, i32, vp]),

@@ -268,6 +268,112 @@ __global__ __launch_bounds__(256) void text_embed_scatter_k(const float* __restr
   }
 }
 
+
+// ------------------------------------------------------------------ deterministic embedding gradients (no float atomics)
+// Word rows: the caller passes `order`, the token positions sorted by id (stable sort of ids, index preparation on the host
+// side).  Pass 1 -- one workgroup per 64 consecutive SORTED positions walks them in order and sums runs of equal ids: a run that
+// lies inside the workgroup's window is added to its word row directly (it is the only writer of that row); the run that
+// touches the window's first / last position may continue in the neighbouring windows and goes to a partial row (head / tail
+// slot of the window).  Pass 2 -- the workgroup whose window holds the FIRST piece of such a run walks the following windows and
+// adds the pieces in window order.  Every row is summed in sorted-position order: run-to-run identical.
+constexpr int ES = 64;                               // sorted positions per window
+__global__ __launch_bounds__(256) void embed_word_pass1_k(const float* __restrict__ ds, const int64_t* __restrict__ ids, const int64_t* __restrict__ order,
+                                                         float* dword, float* ws, int* meta, int n, int H) {
+  const int w0 = blockIdx.x * ES, w1 = min(n, w0 + ES);
+  const long long id_first = ids[order[w0]], id_last = ids[order[w1 - 1]];
+  const bool head_open = w0 > 0 && ids[order[w0 - 1]] == id_first;          // first run continues a run of the previous window
+  const bool tail_open = w1 < n && ids[order[w1]] == id_last;               // last run continues into the next window
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float acc = 0.f;
+    long long cur = id_first;
+    bool first_run = true;
+    for (int j = w0; j < w1; ++j) {
+      const long long tok = order[j], id = ids[tok];
+      if (id != cur) {                                                     // flush the finished run
+        if (first_run && head_open) ws[((long long)blockIdx.x * 2 + 0) * H + c] = acc;
+        else dword[cur * H + c] += acc;
+        first_run = false; cur = id; acc = 0.f;
+      }
+      acc += ds[tok * H + c];
+    }
+    // last run of the window (it may also be the first one: a window inside a long run)
+    if (first_run && head_open) ws[((long long)blockIdx.x * 2 + 0) * H + c] = acc;      // continuation piece (whole window or its head)
+    else if (tail_open) ws[((long long)blockIdx.x * 2 + 1) * H + c] = acc;               // first piece of a run that continues
+    else dword[cur * H + c] += acc;
+  }
+  if (threadIdx.x == 0) {
+    // kind of the window's pieces: bit 0 = head slot holds a continuation piece, bit 1 = tail slot holds the first piece of a run,
+    // bit 2 = the head piece is the whole window and the run goes on (same id at both ends, both open)
+    int m = 0;
+    if (head_open) m |= 1;
+    if (tail_open && !(head_open && id_first == id_last)) m |= 2;
+    if (head_open && tail_open && id_first == id_last) m |= 4;
+    meta[blockIdx.x] = m;
+  }
+}
+__global__ __launch_bounds__(256) void embed_word_pass2_k(const int64_t* __restrict__ ids, const int64_t* __restrict__ order, float* dword, const float* __restrict__ ws,
+                                                         const int* __restrict__ meta, int n, int nwin, int H) {
+  const int k = blockIdx.x;
+  if (!(meta[k] & 2)) return;                                              // this window does not start a multi-window run
+  const long long id = ids[order[min(n, (k + 1) * ES) - 1]];
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float acc = ws[((long long)k * 2 + 1) * H + c];
+    for (int q = k + 1; q < nwin; ++q) {
+      const int m = meta[q];
+      if (!(m & 1)) break;
+      acc += ws[((long long)q * 2 + 0) * H + c];
+      if (!(m & 4)) break;                                                 // the run ended inside window q
+    }
+    dword[id * H + c] += acc;
+  }
+}
+// position / token-type rows: per (position, batch slice) partial sums, then an ordered reduction
+__global__ __launch_bounds__(256) void embed_postype_partial_k(const float* __restrict__ ds, const int64_t* __restrict__ tt, float* ws, int B, int L, int H) {
+  const int pos = blockIdx.x, nsl = gridDim.y, per = (B + nsl - 1) / nsl;
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float ap = 0.f, a1 = 0.f;
+    for (int b = b0; b < b1; ++b) {
+      const long long m = (long long)b * L + pos;
+      const float g = ds[m * H + c];
+      ap += g;
+      if (tt[m] == 1) a1 += g;
+    }
+    float* o = ws + (((long long)pos * nsl + blockIdx.y) * 2) * H;
+    o[c] = ap; o[H + c] = a1;                                              // all tokens, type-1 tokens (type 0 = all - type 1 is NOT used: summed separately below)
+  }
+}
+__global__ __launch_bounds__(256) void embed_postype_reduce_k(const float* __restrict__ ws, float* dpos, float* dtype, int L, int nsl, int H) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= H) return;
+  const int row = blockIdx.y;                                              // 0..L-1: position rows, L: type 0, L+1: type 1
+  if (row < L) {
+    float tot = 0.f;
+    for (int s = 0; s < nsl; ++s) tot += ws[(((long long)row * nsl + s) * 2) * H + c];
+    dpos[(long long)row * H + c] += tot;
+  } else {
+    float all = 0.f, one = 0.f;
+    for (int pos = 0; pos < L; ++pos)
+      for (int s = 0; s < nsl; ++s) {
+        all += ws[(((long long)pos * nsl + s) * 2) * H + c];
+        one += ws[(((long long)pos * nsl + s) * 2 + 1) * H + c];
+      }
+    if (row == L) dtype[c] += all - one; else dtype[H + c] += one;
+  }
+}
+// vision: slice partials of vision_assemble_bwd_k (ws given) -> dcls / dpos in slice order
+__global__ __launch_bounds__(256) void vision_assemble_reduce_k(const float* __restrict__ ws, float* dcls, float* dpos, int P, int nsl, int H, int tail_shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x, u = blockIdx.y;            // output position row u = 0..P
+  if (c >= H) return;
+  float tot = 0.f;
+  for (int s = 0; s < nsl; ++s) tot += ws[(((long long)u * nsl + s) * 2) * H + c];                 // first-image row u (u = 0: class token)
+  if (u == 0) dcls[c] += tot;
+  const int t2 = u + tail_shift;                                           // second-image rows whose position row is u
+  if (t2 >= 1 && t2 <= P)
+    for (int s = 0; s < nsl; ++s) tot += ws[(((long long)t2 * nsl + s) * 2 + 1) * H + c];
+  dpos[(long long)u * H + c] += tot;
+}
+
 // ------------------------------------------------------------------ vision embeddings
 // pixels [B,2,3,S,S] f32 -> patch matrix [(b,img,py,px), (c,ky,kx)] bf16
 __global__ void patchify_k(const float* __restrict__ pix, bf16* __restrict__ out, int B, int S, int p) {
@@ -331,7 +437,7 @@ __global__ void vision_assemble_k(const bf16* __restrict__ patch, const float* _
 
 // dpatch = bf16(ds rows 1..2P); dcls += sum_b ds[b,0]; dpos[t] += sum_b (ds[b,t] + ds[b,t+P])
 // grid (P+1 rows, batch slices), 16-byte accesses; the slice sums reach dcls / dpos with one atomic per (slice, row, column)
-__global__ __launch_bounds__(192) void vision_assemble_bwd_k(const float* __restrict__ ds, bf16* __restrict__ dpatch, float* dcls, float* dpos, int B, int P, int H, int tail_shift) {
+__global__ __launch_bounds__(192) void vision_assemble_bwd_k(const float* __restrict__ ds, bf16* __restrict__ dpatch, float* dcls, float* dpos, int B, int P, int H, int tail_shift, float* ws) {
   const int Nv = 1 + 2 * P;
   const int t = blockIdx.x;                          // 0..P : row of the first image (and of the class token)
   const int nsl = gridDim.y, per = (B + nsl - 1) / nsl;
@@ -349,6 +455,11 @@ __global__ __launch_bounds__(192) void vision_assemble_bwd_k(const float* __rest
       }
     }
     // acc: the first image's row t (position row t); acc_tail: the second image's row t (position row t - tail_shift)
+    if (ws) {                                        // deterministic: slice partials, reduced in slice order by vision_assemble_reduce_k
+      float* o = ws + (((long long)t * nsl + blockIdx.y) * 2) * H;
+      *(f32x4*)(o + c) = acc; *(f32x4*)(o + H + c) = acc_tail;
+      continue;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       atomicAdd(dpos + (long long)t * H + c + e, acc[e]);
@@ -541,7 +652,36 @@ extern "C" int mart_vision_assemble(const void* patch_bf16, const float* cls, co
 }
 extern "C" int mart_vision_assemble_bwd(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, int tail_shift, void* stream) {
   MART_CHECK(ds && dpatch_bf16 && dcls && dpos && B > 0 && P > 0 && H > 0 && H % 4 == 0 && (tail_shift == 0 || tail_shift == 1), "vision_assemble_bwd: bad args (H must be a multiple of 4)");
-  hipLaunchKernelGGL(vision_assemble_bwd_k, dim3(P + 1, B >= 64 ? 16 : 1), dim3(192), 0, (hipStream_t)stream, ds, (bf16*)dpatch_bf16, dcls, dpos, B, P, H, tail_shift);
+  hipLaunchKernelGGL(vision_assemble_bwd_k, dim3(P + 1, B >= 64 ? 16 : 1), dim3(192), 0, (hipStream_t)stream, ds, (bf16*)dpatch_bf16, dcls, dpos, B, P, H, tail_shift, (float*)nullptr);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_vision_assemble_bwd_det(const float* ds, void* dpatch_bf16, float* dcls, float* dpos, int B, int P, int H, int tail_shift,
+                                            float* ws, long long ws_bytes, void* stream) {
+  MART_CHECK(ds && dpatch_bf16 && dcls && dpos && ws && B > 0 && P > 0 && H > 0 && H % 4 == 0 && (tail_shift == 0 || tail_shift == 1), "vision_assemble_bwd_det: bad args");
+  const int nsl = B >= 64 ? 16 : 1;
+  MART_CHECK(ws_bytes >= (long long)(P + 1) * nsl * 2 * H * (long long)sizeof(float), "vision_assemble_bwd_det: workspace too small ((P+1) * 16 * 2 * H floats suffice)");
+  hipLaunchKernelGGL(vision_assemble_bwd_k, dim3(P + 1, nsl), dim3(192), 0, (hipStream_t)stream, ds, (bf16*)dpatch_bf16, dcls, dpos, B, P, H, tail_shift, ws);
+  MART_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vision_assemble_reduce_k, dim3((H + 255) / 256, P + 1), dim3(256), 0, (hipStream_t)stream, ws, dcls, dpos, P, nsl, H, tail_shift);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_text_embed_scatter_det(const float* ds, const int64_t* ids, const int64_t* tt, const int64_t* order, float* dword, float* dpos, float* dtype,
+                                           int B, int L, int H, float* ws, long long ws_bytes, int32_t* meta, void* stream) {
+  MART_CHECK(ds && ids && tt && order && dword && dpos && dtype && ws && meta && B > 0 && L > 0 && H > 0, "text_embed_scatter_det: bad args");
+  const int n = B * L, nwin = (n + ES - 1) / ES, nsl = B >= 64 ? 16 : 1;
+  const long long need = ((long long)nwin * 2 + (long long)L * nsl * 2) * H * (long long)sizeof(float);
+  MART_CHECK(ws_bytes >= need, "text_embed_scatter_det: workspace too small ((ceil(B*L/64) * 2 + L * 16 * 2) * H floats suffice)");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(embed_word_pass1_k, dim3(nwin), dim3(256), 0, st, ds, ids, order, dword, ws, meta, n, H);
+  MART_LAUNCH_CHECK();
+  hipLaunchKernelGGL(embed_word_pass2_k, dim3(nwin), dim3(256), 0, st, ids, order, dword, ws, meta, n, nwin, H);
+  MART_LAUNCH_CHECK();
+  float* ws2 = ws + (long long)nwin * 2 * H;
+  hipLaunchKernelGGL(embed_postype_partial_k, dim3(L, nsl), dim3(256), 0, st, ds, tt, ws2, B, L, H);
+  MART_LAUNCH_CHECK();
+  hipLaunchKernelGGL(embed_postype_reduce_k, dim3((H + 255) / 256, L + 2), dim3(256), 0, st, ws2, dpos, dtype, L, nsl, H);
   MART_LAUNCH_CHECK();
   return 0;
 }

@@ -135,6 +135,11 @@ def vision_assemble(patch, cls, pos, s, B, P, H, tail_shift=0):
 
 
 def vision_assemble_bwd(ds, dpatch, dcls, dpos, B, P, H, tail_shift=0):
+    if TN_DETERMINISTIC:                               # slice partials + ordered reduction instead of f32 atomics
+        ws = torch.empty((P + 1) * 16 * 2 * H, device=ds.device, dtype=F32)
+        L.check(L.lib().mart_vision_assemble_bwd_det(_p(ds), _p(dpatch), _p(dcls), _p(dpos), B, P, H, tail_shift, _p(ws), ws.numel() * 4, _stream()),
+                "mart_vision_assemble_bwd_det")
+        return
     L.check(L.lib().mart_vision_assemble_bwd(_p(ds), _p(dpatch), _p(dcls), _p(dpos), B, P, H, tail_shift, _stream()), "mart_vision_assemble_bwd")
 
 
@@ -152,6 +157,14 @@ def dropout_bwd_f32(dy_f32, dy_bf16, out, n, p, seed):
 
 
 def text_embed_scatter(ds, ids, tt, dword, dpos, dtype, B, Lq, H):
+    if TN_DETERMINISTIC:                               # word rows summed in sorted-token order, position / type rows through slice partials
+        order = torch.argsort(ids.reshape(-1), stable=True)          # index preparation only; the sums are the kernels'
+        nwin = (B * Lq + 63) // 64
+        ws = torch.empty((nwin * 2 + Lq * 16 * 2) * H, device=ds.device, dtype=F32)
+        meta = torch.empty(nwin, device=ds.device, dtype=torch.int32)
+        L.check(L.lib().mart_text_embed_scatter_det(_p(ds), _p(ids), _p(tt), _p(order), _p(dword), _p(dpos), _p(dtype), B, Lq, H,
+                                                    _p(ws), ws.numel() * 4, _p(meta), _stream()), "mart_text_embed_scatter_det")
+        return
     L.check(L.lib().mart_text_embed_scatter(_p(ds), _p(ids), _p(tt), _p(dword), _p(dpos), _p(dtype), B, Lq, H, _stream()),
             "mart_text_embed_scatter")
 
