@@ -306,7 +306,7 @@ def main():
                                                  "unit": "TFLOP/s", "frac": round(f / (m * 1e-3) / 1e12 / bound_tf, 4)}
         others = [r for r in (famrow("gemm_tn", "gemm_tn8_kernel + tn_reduce_k (weight / bias gradients, deterministic split reduction)"),
                               famrow("attn_fwd_vision", "attn_fwd_k<vision> (393 queries x 393 / 457 keys, d 64)"),
-                              famrow("attn_bwd_vision", "attn_bwd_dq_k + attn_bwd_dkv_k <vision> (algorithmic flops = 2 x forward)"),
+                              famrow("attn_bwd_vision", "attn_bwd_fused_k <vision> (one workgroup per head: dQ, dK, dV in one pass; algorithmic flops = 2 x forward)"),
                               famrow("gemm_nt_128", "gemm_nt_kernel<128,128,2,2> (small products: fusion, head, short grids)")) if r]
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,256,2,4> (bf16 MFMA 32x32x16 NT GEMM, 8-phase K loop, fused epilogues)", "achieved": round(ach, 1),
                 "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
