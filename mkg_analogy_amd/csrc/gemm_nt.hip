@@ -531,8 +531,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
           char* dst = epb + l31 * RS + (j * 32 + 8 * q + 4 * h) * 2;
           if constexpr ((EPI & F_PGRAD) != 0) {
             f32x2 a0, a1, g0, g1;
+#ifdef KO_EPI_ACT
+            a0 = f32x2{v[0], v[1]}; a1 = f32x2{v[2], v[3]}; g0 = a0 + a0; g1 = a1 + a1;
+#else
             act_fwd_grad2(f32x2{v[0], v[1]}, ACTK, a0, g0);
             act_fwd_grad2(f32x2{v[2], v[3]}, ACTK, a1, g1);
+#endif
             *(bf16x4*)(dst + 32 * RS) = f2x2_to_bf4(g0, g1);
             *(bf16x4*)dst = f2x2_to_bf4(a0, a1);
             continue;
@@ -556,7 +560,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
         const int row = it * 8 + rr;
         const bf16x8 o = *(const bf16x8*)(epb + row * RS + rc * 2);
         const long long uo = (long long)(ro(i) + it * 8) * p.ldc * 2;          // wave-uniform byte offset of the row group
+#ifdef KO_EPI_ST
+        if (p.alpha == 12345.f) {
+#else
         if (!GUARD || ro(i) + row < mrem) {
+#endif
           st_stream((bf16x8*)(cbase + uo + loff), o);
           if constexpr ((EPI & F_PREACT) != 0) st_stream((bf16x8*)(pbase + uo + loff), *(const bf16x8*)(epb + 32 * RS + row * RS + rc * 2));
         }
@@ -614,8 +622,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
           for (int it = 0; it < NIT; ++it) {
             const int g = ro(i) + it * RPI;
+#ifdef KO_EPI_LD
+            if constexpr ((EPI & F_RES) != 0) pr[i % NPRE][it] = f32x4{p.alpha, p.alpha, p.alpha, p.alpha};
+            if constexpr ((EPI & F_MULZ) != 0) pz[i % NPRE][it] = f4_to_bf4(f32x4{p.alpha, p.alpha, p.alpha, p.alpha});
+#else
             if constexpr ((EPI & F_RES) != 0) pr[i % NPRE][it] = ld_stream((const f32x4*)adr(rbase, g, p.ldres, 4, lo_r));
             if constexpr ((EPI & F_MULZ) != 0) pz[i % NPRE][it] = ld_stream((const bf16x4*)adr(zbase, g, p.ldres, 2, lo_r));
+#endif
           }
         }
       };
@@ -626,7 +639,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
           const int row = it * RPI + er, g = ro(i) + it * RPI;
           f32x4 v = *(const f32x4*)(ep + row * EP_LD + ec);
           v = v * p.alpha + bv;
+#ifdef KO_EPI_ST
+          const bool ok = p.alpha == 12345.f;
+#else
           const bool ok = !GUARD || g + er < mrem;
+#endif
           if constexpr ((EPI & F_PREACT) != 0) { if (ok) st_stream((bf16x4*)adr(pbase, g, p.ldc, 2, lo_c), f4_to_bf4(v)); }
           if constexpr ((EPI & F_ACT) != 0) {
 #pragma unroll

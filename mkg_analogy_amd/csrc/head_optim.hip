@@ -125,15 +125,22 @@ __global__ void simloss_bwd_k(const float* __restrict__ tr, const int64_t* rel, 
 }
 
 // ------------------------------------------------------------------ fused AdamW (torch.optim.AdamW semantics)
+// One workgroup per 8192-element part of a chunk (a chunk is at most 65536 elements of one tensor): the streamed launches of a
+// step cover ~230 chunks each, and one workgroup per chunk left most CUs with a single 4-wave workgroup (2.6 TB/s); eight
+// parts per chunk put 7 workgroups on every CU.  Element-wise, so the split changes no result.
+constexpr int ADAMW_PART = 8192;
 __global__ __launch_bounds__(TPB) void adamw_k(mart_adamw_desc p) {
-  for (int ci = blockIdx.x; ci < p.n_chunks; ci += gridDim.x) {
+  const int parts = 65536 / ADAMW_PART;
+  for (int wi = blockIdx.x; wi < p.n_chunks * parts; wi += gridDim.x) {
+    const int ci = wi / parts, part = wi % parts;
     const int start = p.chunks[3 * ci], len = p.chunks[3 * ci + 1];
     const float wd = p.chunks[3 * ci + 2] ? p.weight_decay : 0.f;
     const float decay = 1.f - p.lr * wd;
     const float step_size = p.lr / p.bc1;
     const float inv_sqrt_bc2 = rsqrtf(p.bc2);
     bf16* sh = (bf16*)p.shadow_bf16;
-    for (int i = threadIdx.x * 4; i < len; i += TPB * 4) {
+    for (int base = part * ADAMW_PART; base < len; base += parts * ADAMW_PART)        // longer chunks (the ABI sets no limit): round-robin
+    for (int i = base + threadIdx.x * 4, pend = min(len, base + ADAMW_PART); i < pend; i += TPB * 4) {
       const long long o = (long long)start + i;
       if (i + 3 < len) {
         f32x4 w = *(f32x4*)(p.master + o), g = *(const f32x4*)(p.grad + o), m = *(f32x4*)(p.m + o), v = *(f32x4*)(p.v + o);
@@ -200,7 +207,8 @@ extern "C" int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, cons
 extern "C" int mart_adamw(const mart_adamw_desc* d, void* stream) {
   MART_CHECK(d && d->master && d->grad && d->m && d->v && d->chunks && d->n_chunks > 0, "adamw: bad args");
   MART_CHECK(d->bc1 > 0.f && d->bc2 > 0.f, "adamw: bias corrections must be positive");
-  int g = d->n_chunks < 4096 ? d->n_chunks : 4096;
+  const long long wg = (long long)d->n_chunks * (65536 / ADAMW_PART);
+  int g = wg < 8192 ? (int)wg : 8192;
   hipLaunchKernelGGL(adamw_k, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
   return 0;

@@ -343,22 +343,29 @@ __global__ __launch_bounds__(256) void embed_postype_partial_k(const float* __re
     o[c] = ap; o[H + c] = a1;                                              // all tokens, type-1 tokens (type 0 = all - type 1 is NOT used: summed separately below)
   }
 }
-__global__ __launch_bounds__(256) void embed_postype_reduce_k(const float* __restrict__ ws, float* dpos, float* dtype, int L, int nsl, int H) {
+__global__ __launch_bounds__(256) void embed_postype_reduce_k(const float* __restrict__ ws, float* dpos, int L, int nsl, int H) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= H) return;
-  const int row = blockIdx.y;                                              // 0..L-1: position rows, L: type 0, L+1: type 1
-  if (row < L) {
-    float tot = 0.f;
-    for (int s = 0; s < nsl; ++s) tot += ws[(((long long)row * nsl + s) * 2) * H + c];
-    dpos[(long long)row * H + c] += tot;
-  } else {
-    float all = 0.f, one = 0.f;
-    for (int pos = 0; pos < L; ++pos)
-      for (int s = 0; s < nsl; ++s) {
-        all += ws[(((long long)pos * nsl + s) * 2) * H + c];
-        one += ws[(((long long)pos * nsl + s) * 2 + 1) * H + c];
-      }
-    if (row == L) dtype[c] += all - one; else dtype[H + c] += one;
+  const int row = blockIdx.y;                                              // position row
+  float tot = 0.f;
+  for (int s = 0; s < nsl; ++s) tot += ws[(((long long)row * nsl + s) * 2) * H + c];
+  dpos[(long long)row * H + c] += tot;
+}
+// token-type rows: all L * nsl partial pairs of a column, 16 groups of 64 columns per workgroup striding over the pairs with
+// independent loads, combined through LDS in group order (fixed order -> run-to-run identical; a single thread walking the
+// 2 * L * nsl loads serially took 0.27 ms)
+__global__ __launch_bounds__(1024) void embed_type_reduce_k(const float* __restrict__ ws, float* dtype, int n_pairs, int H) {
+  __shared__ float sa[16][64], so[16][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6, c = blockIdx.x * 64 + tx;
+  float all = 0.f, one = 0.f;
+  if (c < H)
+    for (int i = g; i < n_pairs; i += 16) { all += ws[((long long)i * 2) * H + c]; one += ws[((long long)i * 2 + 1) * H + c]; }
+  sa[g][tx] = all; so[g][tx] = one;
+  __syncthreads();
+  if (g == 0 && c < H) {
+    all = 0.f; one = 0.f;
+    for (int k = 0; k < 16; ++k) { all += sa[k][tx]; one += so[k][tx]; }
+    dtype[c] += all - one; dtype[H + c] += one;
   }
 }
 // vision: slice partials of vision_assemble_bwd_k (ws given) -> dcls / dpos in slice order
@@ -681,7 +688,9 @@ extern "C" int mart_text_embed_scatter_det(const float* ds, const int64_t* ids, 
   float* ws2 = ws + (long long)nwin * 2 * H;
   hipLaunchKernelGGL(embed_postype_partial_k, dim3(L, nsl), dim3(256), 0, st, ds, tt, ws2, B, L, H);
   MART_LAUNCH_CHECK();
-  hipLaunchKernelGGL(embed_postype_reduce_k, dim3((H + 255) / 256, L + 2), dim3(256), 0, st, ws2, dpos, dtype, L, nsl, H);
+  hipLaunchKernelGGL(embed_postype_reduce_k, dim3((H + 255) / 256, L), dim3(256), 0, st, ws2, dpos, L, nsl, H);
+  MART_LAUNCH_CHECK();
+  hipLaunchKernelGGL(embed_type_reduce_k, dim3((H + 63) / 64), dim3(1024), 0, st, ws2, dtype, L * nsl, H);
   MART_LAUNCH_CHECK();
   return 0;
 }
