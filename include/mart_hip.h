@@ -190,6 +190,32 @@ typedef struct {
 } mart_attn_bwd_desc;
 int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream);
 
+/* ---------------------------------------------------------------- BertFusion as one kernel per direction (modeling_unimo.py:400-414)
+ * fusion_scores = hidden @ visual^T (no scale, :405) ; fusion_probs = softmax(fusion_scores, -1) (:410) ;
+ * fusion_output = fusion_probs @ visual (:411).  q = hidden [B*Lq, H], v = visual [B*Nv, H] (bf16, row-major).  The scores stay on
+ * chip; probs [B*Lq, ldp] (bf16, columns Nv..ldp zero) is written for the backward pass.  Shapes: mart_fusion_supported(Lq, Nv, H)
+ * (H = 768, Lq a multiple of 32, Nv <= 512 within the LDS budget); callers fall back to mart_gemm_nt + mart_softmax_* otherwise. */
+typedef struct {
+  const void* q; int ldq; const void* v; int ldv;
+  void* out; int ldo;                                               /* fusion_output bf16 [B*Lq, H] */
+  void* probs; int ldp;                                             /* bf16 [B*Lq, ldp], ldp a multiple of 8 in [Nv, 64*ceil(Nv/64)] */
+  int B, Lq, Nv, H;
+} mart_fusion_fwd_desc;
+int mart_fusion_supported(int Lq, int Nv, int H);
+int mart_fusion_fwd(const mart_fusion_fwd_desc* d, void* stream);
+/* autograd of the three lines above: dq = d(hidden) (bf16, written), dv_f32 += d(visual) in place (the vision-stream gradient; each
+ * element is updated by one wave per launch and the 64-query blocks are sequential launches: no atomics, fixed order),
+ * dv_bf16 = optional bf16 copy of the updated rows. */
+typedef struct {
+  const void* q; int ldq; const void* v; int ldv;
+  const void* dout; int lddo;                                       /* d(fusion_output) bf16 [B*Lq, H] */
+  const void* probs; int ldp;
+  void* dq; int lddq;
+  float* dv_f32; int lddv; void* dv_bf16; int lddvb;
+  int B, Lq, Nv, H;
+} mart_fusion_bwd_desc;
+int mart_fusion_bwd(const mart_fusion_bwd_desc* d, void* stream);
+
 /* ---------------------------------------------------------------- row softmax (fusion op, modeling_unimo.py:410)
  * probs (bf16, ldp >= C, columns C..ldp zero-filled) = softmax(scores f32 [R,C]) */
 int mart_softmax_fwd(const float* scores, int lds_, void* probs_bf16, int ldp, int R, int C, void* stream);

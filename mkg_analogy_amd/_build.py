@@ -11,7 +11,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmart_hip.so")
-SOURCES = ["util.hip", "gemm_nt.hip", "gemm_tn.hip", "norm_embed.hip", "attention.hip", "head_optim.hip", "precise.hip"]
+SOURCES = ["util.hip", "gemm_nt.hip", "gemm_tn.hip", "norm_embed.hip", "attention.hip", "fusion.hip", "head_optim.hip", "precise.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-file extras: attention keeps MFMA results in arch VGPRs (the softmax consumes them with VALU right away; the
 # default AGPR form cost ~150 v_accvgpr moves per 16 MFMAs)

@@ -73,6 +73,17 @@ class AttnBwd(C.Structure):
                 ("dpk", vp), ("dpv", vp), ("lddp", i32), ("accum_dkv", i32), ("dw", vp), ("dw_ws", vp)]
 
 
+class FusionFwd(C.Structure):
+    _fields_ = [("q", vp), ("ldq", i32), ("v", vp), ("ldv", i32), ("out", vp), ("ldo", i32), ("probs", vp), ("ldp", i32),
+                ("B", i32), ("Lq", i32), ("Nv", i32), ("H", i32)]
+
+
+class FusionBwd(C.Structure):
+    _fields_ = [("q", vp), ("ldq", i32), ("v", vp), ("ldv", i32), ("dout", vp), ("lddo", i32), ("probs", vp), ("ldp", i32),
+                ("dq", vp), ("lddq", i32), ("dv_f32", vp), ("lddv", i32), ("dv_bf16", vp), ("lddvb", i32),
+                ("B", i32), ("Lq", i32), ("Nv", i32), ("H", i32)]
+
+
 class AdamW(C.Structure):
     _fields_ = [("master", vp), ("grad", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("chunks", vp), ("n_chunks", i32),
                 ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bc1", f32), ("bc2", f32),
@@ -100,6 +111,9 @@ _SIGS = {
     "mart_vision_assemble_bwd_det": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp]),
     "mart_attn_fwd": (i32, [C.POINTER(AttnFwd), vp]),
     "mart_attn_bwd": (i32, [C.POINTER(AttnBwd), vp]),
+    "mart_fusion_supported": (i32, [i32, i32, i32]),
+    "mart_fusion_fwd": (i32, [C.POINTER(FusionFwd), vp]),
+    "mart_fusion_bwd": (i32, [C.POINTER(FusionBwd), vp]),
     "mart_softmax_fwd": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "mart_softmax_bwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp]),
     "mart_transpose_bf16": (i32, [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp]),

@@ -58,6 +58,7 @@ class UnimoEngine:
         self.overlap_wgrad = os.environ.get("MART_OVERLAP_WGRAD", "1") == "1"   # weight-gradient GEMMs on a side stream (+2.5 % step rate)
         self._side: Optional[torch.cuda.Stream] = None
         self._side_busy = False
+        self.fused_fusion = os.environ.get("MART_FUSION_FUSED", "1") == "1"   # BertFusion as one kernel per direction where the shape allows
         self.two_stream = os.environ.get("MART_TWO_STREAM", "1") == "1"   # text layers on their own stream (+3 % step rate)
         self._tstream: Optional[torch.cuda.Stream] = None
         # Host run-ahead bound.  Blocks that side-stream kernels touched (record_stream) return to the caching allocator only
@@ -279,14 +280,16 @@ class UnimoEngine:
                 fus = probs = visT = None
                 if l >= self.fuse_from:                                   # BertFusion.forward, modeling_unimo.py:400-414
                     self._text_wait(ev_vis)
-                    scores = _e((Mt, Nvp), F32, dev)
-                    ops.gemm_nt(tctx, x2b, scores, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
-                    probs = _e((Mt, Nvp), BF, dev)
-                    ops.softmax_fwd(scores, probs, Mt, Nv)
-                    visT = _e((B * H, Nvp), BF, dev)
-                    ops.transpose_bf16(x2b, visT, Nv, H, Nvp, batch=B, stride_i=Nv * H, stride_o=H * Nvp)
-                    fus = _e((Mt, H), BF, dev)
-                    ops.gemm_nt(probs, visT, fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
+                    probs, visT, fus = _e((Mt, Nvp), BF, dev), None, _e((Mt, H), BF, dev)
+                    if self.fused_fusion and ops.fusion_supported(Lq, Nv, H):
+                        ops.fusion_fwd(tctx, x2b, fus, probs, B, Lq, Nv, H)        # scores / softmax / probs @ visual in one kernel
+                    else:
+                        scores = _e((Mt, Nvp), F32, dev)
+                        ops.gemm_nt(tctx, x2b, scores, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
+                        ops.softmax_fwd(scores, probs, Mt, Nv)
+                        visT = _e((B * H, Nvp), BF, dev)
+                        ops.transpose_bf16(x2b, visT, Nv, H, Nvp, batch=B, stride_i=Nv * H, stride_o=H * Nvp)
+                        ops.gemm_nt(probs, visT, fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
                 so = _e((Mt, H), BF, dev)
                 w, b = self._lin(t + "attention.output.dense")
                 ops.gemm_nt(tctx, w, so, bias=b)
@@ -411,31 +414,37 @@ class UnimoEngine:
                     self._wgrad(dzt, s["fus"], t + "intermediate.fusion_dense.weight", t + "intermediate.fusion_dense.bias")
                     dfus = _e((Mt, H), BF, dev)
                     ops.gemm_nt(dzt, st.wt(f"t{l}.fus"), dfus)
-                    dprobs = _e((Mt, Nvp), F32, dev)
-                    ops.gemm_nt(dfus, s["visb"], dprobs, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
-                    dsc = _e((Mt, Nvp), BF, dev)
-                    ops.softmax_bwd(s["probs"], dprobs, dsc, Mt, Nv)
-                    dctx_fus = _e((Mt, H), BF, dev)
-                    ops.gemm_nt(dsc, s["visT"], dctx_fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
-                    # d(vis) = dS^T ctx + P^T d(fus), accumulated into the vision-stream gradient
-                    if Lq % 64 == 0:
-                        # one batched NT product with two K segments and the fp32 accumulate fused as residual: the short
-                        # contraction (Lq) makes the transposed-operand form ~2.5x cheaper than two split-1 TN launches with
-                        # 65 k atomics per workgroup
-                        dscT, prT = _e((B * Nv, Lq), BF, dev), _e((B * Nv, Lq), BF, dev)
-                        ops.transpose_bf16(dsc, dscT, Lq, Nv, Lq, batch=B, stride_i=Lq * Nvp, stride_o=Nv * Lq)
-                        ops.transpose_bf16(s["probs"], prT, Lq, Nv, Lq, batch=B, stride_i=Lq * Nvp, stride_o=Nv * Lq)
-                        ctxT, dfT = _e((B * H, Lq), BF, dev), _e((B * H, Lq), BF, dev)
-                        ops.transpose_bf16(s["ctx"], ctxT, Lq, H, Lq, batch=B, stride_i=Lq * H, stride_o=H * Lq)
-                        ops.transpose_bf16(dfus, dfT, Lq, H, Lq, batch=B, stride_i=Lq * H, stride_o=H * Lq)
-                        self._text_wait(ev_vdone)                              # dxv holds the gradient left by vision layer l+1
-                        ops.gemm_nt(dscT, ctxT, dxv, A2=prT, B2=dfT, M=Nv, N=H, batch=B, stride_a=Nv * Lq, stride_b=H * Lq,
-                                    stride_c=Nv * H, stride_aux=Nv * H, res_f32=dxv, C2=dxvb)     # ... and refreshes the bf16 copy
+                    if s["visT"] is None:                                          # fused kernel ran forward: its backward twin
+                        dctx_fus = _e((Mt, H), BF, dev)
+                        self._text_wait(ev_vdone)                                  # dxv holds the gradient left by vision layer l+1
+                        ops.fusion_bwd(s["ctx"], s["visb"], dfus, s["probs"], dctx_fus, dxv, dxvb, B, Lq, Nv, H)   # d(vis) added in place, bf16 copy refreshed
                         dxvb_fresh = True
                     else:
-                        self._text_wait(ev_vdone)
-                        ops.gemm_tn(dsc, s["ctx"], dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
-                        ops.gemm_tn(s["probs"], dfus, dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
+                        dprobs = _e((Mt, Nvp), F32, dev)
+                        ops.gemm_nt(dfus, s["visb"], dprobs, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
+                        dsc = _e((Mt, Nvp), BF, dev)
+                        ops.softmax_bwd(s["probs"], dprobs, dsc, Mt, Nv)
+                        dctx_fus = _e((Mt, H), BF, dev)
+                        ops.gemm_nt(dsc, s["visT"], dctx_fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
+                        # d(vis) = dS^T ctx + P^T d(fus), accumulated into the vision-stream gradient
+                        if Lq % 64 == 0:
+                            # one batched NT product with two K segments and the fp32 accumulate fused as residual: the short
+                            # contraction (Lq) makes the transposed-operand form ~2.5x cheaper than two split-1 TN launches with
+                            # 65 k atomics per workgroup
+                            dscT, prT = _e((B * Nv, Lq), BF, dev), _e((B * Nv, Lq), BF, dev)
+                            ops.transpose_bf16(dsc, dscT, Lq, Nv, Lq, batch=B, stride_i=Lq * Nvp, stride_o=Nv * Lq)
+                            ops.transpose_bf16(s["probs"], prT, Lq, Nv, Lq, batch=B, stride_i=Lq * Nvp, stride_o=Nv * Lq)
+                            ctxT, dfT = _e((B * H, Lq), BF, dev), _e((B * H, Lq), BF, dev)
+                            ops.transpose_bf16(s["ctx"], ctxT, Lq, H, Lq, batch=B, stride_i=Lq * H, stride_o=H * Lq)
+                            ops.transpose_bf16(dfus, dfT, Lq, H, Lq, batch=B, stride_i=Lq * H, stride_o=H * Lq)
+                            self._text_wait(ev_vdone)                              # dxv holds the gradient left by vision layer l+1
+                            ops.gemm_nt(dscT, ctxT, dxv, A2=prT, B2=dfT, M=Nv, N=H, batch=B, stride_a=Nv * Lq, stride_b=H * Lq,
+                                        stride_c=Nv * H, stride_aux=Nv * H, res_f32=dxv, C2=dxvb)     # ... and refreshes the bf16 copy
+                            dxvb_fresh = True
+                        else:
+                            self._text_wait(ev_vdone)
+                            ops.gemm_tn(dsc, s["ctx"], dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
+                            ops.gemm_tn(s["probs"], dfus, dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
                     ev_tfus = self._text_record()
                 ds1, dso = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
                 ops.ln_bwd(dy_f32=ds2, dy_bf16=da2, s=s["s1"], mean=s["m1"], rstd=s["r1"], gamma=st.m(t + "attention.output.LayerNorm.weight"), M=Mt, H=H,

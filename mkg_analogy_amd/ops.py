@@ -231,6 +231,27 @@ def attn_fwd_f32(*, q, k, v, ctx, B, nh, D, Sq, Sk, scale, pk=None, pv=None, Lp=
     L.check(L.lib().mart_attn_fwd_f32(C.byref(d), _stream()), "mart_attn_fwd_f32")
 
 
+def fusion_supported(Lq, Nv, H) -> bool:
+    return bool(L.lib().mart_fusion_supported(int(Lq), int(Nv), int(H)))
+
+
+def fusion_fwd(q, v, out, probs, B, Lq, Nv, H):
+    """BertFusion forward in one kernel (modeling_unimo.py:400-414): out = softmax(q v^T) v, probs saved for the backward pass."""
+    d = L.FusionFwd()
+    d.q, d.ldq, d.v, d.ldv, d.out, d.ldo, d.probs, d.ldp = _p(q), _rows2d(q), _p(v), _rows2d(v), _p(out), _rows2d(out), _p(probs), _rows2d(probs)
+    d.B, d.Lq, d.Nv, d.H = B, Lq, Nv, H
+    L.check(L.lib().mart_fusion_fwd(C.byref(d), _stream()), "mart_fusion_fwd")
+
+
+def fusion_bwd(q, v, dout, probs, dq, dv_f32, dv_bf16, B, Lq, Nv, H):
+    d = L.FusionBwd()
+    d.q, d.ldq, d.v, d.ldv, d.dout, d.lddo, d.probs, d.ldp = _p(q), _rows2d(q), _p(v), _rows2d(v), _p(dout), _rows2d(dout), _p(probs), _rows2d(probs)
+    d.dq, d.lddq, d.dv_f32, d.lddv = _p(dq), _rows2d(dq), _p(dv_f32), _rows2d(dv_f32)
+    d.dv_bf16, d.lddvb = _p(dv_bf16), (_rows2d(dv_bf16) if dv_bf16 is not None else 0)
+    d.B, d.Lq, d.Nv, d.H = B, Lq, Nv, H
+    L.check(L.lib().mart_fusion_bwd(C.byref(d), _stream()), "mart_fusion_bwd")
+
+
 def softmax_fwd(scores, probs, R, Cc):
     L.check(L.lib().mart_softmax_fwd(_p(scores), _rows2d(scores), _p(probs), _rows2d(probs), R, Cc, _stream()), "mart_softmax_fwd")
 

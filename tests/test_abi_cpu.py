@@ -37,7 +37,7 @@ def test_descriptor_layouts_match_header(built):
     txt = open(os.path.join(ROOT, "include", "mart_hip.h")).read()
     for cname, cls in (("mart_gemm_nt_desc", built.GemmNT), ("mart_gemm_tn_desc", built.GemmTN), ("mart_ln_fwd_desc", built.LnFwd),
                        ("mart_ln_bwd_desc", built.LnBwd), ("mart_text_embed_desc", built.TextEmbed), ("mart_attn_fwd_desc", built.AttnFwd),
-                       ("mart_adamw_desc", built.AdamW)):
+                       ("mart_adamw_desc", built.AdamW), ("mart_fusion_fwd_desc", built.FusionFwd), ("mart_fusion_bwd_desc", built.FusionBwd)):
         end = txt.index("} " + cname + ";")
         body = txt[txt.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
@@ -64,7 +64,8 @@ def test_descriptor_sizes_match_a_c_compiler(built, tmp_path):
         pytest.skip("no gcc")
     pairs = [("mart_gemm_nt_desc", built.GemmNT), ("mart_gemm_tn_desc", built.GemmTN), ("mart_ln_fwd_desc", built.LnFwd),
              ("mart_ln_bwd_desc", built.LnBwd), ("mart_text_embed_desc", built.TextEmbed), ("mart_attn_fwd_desc", built.AttnFwd),
-             ("mart_attn_bwd_desc", built.AttnBwd), ("mart_adamw_desc", built.AdamW), ("mart_attn_f32_desc", built.AttnF32)]
+             ("mart_attn_bwd_desc", built.AttnBwd), ("mart_adamw_desc", built.AdamW), ("mart_attn_f32_desc", built.AttnF32),
+             ("mart_fusion_fwd_desc", built.FusionFwd), ("mart_fusion_bwd_desc", built.FusionBwd)]
     src = tmp_path / "sz.c"
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mart_hip.h"', 'int main(void) {']
     for cname, cls in pairs:
