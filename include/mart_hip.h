@@ -62,6 +62,9 @@ typedef struct {
   int preact_grad;                                                /* preact receives act'(z) rather than z (needs preact and act) */
   int b_blocked;                                                  /* B (and B2) stored tile-blocked [N/256][K/64][256][64] (mart_block_table): every LDS-DMA stage of the weight
                                                                      operand is one contiguous 32 KB run instead of 256 strided 128-B rows; needs N % 256 == 0, no b_rows */
+  int a_src_rows, b_src_rows;                                     /* with a_rows / b_rows: number of rows of the table the indices point into (the kernel forms 32-bit
+                                                                     element offsets row * ld, so src_rows * ld must stay below 2^32; checked when stated, 0 = the caller
+                                                                     vouches for it).  Without a gather the same check uses M * lda / N * ldb. */
 } mart_gemm_nt_desc;
 int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream);
 

@@ -24,7 +24,7 @@ class GemmNT(C.Structure):
                 ("batch", i32), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64), ("stride_aux", i64),
                 ("bias", vp), ("bias2", vp), ("bias_by_brow", i32), ("act", i32), ("preact", vp),
                 ("mulz", vp), ("mul_act", i32), ("res_f32", vp), ("res_bf16", vp), ("ldres", i32),
-                ("alpha", f32), ("C", vp), ("ldc", i32), ("c_f32", i32), ("C2", vp), ("ldc2", i32), ("tile_cfg", i32), ("preact_grad", i32), ("b_blocked", i32)]
+                ("alpha", f32), ("C", vp), ("ldc", i32), ("c_f32", i32), ("C2", vp), ("ldc2", i32), ("tile_cfg", i32), ("preact_grad", i32), ("b_blocked", i32), ("a_src_rows", i32), ("b_src_rows", i32)]
 
 
 class GemmTN(C.Structure):

@@ -840,8 +840,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   MART_CHECK(!d->preact_grad || (d->preact && d->act != ACT_NONE), "gemm_nt: preact_grad needs preact and an activation");
   MART_CHECK(d->mul_act >= ACT_NONE && d->mul_act <= ACT_STORED && (d->mul_act == ACT_NONE || d->mulz), "gemm_nt: bad mul_act");
   MART_CHECK(!d->b_blocked || (d->N % 256 == 0 && !d->b_rows && (d->batch <= 1 || d->stride_b == 0)), "gemm_nt: b_blocked needs N % 256 == 0, no b_rows, shared B");
-  MART_CHECK((long long)d->M * d->lda < (1LL << 32) && (long long)d->N * d->ldb < (1LL << 32) || d->a_rows || d->b_rows,
-             "gemm_nt: operand too large for 32-bit element offsets");
+  MART_CHECK((long long)(d->a_rows ? d->a_src_rows : d->M) * d->lda < (1LL << 32) && (long long)(d->b_rows ? d->b_src_rows : d->N) * d->ldb < (1LL << 32),
+             "gemm_nt: operand (or the table a row gather indexes: a_src_rows / b_src_rows) too large for 32-bit element offsets");
   Args a;
   a.A = (const bf16*)d->A; a.B = (const bf16*)d->B; a.A2 = (const bf16*)d->A2; a.B2 = (const bf16*)d->B2;
   a.lda = d->lda; a.ldb = d->ldb; a.M = d->M; a.N = d->N; a.K = d->K; a.K2 = d->K2;

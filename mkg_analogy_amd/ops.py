@@ -52,6 +52,8 @@ def gemm_nt(A, B, out, *, A2=None, B2=None, a_rows=None, b_rows=None, M=None, N=
     if A2 is not None:
         assert _rows2d(A2) == d.lda and _rows2d(B2) == d.ldb
     d.a_rows, d.b_rows = _p(a_rows), _p(b_rows)
+    d.a_src_rows = int(A.shape[-2]) if a_rows is not None else 0     # rows of the tables the gathers index (32-bit offset guard)
+    d.b_src_rows = int(B.shape[-2]) if b_rows is not None else 0
     d.batch, d.stride_a, d.stride_b, d.stride_c, d.stride_aux = batch, stride_a, stride_b, stride_c, stride_aux
     d.bias, d.bias2, d.bias_by_brow = _p(bias), _p(bias2), int(bias_by_brow)
     d.act, d.preact, d.mulz, d.mul_act = act, _p(preact), _p(mulz), mul_act
