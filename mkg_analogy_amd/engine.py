@@ -14,6 +14,7 @@ from __future__ import annotations
 from typing import Callable, Dict, Optional
 
 import collections
+import os
 
 import torch
 
@@ -87,7 +88,7 @@ class UnimoEngine:
             ops.gemm_tn(X, Y, out, **kw)
             return
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("MART_WGRAD_PRIO", "0")))
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
@@ -110,7 +111,7 @@ class UnimoEngine:
         if not self.two_stream:
             self._tstream = None
         elif self._tstream is None:
-            self._tstream = torch.cuda.Stream()
+            self._tstream = torch.cuda.Stream(priority=int(os.environ.get("MART_TEXT_PRIO", "0")))
         if self._tstream is not None:
             self._tstream.wait_stream(torch.cuda.current_stream())
 

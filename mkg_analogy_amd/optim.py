@@ -2,6 +2,8 @@
 (reference: lit_models/transformer.py:224-241; torch.optim.AdamW and HF get_linear_schedule_with_warmup semantics)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -76,7 +78,7 @@ class FusedAdamW(torch.optim.Optimizer):
             self._launch(j)
             return
         if self._stream is None:
-            self._stream = torch.cuda.Stream()
+            self._stream = torch.cuda.Stream(priority=int(os.environ.get("MART_OPT_PRIO", "0")))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self._stream.wait_event(ev)
