@@ -407,3 +407,58 @@ def test_teacher_forced_layers_plain_weights():
                 print(f"   param grad {name}: rel-L2 {err:.3e}")
             assert err < tol, (name, err)
     print(f"   worst per-layer parameter-gradient rel-L2 (teacher-forced): {worst:.3e}")
+
+
+def test_full_bench_batch_forward_vs_oracle():
+    """BASELINE configs[1] at its FULL size -- all 256 examples of bench.py's rank-0 batch, P=196, L=64 (100 608 vision tokens: every
+    tile of every launch is a full-size tile of the benchmark) -- forward pass of the bf16 training path and of the fp32-accurate
+    path against the fp32 CPU oracle run on this box's host cores (no gradient: ~1 minute).  The oracle is pinned to the reference on
+    the first 32 examples of this very batch by G7 (tests/test_oracle_vs_golden.py); conditioned weights, as in G7's absolute test."""
+    g = _load("g7_bench_cond")
+    model, lit, cfg = _product(g)
+    from mkg_analogy_amd import data_synth as D
+    B, L = int(g["batch_total"]), int(g["L"])
+    assert B == 256
+    batch = D.make_batch(B, L, seed=int(g["batch_seed"]))
+    ids = torch.tensor(cfg["analogy_entity_ids"])
+    vc = O.VisionCfg(patch_size=int(g["patch"]))
+    tc = O.TextCfg(vocab_size=BASE + NE + NR + 1)
+    sd = O.init_relation_word(O.condition_weights(O.init_params(vc, O.TextCfg(vocab_size=BASE + NE + NR), seed=int(g["weight_seed"]))),
+                              cfg["analogy_relation_ids"])
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        ml_ref = []
+        for s in range(0, B, 32):                                   # the oracle in slices (its activations are fp32 on the host); per-example independent in eval mode
+            sl = slice(s, s + 32)
+            _, tr = O.forward(sd, vc, tc, batch["input_ids"][sl], batch["attention_mask"][sl], batch["token_type_ids"][sl],
+                              batch["pixel_values"][sl], batch["sep_idx"][sl], train=False)
+            _, ml = O.finetune_loss(sd, tr, batch["input_ids"][sl], batch["label"][sl], batch["rel_idx"][sl], batch["q_head_idx"][sl],
+                                    batch["a_head_idx"][sl], ids, alpha=0.43)
+            ml_ref.append(ml.float())
+        ml_ref = torch.cat(ml_ref)
+    assert float((ml_ref[:32] - torch.from_numpy(g["mask_logits"])).abs().max()) < 2e-4          # the slice G7 pins to the reference
+    gb = {k: v.cuda() for k, v in batch.items()}
+    ar = torch.arange(B, device="cuda")
+    _, mi = (gb["input_ids"] == 103).nonzero(as_tuple=True)
+    model.eval()
+    keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
+
+    def forward():
+        with torch.no_grad():
+            out, _ = model(**{k: gb[k] for k in keys}, return_dict=True)
+            return out.logits[ar, mi][:, ids.cuda()].float().cpu()
+
+    ml = forward()
+    e_l, rms = float((ml - ml_ref).abs().max()), float((ml - ml_ref).pow(2).mean().sqrt())
+    model.set_precision("fp32")
+    ml32 = forward()
+    model.set_precision("bf16")
+    e32 = float((ml32 - ml_ref).abs().max())
+    rank = lambda x: (x > x[torch.arange(B), batch["label"]][:, None]).sum(1) + 1
+    same32 = int((rank(ml32) == rank(ml_ref)).sum())
+    print(f"\nB=256 P=196: bf16 path max|dlogit| {e_l:.3e} rms {rms:.3e}; fp32-accurate path max|dlogit| {e32:.3e}, {same32}/256 ranks identical "
+          f"(logit scale {float(ml_ref.abs().max()):.2f})")
+    assert e32 < 1e-3 and rms < 5e-3 and e_l < 3e-2
+    lab = ml_ref[torch.arange(B), batch["label"]]
+    near = ((ml_ref - lab[:, None]).abs() < 2 * e32).sum(1) - 1
+    assert bool(((rank(ml32) - rank(ml_ref)).abs() <= near).all())
