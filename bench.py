@@ -102,29 +102,35 @@ def cpu_step_rate(patch: int, L: int, threads: int, iters: int = 3, B: int = 8) 
     return B * iters / (time.time() - t0)
 
 
-def cpu_baseline(patch: int, L: int, iters: int = 3, B: int = 8, all_core_budget_s: int = 140):
-    """The CPU oracle (port of the reference algorithm, fp32, torch CPU ops) on this box's host cores, as SURVEY 8(d) defines it:
-    the same synthetic batch shape at B=8, one warm-up + three timed full fine-tune steps.  ``value`` is measured on at most 16
-    threads: at this batch size torch's CPU GEMMs stop scaling there and COLLAPSE under wider pools (measured on a 256-thread GPU
-    box: 2.61 examples/s on 16 threads, 2.05 on 32, 0.96 on 64, 0.44 on 128); ``cores`` = the threads actually used.  The
-    all-host-cores run the survey asks for is made in a child process with one warm-up + one timed step under a time budget and
-    reported next to it."""
-    allc = os.cpu_count() or 1
-    n = min(allc, 16)
-    out = {"value": round(cpu_step_rate(patch, L, n, iters, B), 3), "unit": "examples/s", "cores": n, "kind": "port",
-           "sample": f"CPU oracle (fp32 torch) full fine-tune step (fwd + loss + bwd + AdamW), B={B}, seq_len={L}, {196 if patch == 16 else 49} patches, "
-                     f"1 warm-up + {iters} timed, torch.set_num_threads({n}); host has {allc} logical cores"}
-    if allc > n:
-        import subprocess
+def usable_cpus() -> int:
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show 256 logical cores
+    and run the container under ``cpu.max = 1600000 100000``: 16 cores' worth of time, whatever the thread count)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-rate-only", str(allc), "--cpu-iters", "1", "--patch", str(patch), "--seq-len", str(L)],
-                               capture_output=True, text=True, timeout=all_core_budget_s)
-            out["all_cores"] = {"cores": allc, "value": round(float(r.stdout.strip().splitlines()[-1]), 3), "sample": "1 warm-up + 1 timed step"}
-        except subprocess.TimeoutExpired:
-            out["all_cores"] = {"cores": allc, "value": None, "note": f"1 + 1 steps on {allc} threads did not finish within {all_core_budget_s} s (oversubscribed intra-op pool)"}
-        except Exception as e:
-            out["all_cores"] = {"cores": allc, "value": None, "note": f"failed: {type(e).__name__}"}
-    return out
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(patch: int, L: int, iters: int = 3, B: int = 8):
+    """The CPU oracle (port of the reference algorithm, fp32, torch CPU ops) on ALL host cores this process may use, as SURVEY 8(d)
+    defines it: the same synthetic batch shape at B=8, one warm-up + three timed full fine-tune steps.  ``cores`` = the threads
+    used = the cgroup CPU quota of the container (16 on the GPU boxes, which list 256 logical cores: wider pools only get the same
+    16 cores' worth of time and thrash -- measured 2.61 examples/s on 16 threads, 2.05 on 32, 0.96 on 64, 0.44 on 128)."""
+    n = usable_cpus()
+    return {"value": round(cpu_step_rate(patch, L, n, iters, B), 3), "unit": "examples/s", "cores": n, "kind": "port",
+            "sample": f"CPU oracle (fp32 torch) full fine-tune step (fwd + loss + bwd + AdamW), B={B}, seq_len={L}, {196 if patch == 16 else 49} patches, "
+                      f"1 warm-up + {iters} timed, torch.set_num_threads({n}) = every core the container may use "
+                      f"(host lists {os.cpu_count()} logical cores, cgroup quota / affinity allow {n})"}
 
 
 class KernelTimer:
