@@ -134,11 +134,12 @@ def cpu_baseline(patch: int, L: int, iters: int = 3, B: int = 8):
 
 
 class KernelTimer:
-    """HIP-event timing of every launch of the three MFMA kernel families (on the stream each one is launched on):
-    gemm_nt (the dominant kernel), gemm_tn (weight gradients) and the attention kernels."""
+    """HIP-event timing of every launch of the three MFMA kernel families (on the stream each one is launched on): gemm_nt (the
+    dominant kernel), gemm_tn (weight gradients) and the attention kernels -- and of the largest HBM-bound family, LayerNorm forward /
+    backward, with its algorithmic bytes (every operand once)."""
 
     def __init__(self, ops):
-        self.ops, self.orig, self.rec = ops, {n: getattr(ops, n) for n in ("gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd")}, []
+        self.ops, self.orig, self.rec = ops, {n: getattr(ops, n) for n in ("gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "ln_fwd", "ln_bwd")}, []
 
     def _wrap(self, name, work):
         orig = self.orig[name]
@@ -181,6 +182,13 @@ class KernelTimer:
                 fam = ("attn_fwd" if mult == 1 else "attn_bwd") + ("_vision" if kw["Sq"] > 128 else "_text")
                 return fam, mult * 4.0 * kw["B"] * kw["nh"] * S * 64, 0.0
             return f
+        def ln(which, sizes):
+            def f(**kw):
+                n = float(kw["M"]) * kw["H"]
+                return which + ("_vision" if kw["M"] > 50000 else "_text"), 0.0, sum(n * sz for key, sz in sizes if kw.get(key) is not None)
+            return f
+        self.ops.ln_fwd = self._wrap("ln_fwd", lambda **kw: ln("ln_fwd", (("x_f32", 4), ("y_bf16", 2), ("s_out", 4), ("out_f32", 4), ("out_bf16", 2)))(**kw))
+        self.ops.ln_bwd = self._wrap("ln_bwd", lambda **kw: ln("ln_bwd", (("dy_f32", 4), ("dy_bf16", 2), ("s", 4), ("add_f32", 4), ("ds_f32", 4), ("ds_bf16", 2)))(**kw))
         self.ops.gemm_nt = self._wrap("gemm_nt", nt)
         self.ops.gemm_tn = self._wrap("gemm_tn", tn)
         self.ops.attn_fwd = self._wrap("attn_fwd", lambda **kw: att(1)(**kw))
@@ -311,10 +319,16 @@ def main():
             c, f, m, _ = fam.get(key, [0, 0.0, 0.0, 0.0])
             return None if not c or m <= 0 else {"kernel": name, "launches_per_step": c, "ms_per_step": round(m, 3), "achieved": round(f / (m * 1e-3) / 1e12, 1),
                                                  "unit": "TFLOP/s", "frac": round(f / (m * 1e-3) / 1e12 / bound_tf, 4)}
+        def hbmrow(key, name):
+            c, _, m, by = fam.get(key, [0, 0.0, 0.0, 0.0])
+            return None if not c or m <= 0 else {"kernel": name, "bound": "hbm", "launches_per_step": c, "ms_per_step": round(m, 3), "achieved": round(by / (m * 1e-3) / 1e12, 2),
+                                                 "peak": 8.0, "unit": "TB/s", "frac": round(by / (m * 1e-3) / 8e12, 4), "algorithmic_mb_per_launch": round(by / c / 1e6, 1)}
         others = [r for r in (famrow("gemm_tn", "gemm_tn8_kernel + tn_reduce_k (weight / bias gradients, deterministic split reduction)"),
                               famrow("attn_fwd_vision", "attn_fwd_k<vision> (393 queries x 393 / 457 keys, d 64)"),
                               famrow("attn_bwd_vision", "attn_bwd_fused_k <vision> (one workgroup per head: dQ, dK, dV in one pass; algorithmic flops = 2 x forward)"),
-                              famrow("gemm_nt_128", "gemm_nt_kernel<128,128,2,2> (small products: fusion, head, short grids)")) if r]
+                              famrow("gemm_nt_128", "gemm_nt_kernel<128,128,2,2> (small products: head, short grids)"),
+                              hbmrow("ln_bwd_vision", "ln_bwd_k (vision stream: dy bf16 + x f32 + residual gradient f32 in, f32 + bf16 out)"),
+                              hbmrow("ln_fwd_vision", "ln_fwd_k (vision stream: x f32 in, bf16 out)")) if r]
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,256,2,4> (bf16 MFMA 32x32x16 NT GEMM, 8-phase K loop, fused epilogues)", "achieved": round(ach, 1),
                 "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": round(by / max(n, 1)), "launches_per_step": n, "ms_per_step": round(kms, 3),
