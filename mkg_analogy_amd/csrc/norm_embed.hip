@@ -5,6 +5,14 @@
 #include "mart_hip.h"
 
 namespace {
+// Streaming hints of the LayerNorm kernels.  bit 0: nontemporal loads in ln_fwd, bit 1: nontemporal f32 stores, bit 2: nontemporal bf16
+// stores.  Measured in the step (same box, pipelined ln_bwd): 0 -> 93.0 ms, 1 -> 92.6, 2 -> 92.55, 3 -> 92.3; the bf16 outputs are the next
+// GEMM's A operand and stay cacheable.
+#ifndef LN_NT
+#define LN_NT 3
+#endif
+template <typename T> __device__ __forceinline__ T ldx(const T* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+template <typename T> __device__ __forceinline__ void stx(T* p, T v, bool nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
 constexpr int WPB = 4;            // waves (rows in flight) per workgroup
 constexpr int TPB = 64 * WPB;
 constexpr int VMAX_ALL = 4;       // float4 per lane cached in registers -> H <= 1024 (kernels are instantiated for 3 = H 768, and 4)
@@ -32,9 +40,9 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
         const int c = (v * 64 + lane) * 4;
         const long long o = (long long)m * p.H + c;
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (p.x_f32) t = *(const f32x4*)(p.x_f32 + o);
+        if (p.x_f32) t = ldx((const f32x4*)(p.x_f32 + o), (LN_NT & 1) != 0);
         if (yb) {
-          f32x4 y = bf4_to_f4(*(const bf16x4*)(yb + o));
+          f32x4 y = bf4_to_f4(ldx((const bf16x4*)(yb + o), (LN_NT & 1) != 0));
           if (p.p_drop > 0.f) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? y[e] * inv_keep : 0.f;
@@ -43,7 +51,7 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
         }
         x[v] = t;
         sum += t[0] + t[1] + t[2] + t[3];
-        if (p.s_out) *(f32x4*)(p.s_out + o) = t;
+        if (p.s_out) stx((f32x4*)(p.s_out + o), t, (LN_NT & 2) != 0);
       }
     }
     const float mean = wave_sum(sum) / (float)p.H;
@@ -64,10 +72,66 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
         f32x4 g = *(const f32x4*)(p.gamma + c), b = *(const f32x4*)(p.beta + c), y;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = (x[v][e] - mean) * rstd * g[e] + b[e];
-        if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
-        if (p.out_bf16) *(bf16x4*)((bf16*)p.out_bf16 + o) = f4_to_bf4(y);
+        if (p.out_f32) stx((f32x4*)(p.out_f32 + o), y, (LN_NT & 2) != 0);
+        if (p.out_bf16) stx((bf16x4*)((bf16*)p.out_bf16 + o), f4_to_bf4(y), (LN_NT & 4) != 0);
       }
   }
+}
+
+// ---- the two LayerNorm shapes of the vision stream (24 launches each per step, 100 608 rows), straight-line and software-pipelined.
+// The general kernels take every operand as an option: each `if (p.x)` around a load or a store is a join at which the compiler can no
+// longer count the outstanding memory operations and waits vmcnt(0) -- which also drains the row that was prefetched.  Here the operand set
+// is fixed, rows past the end are clamped duplicates of the last row (same values to the same addresses; their dgamma / dbeta share is
+// multiplied by 0), every wave runs the same trip count, and the waits are counted: two rows are really in flight per wave.
+template <int VMAX>
+__global__ __launch_bounds__(TPB) void ln_fwd_fast_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                     int M, bf16* __restrict__ out, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  constexpr int H = VMAX * 256;
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * WPB;
+  f32x4 gam[VMAX], bet[VMAX];
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) { gam[v] = *(const f32x4*)(gamma + (v * 64 + lane) * 4); bet[v] = *(const f32x4*)(beta + (v * 64 + lane) * 4); }
+  const int iters = (M + nwaves - 1) / nwaves;
+  float keep_mean = 0.f, keep_rstd = 0.f;                 // lane k keeps the statistics of the wave's k-th row (written after the loop: no store under a lane predicate inside it)
+  auto row_of = [&](int k) { return min(wave_g + k * nwaves, M - 1); };
+  auto fetch = [&](int k, f32x4 (&r)[VMAX]) {
+    const float* src = x + (long long)row_of(k) * H + lane * 4;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) r[v] = __builtin_nontemporal_load((const f32x4*)(src + v * 256));
+  };
+  auto process = [&](int k, const f32x4 (&r)[VMAX]) {
+    float sum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) sum += r[v][0] + r[v][1] + r[v][2] + r[v][3];
+    const float mean = wave_sum(sum) * (1.f / H);
+    float sq = 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = r[v][e] - mean; sq += d * d; }
+    const float rstd = rsqrtf(wave_sum(sq) * (1.f / H) + eps);
+    keep_mean = lane == (k & 63) ? mean : keep_mean;
+    keep_rstd = lane == (k & 63) ? rstd : keep_rstd;
+    bf16* dst = out + (long long)row_of(k) * H + lane * 4;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) {
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (r[v][e] - mean) * rstd * gam[v][e] + bet[v][e];
+      *(bf16x4*)(dst + v * 256) = f4_to_bf4(y);
+    }
+  };
+  f32x4 ra[VMAX], rb[VMAX];
+  fetch(0, ra);
+  for (int k = 0; k < iters; k += 2) {
+    fetch(k + 1, rb);
+    process(k, ra);
+    fetch(k + 2, ra);
+    process(k + 1, rb);
+  }
+  if (lane < iters && wave_g + lane * nwaves < M) { mean_o[wave_g + lane * nwaves] = keep_mean; rstd_o[wave_g + lane * nwaves] = keep_rstd; }   // iters <= 64 (launcher)
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -86,30 +150,35 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
     dg[v] = f32x4{0.f, 0.f, 0.f, 0.f}; db[v] = dg[v]; gam[v] = dg[v];
     if (v < nv) gam[v] = *(const f32x4*)(p.gamma + (v * 64 + lane) * 4);
   }
-  for (int m = wave_g; m < p.M; m += nwaves) {
-    const float mean = p.mean[m], rstd = p.rstd[m];
-    f32x4 dy[VMAX], xh[VMAX], addv[VMAX];
-    float s1 = 0.f, s2 = 0.f;
-    // every operand of the row is requested up front (the residual-gradient add used to be loaded after the row
-    // reduction: one exposed HBM round trip per row); all of them are read once -> nontemporal
+  // Two rows in flight per wave: the operands of row m + nwaves are requested before row m is reduced and stored, so the wave always
+  // has a row's worth of loads outstanding (with one row at a time the loads of the next row were only issued after the stores of this
+  // one: 4.9 TB/s; a plain streaming kernel with the same read / write mix reaches 6.1-6.3 TB/s on this part, tools/copy_bw.hip).
+  struct Row { f32x4 add[VMAX], dyf[VMAX], s[VMAX]; bf16x4 dyh[VMAX]; float mean, rstd; };
+  auto fetch = [&](int m, Row& r) {
+    r.mean = p.mean[m]; r.rstd = p.rstd[m];
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
       if (v < nv) {
         const long long o = (long long)m * p.H + (v * 64 + lane) * 4;
-        addv[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.add_f32) addv[v] = __builtin_nontemporal_load((const f32x4*)(p.add_f32 + o));
+        r.add[v] = f32x4{0.f, 0.f, 0.f, 0.f}; r.dyf[v] = r.add[v]; r.dyh[v] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        if (p.add_f32) r.add[v] = __builtin_nontemporal_load((const f32x4*)(p.add_f32 + o));
+        if (p.dy_f32) r.dyf[v] = __builtin_nontemporal_load((const f32x4*)(p.dy_f32 + o));
+        if (dyb) r.dyh[v] = __builtin_nontemporal_load((const bf16x4*)(dyb + o));
+        r.s[v] = __builtin_nontemporal_load((const f32x4*)(p.s + o));
       }
+  };
+  auto process = [&](int m, const Row& r) {
+    const float mean = r.mean, rstd = r.rstd;
+    f32x4 dy[VMAX], xh[VMAX];
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int v = 0; v < VMAX; ++v)
       if (v < nv) {
-        const long long o = (long long)m * p.H + (v * 64 + lane) * 4;
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        if (p.dy_f32) d = __builtin_nontemporal_load((const f32x4*)(p.dy_f32 + o));
-        if (dyb) d += bf4_to_f4(__builtin_nontemporal_load((const bf16x4*)(dyb + o)));
-        f32x4 s = __builtin_nontemporal_load((const f32x4*)(p.s + o));
+        f32x4 d = r.dyf[v];
+        if (dyb) d += bf4_to_f4(r.dyh[v]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float xhat = (s[e] - mean) * rstd;
+          float xhat = (r.s[v][e] - mean) * rstd;
           xh[v][e] = xhat;
           float g = d[e] * gam[v][e];
           s1 += g; s2 += g * xhat;
@@ -131,12 +200,24 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) dd[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? dd[e] * inv_keep : 0.f;
           }
-          *(bf16x4*)((bf16*)p.ds_bf16 + o) = f4_to_bf4(dd);
+          stx((bf16x4*)((bf16*)p.ds_bf16 + o), f4_to_bf4(dd), (LN_NT & 4) != 0);
         }
-        if (p.add_f32) ds += addv[v];
-        if (p.ds_f32) *(f32x4*)(p.ds_f32 + o) = ds;
-        if (p.ds_bf16 && p.bf16_total) *(bf16x4*)((bf16*)p.ds_bf16 + o) = f4_to_bf4(ds);
+        if (p.add_f32) ds += r.add[v];
+        if (p.ds_f32) stx((f32x4*)(p.ds_f32 + o), ds, (LN_NT & 2) != 0);
+        if (p.ds_bf16 && p.bf16_total) stx((bf16x4*)((bf16*)p.ds_bf16 + o), f4_to_bf4(ds), (LN_NT & 4) != 0);
       }
+  };
+  {
+    Row ra, rb;
+    int m = wave_g;
+    if (m < p.M) fetch(m, ra);
+    for (; m < p.M; m += 2 * nwaves) {
+      const int m2 = m + nwaves, m3 = m2 + nwaves;
+      if (m2 < p.M) fetch(m2, rb);
+      process(m, ra);
+      if (m3 < p.M) fetch(m3, ra);
+      if (m2 < p.M) process(m2, rb);
+    }
   }
   if (!p.dgamma && !p.dbeta) return;
 #pragma unroll
@@ -160,6 +241,88 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
       if (p.dgamma) atomicAdd(p.dgamma + c, a);
       if (p.dbeta) atomicAdd(p.dbeta + c, b);
     }
+  }
+}
+
+// vision-stream shape of the backward pass: dy bf16, x f32, residual gradient f32 in; f32 total + its bf16 copy out; dgamma / dbeta partials to the
+// workspace.  Straight-line and pipelined like ln_fwd_fast_k (rows past the end: clamped duplicates, weight 0 in dgamma / dbeta).
+template <int VMAX>
+__global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i, const float* __restrict__ gamma, int M, float* __restrict__ ds_f32, bf16* __restrict__ ds_bf16,
+                                                     float* __restrict__ ws) {
+  constexpr int H = VMAX * 256;
+  __shared__ float red[WPB][2][VMAX * 256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave_g = blockIdx.x * WPB + w;
+  const int nwaves = gridDim.x * WPB;
+  f32x4 dg[VMAX], db[VMAX], gam[VMAX];
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v) { dg[v] = f32x4{0.f, 0.f, 0.f, 0.f}; db[v] = dg[v]; gam[v] = *(const f32x4*)(gamma + (v * 64 + lane) * 4); }
+  const int iters = (M + nwaves - 1) / nwaves;
+  struct Row { f32x4 a[VMAX], s[VMAX]; bf16x4 d[VMAX]; float mean, rstd; };
+  auto row_of = [&](int k) { return min(wave_g + k * nwaves, M - 1); };
+  auto fetch = [&](int k, Row& r) {
+    const int m = row_of(k);
+    const long long o = (long long)m * H + lane * 4;
+    r.mean = mean_i[m]; r.rstd = rstd_i[m];
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) {
+      r.a[v] = __builtin_nontemporal_load((const f32x4*)(add + o + v * 256));
+      r.d[v] = __builtin_nontemporal_load((const bf16x4*)(dy + o + v * 256));
+      r.s[v] = __builtin_nontemporal_load((const f32x4*)(x + o + v * 256));
+    }
+  };
+  auto process = [&](int k, const Row& r) {
+    const float valid = wave_g + k * nwaves < M ? 1.f : 0.f;
+    f32x4 d[VMAX], xh[VMAX];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) {
+      d[v] = bf4_to_f4(r.d[v]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xhat = (r.s[v][e] - r.mean) * r.rstd;
+        xh[v][e] = xhat;
+        const float g = d[v][e] * gam[v][e];
+        s1 += g; s2 += g * xhat;
+        dg[v][e] += valid * (d[v][e] * xhat); db[v][e] += valid * d[v][e];
+      }
+    }
+    const float c1 = wave_sum(s1) * (1.f / H), c2 = wave_sum(s2) * (1.f / H);
+    const long long o = (long long)row_of(k) * H + lane * 4;
+#pragma unroll
+    for (int v = 0; v < VMAX; ++v) {
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = r.rstd * (d[v][e] * gam[v][e] - c1 - xh[v][e] * c2) + r.a[v][e];
+      __builtin_nontemporal_store(t, (f32x4*)(ds_f32 + o + v * 256));
+      *(bf16x4*)(ds_bf16 + o + v * 256) = f4_to_bf4(t);
+    }
+  };
+  {
+    Row ra, rb;
+    fetch(0, ra);
+    for (int k = 0; k < iters; k += 2) {
+      fetch(k + 1, rb);
+      process(k, ra);
+      fetch(k + 2, ra);
+      process(k + 1, rb);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VMAX; ++v)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[w][0][(v * 64 + lane) * 4 + e] = dg[v][e];
+      red[w][1][(v * 64 + lane) * 4 + e] = db[v][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += TPB) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < WPB; ++ww) { a += red[ww][0][c]; b += red[ww][1][c]; }
+    ws[((long long)blockIdx.x * 2 + 0) * H + c] = a;
+    ws[((long long)blockIdx.x * 2 + 1) * H + c] = b;
   }
 }
 
@@ -236,8 +399,8 @@ __global__ __launch_bounds__(TPB) void text_embed_k(mart_text_embed_desc p) {
           y[e] = (x[v][e] - mean) * rstd * g[e] + b[e];
           if (p.p_drop > 0.f) y[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? y[e] * inv_keep : 0.f;
         }
-        if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
-        if (p.out_bf16) *(bf16x4*)((bf16*)p.out_bf16 + o) = f4_to_bf4(y);
+        if (p.out_f32) stx((f32x4*)(p.out_f32 + o), y, (LN_NT & 2) != 0);
+        if (p.out_bf16) stx((bf16x4*)((bf16*)p.out_bf16 + o), f4_to_bf4(y), (LN_NT & 4) != 0);
       }
   }
 }
@@ -592,6 +755,18 @@ extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
   MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_fwd: H must be a multiple of 256 and <= 1024");
   MART_CHECK(d->gamma && d->beta && d->mean && d->rstd && (d->out_f32 || d->out_bf16), "ln_fwd: null pointer");
   MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "ln_fwd: bad dropout p");
+  static const int fast = getenv("MART_LN_FAST") ? atoi(getenv("MART_LN_FAST")) : 1;
+  static const int fcap = getenv("MART_LN_FWD_GRID") ? atoi(getenv("MART_LN_FWD_GRID")) : 512;   // 6.15 TB/s (768 / 1024 / 2048: 5.8-5.95)
+  if (fast && d->x_f32 && !d->y_bf16 && !d->s_out && !d->out_f32 && d->out_bf16 && d->p_drop == 0.f && (d->H == 768 || d->H == 1024) && d->M >= 4096) {
+    int g = (d->M + WPB - 1) / WPB;
+    if (g > fcap) g = fcap;
+    const int gmin = (d->M + WPB * 64 - 1) / (WPB * 64);          // at most 64 rows per wave (their statistics live in one register across the lanes)
+    if (g < gmin) g = gmin;
+    if (d->H == 768) hipLaunchKernelGGL(ln_fwd_fast_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, d->x_f32, d->gamma, d->beta, d->eps, d->M, (bf16*)d->out_bf16, d->mean, d->rstd);
+    else hipLaunchKernelGGL(ln_fwd_fast_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, d->x_f32, d->gamma, d->beta, d->eps, d->M, (bf16*)d->out_bf16, d->mean, d->rstd);
+    MART_LAUNCH_CHECK();
+    return 0;
+  }
   if (d->H <= 768) hipLaunchKernelGGL(ln_fwd_k<3>, dim3(row_grid(d->M)), dim3(TPB), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(ln_fwd_k<4>, dim3(row_grid(d->M)), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
@@ -602,12 +777,18 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_bwd: H must be a multiple of 256 and <= 1024");
   MART_CHECK(d->s && d->mean && d->rstd && d->gamma && (d->ds_f32 || d->ds_bf16), "ln_bwd: null pointer");
   int g = row_grid(d->M);
-  // 6 workgroups fit a CU (24.6 KB of static LDS each) and every workgroup ends with 2H contended atomics (dgamma, dbeta):
-  // grid = 3 per CU in ONE round measured best (768: 257 us; 1536: 262 us; 2048, i.e. 1.33 rounds: 288 us at M = 100608)
-  static int cap = getenv("MART_LN_BWD_GRID") ? atoi(getenv("MART_LN_BWD_GRID")) : 768;
+  // Two rows in flight per wave cost 206 VGPRs: two waves per SIMD, i.e. two 4-wave workgroups per CU -> grid = 512 is exactly ONE round
+  // (768, one and a half rounds: 4.65 TB/s; 512: 5.66 TB/s at M = 100608; the one-row kernel ran 4.97 TB/s at its best grid of 768)
+  static const int cap_env = getenv("MART_LN_BWD_GRID") ? atoi(getenv("MART_LN_BWD_GRID")) : 0;
+  static const int fastb = getenv("MART_LN_FAST") ? atoi(getenv("MART_LN_FAST")) : 1;
+  const bool fast_shape = fastb && d->dy_bf16 && !d->dy_f32 && d->add_f32 && d->ds_f32 && d->ds_bf16 && d->bf16_total && d->p_drop == 0.f && d->ws && d->dgamma && d->dbeta &&
+                          (d->H == 768 || d->H == 1024) && d->M >= 4096 && d->add_f32 != d->ds_f32;
+  const int cap = cap_env ? cap_env : 512;      // two workgroups per CU in one round: 6.1 TB/s for the straight-line kernel (768: 5.9, 384: 5.6, 256: 5.0), 5.66 for the general one
   if (g > cap) g = cap;
   MART_CHECK(!d->ws || d->ws_bytes >= (long long)g * 2 * d->H * (long long)sizeof(float), "ln_bwd: workspace too small (768 * 2 * H floats always suffice)");
-  if (d->H <= 768) hipLaunchKernelGGL(ln_bwd_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
+  if (fast_shape && d->H == 768) hipLaunchKernelGGL(ln_bwd_fast_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws);
+  else if (fast_shape) hipLaunchKernelGGL(ln_bwd_fast_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws);
+  else if (d->H <= 768) hipLaunchKernelGGL(ln_bwd_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(ln_bwd_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
   if (d->ws && (d->dgamma || d->dbeta)) {
