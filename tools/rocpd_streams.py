@@ -36,3 +36,11 @@ for g in sorted(big, key=lambda g: g[3])[:4]:
     for n, s, e, q in sel:
         if e > t0 and s < t1 and (s, e, n) not in main:
             print(f"    q{q} {(s - lo) / 1e6:8.3f} +{(e - s) / 1e3:7.1f} us  {short(n)}")
+# small-copy / fill kernels of the first of the two steps: when, on which queue, between which kernels
+step_end = lo + (hi - lo) // 2
+print("--- copy / fill / elementwise kernels in the first step:")
+prev = {}
+for n, s, e, q in sel:
+    if s < step_end and ("copyBuffer" in n or "fillBuffer" in n or "at6native" in n or "at_native" in n):
+        print(f"    q{q} t={(s - lo) / 1e6:8.3f} +{(e - s) / 1e3:6.1f} us {n[:70]}   after {short(prev.get(q, ''))}")
+    prev[q] = n
