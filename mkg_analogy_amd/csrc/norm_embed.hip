@@ -782,7 +782,8 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   static const int cap_env = getenv("MART_LN_BWD_GRID") ? atoi(getenv("MART_LN_BWD_GRID")) : 0;
   static const int fastb = getenv("MART_LN_FAST") ? atoi(getenv("MART_LN_FAST")) : 1;
   const bool fast_shape = fastb && d->dy_bf16 && !d->dy_f32 && d->add_f32 && d->ds_f32 && d->ds_bf16 && d->bf16_total && d->p_drop == 0.f && d->ws && d->dgamma && d->dbeta &&
-                          (d->H == 768 || d->H == 1024) && d->M >= 4096 && d->add_f32 != d->ds_f32;
+                          (d->H == 768 || d->H == 1024) && d->M >= 4096 &&
+                          d->add_f32 != d->ds_f32 && d->s != d->ds_f32 && d->dy_bf16 != d->ds_bf16;   // clamped duplicate rows re-read their inputs: no in-place operands
   const int cap = cap_env ? cap_env : 512;      // two workgroups per CU in one round: 6.1 TB/s for the straight-line kernel (768: 5.9, 384: 5.6, 256: 5.0), 5.66 for the general one
   if (g > cap) g = cap;
   MART_CHECK(!d->ws || d->ws_bytes >= (long long)g * 2 * d->H * (long long)sizeof(float), "ln_bwd: workspace too small (768 * 2 * H floats always suffice)");
