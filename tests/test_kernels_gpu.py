@@ -244,6 +244,46 @@ def test_layernorm_fwd_bwd(ops, eps):
     close(db, br.grad, 2e-3, 1e-4, "ln dbeta")
 
 
+@pytest.mark.parametrize("M", [4096, 4099, 33333])
+def test_layernorm_vision_stream_shapes(ops, M):
+    """The two operand sets of the vision stream take the straight-line, software-pipelined kernels (ln_fwd_fast_k: x f32 -> bf16;
+    ln_bwd_fast_k: dy bf16 + x + residual gradient -> f32 total + bf16 copy, dgamma / dbeta through the workspace) from 4096 rows up.
+    Ragged row counts exercise the clamped duplicate rows of the last round; compared with torch's fp32 layer_norm and with the general
+    kernels (MART_LN_FAST is read once per process, so the general path is reached through an operand set it does not take)."""
+    H, eps = 768, 1e-5
+    x = rnd(M, H, seed=11, dtype=F32, scale=2.0) + 0.3
+    gamma, beta = 1 + 0.1 * rnd(H, seed=12, dtype=F32), 0.1 * rnd(H, seed=13, dtype=F32)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ob = torch.empty(M, H, device=DEV, dtype=BF)
+    ops.ln_fwd(x_f32=x, gamma=gamma, beta=beta, eps=eps, M=M, H=H, mean=mean, rstd=rstd, out_bf16=ob)                    # fast
+    mean2, rstd2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    of2, ob2 = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV, dtype=BF)
+    ops.ln_fwd(x_f32=x, gamma=gamma, beta=beta, eps=eps, M=M, H=H, mean=mean2, rstd=rstd2, out_f32=of2, out_bf16=ob2)   # general (f32 output as well)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (H,), gr, br, eps)
+    close(ob, ref, 2e-2, 1e-2, "fast ln fwd bf16")
+    close(ob, ob2, 1e-2, 4e-3, "fast vs general forward (the statistics are summed with 1/H folded in: last-ulp differences before the bf16 rounding)")
+    close(mean, mean2, 1e-6, 1e-6, "row means"); close(rstd, rstd2, 1e-6, 1e-5, "row rstd")
+    dyb = rnd(M, H, seed=15)
+    add = rnd(M, H, seed=16, dtype=F32)
+    ref.backward(dyb.float())
+    ds, dsb = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV, dtype=BF)
+    dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_f32=add, ds_f32=ds, ds_bf16=dsb, bf16_total=True, dgamma=dg, dbeta=db)   # fast
+    close(ds, xr.grad + add, 1e-4, 1e-4, "fast ln bwd dx + add")
+    close(dsb, xr.grad + add, 2e-2, 1e-2, "fast ln bwd bf16 total")
+    close(dg, gr.grad, 2e-3, 1e-3, "fast ln dgamma")
+    close(db, br.grad, 2e-3, 1e-3, "fast ln dbeta")
+    ds2, dg2, db2 = torch.empty(M, H, device=DEV), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_f32=add, ds_f32=ds2, dgamma=dg2, dbeta=db2)                            # general (no bf16 copy)
+    close(ds, ds2, 1e-5, 1e-5, "fast vs general backward")
+    close(dg, dg2, 1e-5, 1e-4, "dgamma fast vs general"); close(db, db2, 1e-5, 1e-4, "dbeta fast vs general")
+    dg3, db3, ds3, dsb3 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.empty_like(ds), torch.empty_like(dsb)
+    ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_f32=add, ds_f32=ds3, ds_bf16=dsb3, bf16_total=True, dgamma=dg3, dbeta=db3)
+    assert torch.equal(dg, dg3) and torch.equal(db, db3) and torch.equal(ds, ds3) and torch.equal(dsb, dsb3), "run-to-run"
+
+
 def test_dropout_add_layernorm(ops):
     M, H, p, seed = 300, 768, 0.1, 1234567
     res = rnd(M, H, seed=1, dtype=F32)
