@@ -235,6 +235,8 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-rate-only", type=int, default=0, help=argparse.SUPPRESS)      # child process of cpu_baseline(): threads
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--train-only", action="store_true", help="skip the evaluation pass (Hits@1), the precision comparison and the alternate-head run: "
+                                                              "the process then launches nothing but training steps (rocprofv3 traces whose per-kernel averages are per training step)")
     a = ap.parse_args()
     if a.cpu_rate_only:
         print(cpu_step_rate(a.patch, a.seq_len, a.cpu_rate_only, a.cpu_iters), flush=True)
@@ -338,9 +340,9 @@ def main():
                 "achieved_with_wgrad_overlap": round(fl_ov / (kms_ov * 1e-3) / 1e12, 1) if kms_ov > 0 else None,
                 "avg_launch_ms_with_wgrad_overlap": round(kms_ov / max(n_ov, 1), 4), "other_kernels": others}
     # Hits@1 of the (untrained, random-init) model on the same batch -- reported to exercise the ranking eval path
-    metrics = tr.validate(lit, [batch])
+    metrics = tr.validate(lit, [batch]) if not a.train_only else {}
     parity = None
-    if world == 1 and a.model == "mkgformer" and not pre and not a.no_kernel_timing:
+    if world == 1 and a.model == "mkgformer" and not pre and not a.no_kernel_timing and not a.train_only:
         # the bf16 training path against the fp32-accurate evaluation path (engine_precise: held to the reference at 1e-3 on logits
         # in tests/test_parity_full_gpu.py) on THIS batch and THESE weights: mask-row logits over the scored entity ids, eval mode
         model.eval()
@@ -362,7 +364,7 @@ def main():
                   "median_abs_rank_diff": float((rk["bf16"] - rk["fp32"]).abs().float().median()), "entity_head": head,
                   "note": "plain N(0,0.02) weights: the unscaled fusion softmax of layers 8-11 makes the map chaotic (DESIGN section 5); per-layer parity is in tests/test_parity_full_gpu.py"}
     alt = None
-    if world == 1 and a.model == "mkgformer" and not pre and not a.no_kernel_timing:
+    if world == 1 and a.model == "mkgformer" and not pre and not a.no_kernel_timing and not a.train_only:
         # the other scoring head, timed briefly on the same network (the head is 0.03 % of the step's FLOPs either way)
         other = D.N_ANALOGY if head == D.N_ENT else D.N_ENT
         lit.analogy_entity_ids = D.data_config()["analogy_entity_ids"] if other == D.N_ANALOGY else list(range(D.BASE_VOCAB, D.BASE_VOCAB + D.N_ENT))

@@ -7,7 +7,7 @@ timeout 500 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_ou
 for mode in serial overlap; do
   if [ $mode = serial ]; then export MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0; else export MART_OVERLAP_WGRAD=1 MART_TWO_STREAM=1; fi
   rm -rf gpurun_out/prof_tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/prof_$mode.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --train-only > gpurun_out/prof_$mode.log 2>&1
   DB=$(find gpurun_out/prof_tmp -name "*.db" | head -1)
   python tools/rocpd_stats.py $DB > gpurun_out/${TAG}_bench_kernel_stats_$mode.csv
   tail -1 gpurun_out/prof_$mode.log | cut -c1-200
