@@ -55,10 +55,9 @@ typedef struct {
   float alpha;
   void* C; int ldc; int c_f32;
   void* C2; int ldc2;                                             /* optional bf16 copy; 0 -> ldc */
-  int tile_cfg;                                                   /* 0 auto (256x256 tiles from 128 tiles up and M > 128, else 128x128), 128, 256.
-                                                                     Measurement / test hooks, never used by the engine: 2560 BK=32 four-slot ring, 2561 256-tile with the
-                                                                     general epilogue, 2562 fast epilogue without the persistent loop, 999 / 9992 / 9993 timing experiments
-                                                                     (results are wrong on purpose), 70000+t start stagger of t x 10 ns per CU group */
+  int tile_cfg;                                                   /* 0 auto (256x256 tiles from 128 tiles up and M > 128, else 128x128), 128, 256; 2561 = 256-tile with the
+                                                                     general epilogue (test hook).  Anything else is rejected by the product library; the timing / A-B
+                                                                     experiment codes of tools/nt_harness exist only in -DMART_EXPERIMENTS builds of gemm_nt.hip */
   int preact_grad;                                                /* preact receives act'(z) rather than z (needs preact and act) */
   int b_blocked;                                                  /* B (and B2) stored tile-blocked [N/256][K/64][256][64] (mart_block_table): every LDS-DMA stage of the weight
                                                                      operand is one contiguous 32 KB run instead of 256 strided 128-B rows; needs N % 256 == 0, no b_rows */
@@ -74,7 +73,9 @@ int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream);
 typedef struct {
   const void* X; const void* Y; int ldx, ldy;                     /* bf16 */
   int M, NX, NY;
-  float* out; int ldo; const int32_t* out_rows;
+  float* out; int ldo; const int32_t* out_rows;                  /* out_rows: scatter of the NX result rows; the indices must be UNIQUE when a workspace
+                                                                     is given (the ordered reduction adds each row with a plain read-modify-write); the
+                                                                     atomic path tolerates repeats */
   float* colsum; int colsum_by_row;                               /* colsum index = out_rows[nx] when set */
   int batch; long long stride_x, stride_y, stride_o;
   int splits;                                                     /* 0 auto */
@@ -88,7 +89,7 @@ int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream);
 long long mart_gemm_tn_workspace_bytes(int M, int NX, int NY, int splits);
 
 /* ---------------------------------------------------------------- layer norm family
- * s = x_f32 (+ dropout(y_bf16, p)) ; out = LN(s) * gamma + beta.  nn.LayerNorm call sites
+ * s = x_f32 (+ dropout(y_bf16 | y_f32, p)) ; out = LN(s) * gamma + beta.  nn.LayerNorm call sites
  * modeling_unimo.py:509,518,711 (CLIP pre-LN, eps 1e-5), :390,477 (BERT post-LN with dropout+residual,
  * eps 1e-12), :975 (head transform LN). */
 typedef struct {
@@ -99,6 +100,7 @@ typedef struct {
   float* s_out;                                                   /* optional: the pre-LN sum (saved for bwd) */
   float* out_f32; void* out_bf16;                                 /* either may be NULL */
   float* mean; float* rstd;                                       /* [M] */
+  const float* y_f32;                                             /* optional: the dropped-out branch in f32 instead of y_bf16 (text layers in split precision) */
 } mart_ln_fwd_desc;
 int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream);
 
@@ -279,6 +281,10 @@ int mart_block_table(const void* src_bf16, void* dst_bf16, const int64_t* table,
  * mart_gemm_nt on two-term bf16 splits laid out K-concatenated (K' = 3K):  role 0 (activations) [hi|lo|hi],
  * role 1 (weights) [hi|hi|lo]  =>  hi*hi + lo*hi + hi*lo accumulated in fp32. */
 int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16 /* [rows, 3K] */, int rows, int K, int role, void* stream);
+/* ... of gathered source rows: dst row r = split(src[gather[r]]).  The scoring head of the TRAINING path runs on these too (mask rows of
+ * trans_hidden x the scored rows of the tied embedding, modeling_unimo.py:958): 2 x 768 x (B + ids) extra MFMA flops per step buy back the
+ * third of the bf16 logit error that the head alone contributed (tools/error_budget.py). */
+int mart_split_bf16x3_rows(const float* src, long long ld, const int32_t* gather, void* dst_bf16 /* [rows, 3K] */, int rows, int K, int role, void* stream);
 /* f32 twins of mart_patchify / mart_patchify_gather (index NULL: pixels are [B,2,3,S,S]; else table rows, -1 = zero image) and mart_vision_assemble */
 int mart_patchify_f32(const float* pixels_or_table, const int32_t* index, float* out, int B, int S, int p, void* stream);
 int mart_vision_assemble_f32(const float* patch, const float* cls, const float* pos, float* s, int B, int P, int H, int tail_shift, void* stream);

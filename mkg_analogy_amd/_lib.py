@@ -36,7 +36,7 @@ class GemmTN(C.Structure):
 
 class LnFwd(C.Structure):
     _fields_ = [("x_f32", vp), ("y_bf16", vp), ("p_drop", f32), ("seed", u64), ("gamma", vp), ("beta", vp), ("eps", f32),
-                ("M", i32), ("H", i32), ("s_out", vp), ("out_f32", vp), ("out_bf16", vp), ("mean", vp), ("rstd", vp)]
+                ("M", i32), ("H", i32), ("s_out", vp), ("out_f32", vp), ("out_bf16", vp), ("mean", vp), ("rstd", vp), ("y_f32", vp)]
 
 
 class LnBwd(C.Structure):
@@ -136,6 +136,7 @@ _SIGS = {
     "mart_transpose_table": (i32, [vp, vp, vp, i32, vp]),
     "mart_block_table": (i32, [vp, vp, vp, i32, vp]),
     "mart_split_bf16x3": (i32, [vp, i64, vp, i32, i32, i32, vp]),
+    "mart_split_bf16x3_rows": (i32, [vp, i64, vp, vp, i32, i32, i32, vp]),
     "mart_patchify_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "mart_vision_assemble_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mart_attn_fwd_f32": (i32, [vp, vp]),

@@ -269,7 +269,12 @@ __global__ __launch_bounds__(FT, 1) void fusion_fwd_k(mart_fusion_fwd_desc p, in
 // One launch per 64-query block (the host loops: the blocks of a batch element add into the same rows of the vision gradient, and
 // sequential launches keep that sum in a fixed order without atomics).
 template <int DT>
-__global__ __launch_bounds__(FT, 1) void fusion_bwd_k(mart_fusion_bwd_desc p, int qblock, int nbuf, int red_off, int dbg) {
+__global__ __launch_bounds__(FT, 1) void fusion_bwd_k(mart_fusion_bwd_desc p, int qblock, int nbuf, int red_off, int dbg_) {
+#ifdef MART_EXPERIMENTS
+  const int dbg = dbg_;                                  // timing knock-outs (harness builds only): 1 no dV loads, 2 no dV stores, 4 no B4, 8 no B3
+#else
+  constexpr int dbg = 0;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -449,15 +454,22 @@ extern "C" int mart_fusion_bwd(const mart_fusion_bwd_desc* d, void* stream) {
   MART_CHECK(pl.ok, "fusion_bwd: unsupported shape (mart_fusion_supported)");
   MART_CHECK(d->ldq >= d->H && d->ldv >= d->H && d->lddo >= d->H && d->lddq >= d->H && d->lddv >= d->H && d->ldq % 8 == 0 && d->ldv % 8 == 0 && d->lddo % 8 == 0 &&
              d->lddq % 4 == 0 && (!d->dv_bf16 || d->lddvb >= d->H), "fusion_bwd: row strides must cover H (ldq, ldv, lddo multiples of 8)");
-  MART_CHECK(d->ldp >= d->Nv && d->ldp % 8 == 0, "fusion_bwd: ldp must be a multiple of 8 >= Nv");
+  MART_CHECK(d->ldp >= d->Nv && d->ldp % 8 == 0 && d->ldp <= ((d->Nv + 63) / 64) * 64, "fusion_bwd: ldp must be a multiple of 8 in [Nv, 64 * ceil(Nv / 64)]");
   MART_CHECK(((uintptr_t)d->q | (uintptr_t)d->v | (uintptr_t)d->dout) % 16 == 0 && ((uintptr_t)d->dq | (uintptr_t)d->probs) % 8 == 0, "fusion_bwd: operands must be 16-byte aligned");
+  // the vision-stream gradient is read and written as f32x4 (and its bf16 copy as bf16x4) at columns that are multiples of 4
+  MART_CHECK(d->lddv % 4 == 0 && (uintptr_t)d->dv_f32 % 16 == 0, "fusion_bwd: dv_f32 must be 16-byte aligned with lddv a multiple of 4");
+  MART_CHECK(!d->dv_bf16 || (d->lddvb % 4 == 0 && (uintptr_t)d->dv_bf16 % 8 == 0), "fusion_bwd: dv_bf16 must be 8-byte aligned with lddvb a multiple of 4");
   bool* once = g_attr_bwd.slot();
   if (!*once) {
     if (hipFuncSetAttribute((const void*)fusion_bwd_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess) { mart_set_error("fusion_bwd: cannot raise the dynamic LDS limit"); return -2; }
     *once = true;
   }
   for (int qb = 0; qb < (d->Lq + 63) / 64; ++qb) {
-    static const int dbg = getenv("MART_FUSION_DBG") ? atoi(getenv("MART_FUSION_DBG")) : 0;   // timing experiments: 1 no dV loads, 2 no dV stores, 4 no B4, 8 no B3
+#ifdef MART_EXPERIMENTS
+    static const int dbg = getenv("MART_FUSION_DBG") ? atoi(getenv("MART_FUSION_DBG")) : 0;
+#else
+    const int dbg = 0;
+#endif
     hipLaunchKernelGGL((fusion_bwd_k<3>), dim3(d->B), dim3(FT), pl.lds, (hipStream_t)stream, *d, qb, pl.nbuf, pl.red_off, dbg);
     MART_LAUNCH_CHECK();
   }

@@ -42,6 +42,14 @@ template <typename T> __device__ __forceinline__ T ld_stream(const T* p) {
 #endif
 }
 
+// Timing / A-B experiments (DMA knock-outs, the round-1 K loops, start-stagger sweeps) exist only in harness builds
+// (-DMART_EXPERIMENTS: tools/nt_harness, tools/build_variant.sh); the product library carries none of them.
+#ifdef MART_EXPERIMENTS
+#define NT_DBG(p) ((p).dbg)
+#else
+#define NT_DBG(p) 0
+#endif
+
 struct Args {
   const bf16* A; const bf16* B; const bf16* A2; const bf16* B2;
   int lda, ldb;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight
     if (!have0) { issueA(tileA(0), 0, I0{}); issueB(tileB(0), 0, I0{}); issueB(tileB(0), 0, I1{}); issueA(tileA(0), 0, I1{}); }
     else bar();                                            // persistent loop: the epilogue staging region overlaps buffer 1
-    if (nk > 1 && !(p.dbg & 1)) {
+    if (nk > 1 && !(NT_DBG(p) & 1)) {
       issueA(tileA(1), 1, I0{}); issueB(tileB(1), 1, I0{}); issueB(tileB(1), 1, I1{});
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     } else {
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     for (int t = 0; t < nk; ++t) {
       const char* sA = smem + (t & 1) * STAGE;
       const char* sB = sA + A_BYTES;
-      const bool more1 = t + 1 < nk && !(p.dbg & 1), more2 = t + 2 < nk && !(p.dbg & 1);
+      const bool more1 = t + 1 < nk && !(NT_DBG(p) & 1), more2 = t + 2 < nk && !(NT_DBG(p) & 1);
       // P1
       readA(sA, I0{});
       __builtin_amdgcn_sched_barrier(0);
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       const char* sA = smem + (t & 1) * STAGE;
       const char* sB = sA + A_BYTES;
       read2(sA, sB, 0);                                   // R0
-      if (t + 1 < nk && !(p.dbg & 1)) stage(t + 1, (t + 1) & 1);
+      if (t + 1 < nk && !(NT_DBG(p) & 1)) stage(t + 1, (t + 1) & 1);
       phase_end();
       mma2();                                             // M0
       phase_end();
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   // 16-byte reads with WN/4 lanes covering one row), so that ALL global epilogue traffic (bias, residual,
   // pre-activation, output) is coalesced: a row segment of WN columns = 128 B of bf16 / 256 B of f32 per request.
   // No block-level barrier after the first one, and all waves (both SIMD halves of the LDS store path) stay busy.
-  if (p.dbg & 2) return;                                         // timing experiment: no epilogue (non-persistent only)
+  if (NT_DBG(p) & 2) return;                                         // timing experiment: no epilogue (non-persistent only)
   constexpr int EP_LD = WN + 4;
   constexpr int LPR = WN / 4, RPI = 64 / LPR;                    // lanes per row, rows per wave-instruction
   constexpr int NIT = 32 / RPI;
@@ -860,18 +868,27 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   a.dbg = 0;
   a.stagger_ticks = 0;
   a.b_blocked = d->b_blocked;
+#ifdef MART_EXPERIMENTS
   if (cfg == 999) { a.dbg = 1; cfg = 256; }
   if (cfg >= 70000 && cfg < 80000) { a.stagger_ticks = cfg - 70000; cfg = 256; }
   if (cfg == 9992 || cfg == 9993) { a.dbg = cfg - 9990; cfg = 256; }           // 9992: no epilogue, 9993: no LDS-DMA and no epilogue
   if (cfg >= 99900 && cfg <= 99903) { a.dbg = cfg - 99900; old_loop = true; cfg = 256; }   // the same experiments on the round-1 loop
+#else
+  MART_CHECK(cfg == 0 || cfg == 128 || cfg == 256 || cfg == 2561, "gemm_nt: tile_cfg must be 0 (auto), 128, 256 or 2561 (256 tile, general epilogue); "
+             "experiment codes need a -DMART_EXPERIMENTS build");
+#endif
   // 256x256 tiles from half a round of workgroups up (128 tiles): the 192-tile text products (16384 x 768) run 7-15 % faster on
   // the large tile than on four times as many 128x128 tiles (step -0.6 %); below that the small tile fills the CUs better
   if (cfg == 0) cfg = ((t256 >= 128 && d->M > 128) || d->b_blocked) ? 256 : 128;   // short-M batched products (fusion, M = L = 64): 128-row tiles waste less
+#ifdef MART_EXPERIMENTS
   // 2563 / 2564: the round-1 ping-pong K loop (one vmcnt(0) per K-tile), fast / general epilogue (A/B + bit-identity tests)
   if (cfg == 2563 || cfg == 2564) { old_loop = true; cfg = cfg == 2563 ? 256 : 2561; }
-  if (cfg == 2561 || cfg == 2562) { /* 256x256 tile: 2561 general epilogue, 2562 fast epilogue without the persistent loop (A/B) */ if (cfg == 2562) cfg = 256; }
-  MART_CHECK(!d->b_blocked || cfg == 256 || cfg == 999, "gemm_nt: b_blocked requires the 256x256 tile");
+  if (cfg == 2562) cfg = 256;                       // 2562: fast epilogue without the persistent loop (A/B)
+#endif
+  MART_CHECK(!d->b_blocked || cfg == 256, "gemm_nt: b_blocked requires the 256x256 tile");
+#ifdef MART_EXPERIMENTS
   if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
+#endif
   // fast epilogue instantiations: full-width tiles, 16-byte aligned rows, no gathers / bf16 residual / debug modes
   const int tile = cfg == 256 ? 256 : 128;
   const bool aligned = (d->ldc % (d->c_f32 ? 4 : 8) == 0) && ((uintptr_t)d->preact % 16 == 0) && (d->stride_c % 8 == 0 || d->c_f32) &&
@@ -892,12 +909,19 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (aligned) {
     // persistent loop: +6-7 % where the epilogue is light (bf16 out); with the fp32 residual or two bf16 outputs it is
     // neutral at best (re-measured after the epilogue work: fc1 0.571 vs 0.572 ms, step +0.3 %) -> only for the light masks
-    const bool persist = d->tile_cfg != 2562 && (int)d->tile_cfg != 25620 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;
+    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;
+#ifdef MART_EXPERIMENTS
 #define MART_FAST(M_, K_)                                                                   \
     if (mask == (M_) && kind == (K_)) {                                                       \
       if (tile == 256 && !old_loop) return persist ? launch<256, 256, 2, 4, 2, (M_), (K_), true>(a, batch, st) : launch<256, 256, 2, 4, 2, (M_), (K_)>(a, batch, st); \
       if (persist) return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_), true>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_), true>(a, batch, st); \
       return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_)>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st); }
+#else
+#define MART_FAST(M_, K_)                                                                   \
+    if (mask == (M_) && kind == (K_)) {                                                       \
+      if (tile == 256) return persist ? launch<256, 256, 2, 4, 2, (M_), (K_), true>(a, batch, st) : launch<256, 256, 2, 4, 2, (M_), (K_)>(a, batch, st); \
+      return persist ? launch<128, 128, 2, 2, 0, (M_), (K_), true>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st); }
+#endif
     const int kind = d->mulz ? d->mul_act : d->act;
     MART_FAST(0, ACT_NONE)                        // bf16 out (+bias): QKV, data gradients
     MART_FAST(F_CF32, ACT_NONE)                   // f32 out: scores, head
@@ -915,6 +939,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
 #undef MART_FAST
   }
   if ((cfg == 256 || cfg == 2561) && !old_loop) return launch<256, 256, 2, 4, 2>(a, batch, st);
+#ifdef MART_EXPERIMENTS
   if (cfg == 256 || cfg == 2561) return launch<256, 256, 2, 4>(a, batch, st);
+#endif
   return launch<128, 128, 2, 2>(a, batch, st);
 }

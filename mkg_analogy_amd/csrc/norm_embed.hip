@@ -49,6 +49,14 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
           }
           t += y;
         }
+        if (p.y_f32) {
+          f32x4 y = ldx((const f32x4*)(p.y_f32 + o), (LN_NT & 1) != 0);
+          if (p.p_drop > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? y[e] * inv_keep : 0.f;
+          }
+          t += y;
+        }
         x[v] = t;
         sum += t[0] + t[1] + t[2] + t[3];
         if (p.s_out) stx((f32x4*)(p.s_out + o), t, (LN_NT & 2) != 0);
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(256) void embed_postype_partial_k(const float* __re
       if (tt[m] == 1) a1 += g;
     }
     float* o = ws + (((long long)pos * nsl + blockIdx.y) * 2) * H;
-    o[c] = ap; o[H + c] = a1;                                              // all tokens, type-1 tokens (type 0 = all - type 1 is NOT used: summed separately below)
+    o[c] = ap; o[H + c] = a1;                                              // all tokens, type-1 tokens (embed_type_reduce_k forms the type-0 row as all - type 1)
   }
 }
 __global__ __launch_bounds__(256) void embed_postype_reduce_k(const float* __restrict__ ws, float* dpos, int L, int nsl, int H) {
@@ -751,13 +759,14 @@ __global__ void block_table_k(const bf16* __restrict__ src, bf16* __restrict__ d
 }  // namespace
 
 extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
-  MART_CHECK(d && (d->x_f32 || d->y_bf16), "ln_fwd: need x_f32 or y_bf16");
+  MART_CHECK(d && (d->x_f32 || d->y_bf16 || d->y_f32), "ln_fwd: need x_f32, y_bf16 or y_f32");
+  MART_CHECK(!(d->y_bf16 && d->y_f32), "ln_fwd: y_bf16 and y_f32 are alternatives");
   MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_fwd: H must be a multiple of 256 and <= 1024");
   MART_CHECK(d->gamma && d->beta && d->mean && d->rstd && (d->out_f32 || d->out_bf16), "ln_fwd: null pointer");
   MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "ln_fwd: bad dropout p");
   static const int fast = getenv("MART_LN_FAST") ? atoi(getenv("MART_LN_FAST")) : 1;
   static const int fcap = getenv("MART_LN_FWD_GRID") ? atoi(getenv("MART_LN_FWD_GRID")) : 512;   // 6.15 TB/s (768 / 1024 / 2048: 5.8-5.95)
-  if (fast && d->x_f32 && !d->y_bf16 && !d->s_out && !d->out_f32 && d->out_bf16 && d->p_drop == 0.f && (d->H == 768 || d->H == 1024) && d->M >= 4096) {
+  if (fast && d->x_f32 && !d->y_bf16 && !d->y_f32 && !d->s_out && !d->out_f32 && d->out_bf16 && d->p_drop == 0.f && (d->H == 768 || d->H == 1024) && d->M >= 4096) {
     int g = (d->M + WPB - 1) / WPB;
     if (g > fcap) g = fcap;
     const int gmin = (d->M + WPB * 64 - 1) / (WPB * 64);          // at most 64 rows per wave (their statistics live in one register across the lanes)

@@ -13,12 +13,14 @@
 
 namespace {
 
-__global__ void split3_k(const float* __restrict__ src, long long ld, bf16* __restrict__ dst, int rows, int K, int role) {
+__global__ void split3_k(const float* __restrict__ src, long long ld, bf16* __restrict__ dst, int rows, int K, int role,
+                         const int32_t* __restrict__ gather) {
   const long long total = (long long)rows * (K / 4);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / (K / 4);
     const int c = (int)(i % (K / 4)) * 4;
-    const f32x4 x = *(const f32x4*)(src + r * ld + c);
+    const long long sr = gather ? (long long)gather[r] : r;
+    const f32x4 x = *(const f32x4*)(src + sr * ld + c);
     const bf16x4 hi = f4_to_bf4(x);
     const f32x4 hf = bf4_to_f4(hi);
     const bf16x4 lo = f4_to_bf4(f32x4{x[0] - hf[0], x[1] - hf[1], x[2] - hf[2], x[3] - hf[3]});
@@ -175,11 +177,20 @@ int launch_attn(const mart_attn_f32_desc* d, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int mart_split_bf16x3_rows(const float* src, long long ld, const int32_t* gather, void* dst_bf16, int rows, int K, int role, void* stream) {
+  MART_CHECK(src && gather && dst_bf16 && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3_rows: bad args");
+  const long long total = (long long)rows * (K / 4);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split3_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role, gather);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16, int rows, int K, int role, void* stream) {
   MART_CHECK(src && dst_bf16 && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3: bad args");
   const long long total = (long long)rows * (K / 4);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(split3_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role);
+  hipLaunchKernelGGL(split3_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role, (const int32_t*)nullptr);
   MART_LAUNCH_CHECK();
   return 0;
 }

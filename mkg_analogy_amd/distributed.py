@@ -62,6 +62,19 @@ class BucketedAllReduce:
         self.handles = []
 
 
+def rank_seed(base_seed: int, rank: int) -> int:
+    """Dropout base seed of a rank: a splitmix64 hash of (base_seed, rank), 26 bits so that the model's per-step seed
+    (base_seed * 1000003 + step * 7919, + small per-layer offsets) stays injective in (base_seed, step, offset).  Rank 0 keeps
+    ``base_seed`` (the single-process stream)."""
+    if rank == 0:
+        return base_seed
+    z = ((base_seed & 0xFFFFFFFF) | (rank << 32)) + 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    z ^= z >> 31
+    return int(z & 0x3FFFFFF) | 1
+
+
 class GradSync:
     """Glue between a finalized model's engine and ``BucketedAllReduce``."""
 
@@ -85,8 +98,10 @@ class GradSync:
             # ... and draw DIFFERENT dropout masks: the counter-based dropout seed is derived from base_seed, identical on
             # every rank by construction; mix the rank in (rank 0 keeps the single-process stream)
             rank = dist.get_rank(group)
-            if rank and hasattr(model, "base_seed") and not getattr(model, "_rank_seeded", False):
-                model.base_seed = (int(model.base_seed) ^ (rank * 0x9E3779B1)) & 0x7FFFFFFF
+            if not hasattr(model, "base_seed"):
+                raise RuntimeError("GradSync: the model has no base_seed attribute; every rank would draw the same dropout masks")
+            if rank and not getattr(model, "_rank_seeded", False):
+                model.base_seed = rank_seed(int(model.base_seed), rank)
                 model._rank_seeded = True
 
     def broadcast_optimizer(self, optimizer) -> None:

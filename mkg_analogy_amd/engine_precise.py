@@ -30,6 +30,14 @@ class _PreciseBase:
     def _init_base(self, store: FlatStore):
         self.st = store
         self._w3: Dict[str, Tuple[int, torch.Tensor]] = {}
+        # Error-budget hook (tools/error_budget.py): the components named here run with their operands ROUNDED TO BF16
+        # (as the training path stores them) while everything else stays fp32-accurate, so the logit error each component class
+        # contributes can be measured in isolation.  Tags: vis_lin, vis_attn, txt_lin_lo (layers < 8), txt_lin_hi, txt_attn,
+        # fusion, head_t, head_s.  Empty in normal use.
+        self.degrade: set = set()
+
+    def _rb(self, x: torch.Tensor, tag: Optional[str]) -> torch.Tensor:
+        return x.to(BF).to(F32) if tag is not None and tag in self.degrade else x
 
 
 class PreciseUnimoForward(_PreciseBase):
@@ -43,24 +51,27 @@ class PreciseUnimoForward(_PreciseBase):
         self.fuse_from, self.export_from = 8, 7
 
     # ------------------------------------------------------------------ operands
-    def w3(self, names: Sequence[str]) -> torch.Tensor:
+    def w3(self, names: Sequence[str], rounded: bool = False) -> torch.Tensor:
         """[sum(out), 3*in] bf16 weight split (role 1) of one or several adjacent matrices, cached per store version."""
-        key = names[0] + f"+{len(names)}"
+        key = names[0] + f"+{len(names)}" + ("~bf16" if rounded else "")
         ver = getattr(self.st, "version", 0)
         hit = self._w3.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         W = self.st.fused(list(names), self.st.master)
         W = W.reshape(W.shape[0], -1)
+        if rounded:
+            W = W.to(BF).to(F32)
         out = ops.split_bf16x3(W, 1)
         self._w3[key] = (ver, out)
         return out
 
-    def lin(self, x: torch.Tensor, wnames: Sequence[str], bnames: Optional[Sequence[str]], N: int, **epi) -> torch.Tensor:
+    def lin(self, x: torch.Tensor, wnames: Sequence[str], bnames: Optional[Sequence[str]], N: int, tag: Optional[str] = None, **epi) -> torch.Tensor:
         """f32 [M, N] = epilogue(x @ W^T + b) with x f32 [M, K]."""
         out = _e((x.shape[0], N), F32, x.device)
         bias = self.st.fused(list(bnames), self.st.master) if bnames else None
-        ops.gemm_nt(ops.split_bf16x3(x, 0), self.w3(wnames), out, bias=bias, **epi)
+        deg = tag is not None and tag in self.degrade
+        ops.gemm_nt(ops.split_bf16x3(self._rb(x, tag), 0), self.w3(wnames, rounded=deg), out, bias=bias, **epi)
         return out
 
     def _ln(self, x, wname, bname, eps):
@@ -103,46 +114,52 @@ class PreciseUnimoForward(_PreciseBase):
             v = f"unimo.encoder.vision_layers.{l}."
             h1 = self._ln(xv, v + "layer_norm1.weight", v + "layer_norm1.bias", self.eps_v)
             names = [v + f"self_attn.{n}" for n in ("q_proj", "k_proj", "v_proj")]
-            qkv = self.lin(h1, [n + ".weight" for n in names], [n + ".bias" for n in names], 3 * H)
+            qkv = self._rb(self.lin(h1, [n + ".weight" for n in names], [n + ".bias" for n in names], 3 * H, tag="vis_lin"), "vis_attn")
             ctx = _e((Mv, H), F32, dev)
             pre = t_qkv_prev if l >= self.fuse_from else None
             ops.attn_fwd_f32(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, B=B, nh=nh, D=64, Sq=Nv, Sk=Nv, scale=0.125,
                              pk=pre[:, H:2 * H] if pre is not None else None, pv=pre[:, 2 * H:] if pre is not None else None,
                              Lp=Lq if pre is not None else 0)
-            x1 = self.lin(ctx, [v + "self_attn.out_proj.weight"], [v + "self_attn.out_proj.bias"], H, res_f32=xv)
+            ctx = self._rb(ctx, "vis_attn")
+            x1 = self.lin(ctx, [v + "self_attn.out_proj.weight"], [v + "self_attn.out_proj.bias"], H, tag="vis_lin", res_f32=xv)
             h2 = self._ln(x1, v + "layer_norm2.weight", v + "layer_norm2.bias", self.eps_v)
-            f = self.lin(h2, [v + "mlp.fc1.weight"], [v + "mlp.fc1.bias"], I, act=ops.ACT_QGELU)
-            xv = self.lin(f, [v + "mlp.fc2.weight"], [v + "mlp.fc2.bias"], H, res_f32=x1)
+            f = self.lin(h2, [v + "mlp.fc1.weight"], [v + "mlp.fc1.bias"], I, tag="vis_lin", act=ops.ACT_QGELU)
+            xv = self.lin(f, [v + "mlp.fc2.weight"], [v + "mlp.fc2.bias"], H, tag="vis_lin", res_f32=x1)
             # ---- text layer l (BertLayer.forward :540-577)
             t = f"unimo.encoder.text_layer.{l}."
             names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
-            tqkv = self.lin(xt, [n + ".weight" for n in names], [n + ".bias" for n in names], 3 * H)
+            tl = "txt_lin_hi" if l >= self.fuse_from else "txt_lin_lo"
+            tqkv = self._rb(self.lin(xt, [n + ".weight" for n in names], [n + ".bias" for n in names], 3 * H, tag=tl), "txt_attn")
             tctx = _e((Mt, H), F32, dev)
             on = sep_idx is not None
             ops.attn_fwd_f32(q=tqkv[:, :H], k=tqkv[:, H:2 * H], v=tqkv[:, 2 * H:], ctx=tctx, B=B, nh=nh, D=64, Sq=Lq, Sk=Lq, scale=0.125,
                              attn_mask=attention_mask, sep=sep_idx[:, 2:] if on else None, sep_stride=sep_idx.shape[1] if on else 0,
                              w0=st.m(t + "attention.self.adaptive_weight.0") if on else None,
                              w1=st.m(t + "attention.self.adaptive_weight.1") if on else None)
+            tctx = self._rb(tctx, "txt_attn")
             fus = None
             if l >= self.fuse_from:                                  # BertFusion.forward :400-414 (unscaled, unmasked, one "head" of 768)
                 fus = _e((Mt, H), F32, dev)
-                ops.attn_fwd_f32(q=tctx, k=xv, v=xv, ctx=fus, B=B, nh=1, D=H, Sq=Lq, Sk=Nv, scale=1.0)
-            s1 = self.lin(tctx, [t + "attention.output.dense.weight"], [t + "attention.output.dense.bias"], H, res_f32=xt)
+                xvf = self._rb(xv, "fusion")
+                ops.attn_fwd_f32(q=self._rb(tctx, "fusion"), k=xvf, v=xvf, ctx=fus, B=B, nh=1, D=H, Sq=Lq, Sk=Nv, scale=1.0)
+                fus = self._rb(fus, "fusion")
+            s1 = self.lin(tctx, [t + "attention.output.dense.weight"], [t + "attention.output.dense.bias"], H, tag=tl, res_f32=xt)
             a = self._ln(s1, t + "attention.output.LayerNorm.weight", t + "attention.output.LayerNorm.bias", self.eps_t)
             ht = _e((Mt, I), F32, dev)
-            a3 = ops.split_bf16x3(a, 0)
+            deg = tl in self.degrade
+            a3 = ops.split_bf16x3(self._rb(a, tl), 0)
             if fus is not None:
-                ops.gemm_nt(a3, self.w3([t + "intermediate.dense.weight"]), ht, A2=ops.split_bf16x3(fus, 0),
-                            B2=self.w3([t + "intermediate.fusion_dense.weight"]), bias=st.m(t + "intermediate.dense.bias"),
+                ops.gemm_nt(a3, self.w3([t + "intermediate.dense.weight"], rounded=deg), ht, A2=ops.split_bf16x3(self._rb(fus, tl), 0),
+                            B2=self.w3([t + "intermediate.fusion_dense.weight"], rounded=deg), bias=st.m(t + "intermediate.dense.bias"),
                             bias2=st.m(t + "intermediate.fusion_dense.bias"), act=ops.ACT_GELU)
             else:
-                ops.gemm_nt(a3, self.w3([t + "intermediate.dense.weight"]), ht, bias=st.m(t + "intermediate.dense.bias"), act=ops.ACT_GELU)
-            s2 = self.lin(ht, [t + "output.dense.weight"], [t + "output.dense.bias"], H, res_f32=a)
+                ops.gemm_nt(a3, self.w3([t + "intermediate.dense.weight"], rounded=deg), ht, bias=st.m(t + "intermediate.dense.bias"), act=ops.ACT_GELU)
+            s2 = self.lin(ht, [t + "output.dense.weight"], [t + "output.dense.bias"], H, tag=tl, res_f32=a)
             xt = self._ln(s2, t + "output.LayerNorm.weight", t + "output.LayerNorm.bias", self.eps_t)
             t_qkv_prev = tqkv if l >= self.export_from else None
         # ---- MLM head transform (:972-975)
         hp = "cls.predictions.transform."
-        y = self.lin(xt, [hp + "dense.weight"], [hp + "dense.bias"], H, act=ops.ACT_GELU)
+        y = self.lin(xt, [hp + "dense.weight"], [hp + "dense.bias"], H, tag="head_t", act=ops.ACT_GELU)
         trans = self._ln(y, hp + "LayerNorm.weight", hp + "LayerNorm.bias", self.eps_t)
         return trans.view(B, Lq, H)
 
@@ -150,9 +167,9 @@ class PreciseUnimoForward(_PreciseBase):
     def score(self, trans: torch.Tensor, rows: torch.Tensor, ids: torch.Tensor, word_name: str, bias_name: str) -> torch.Tensor:
         """logits[rows][:, ids] of the tied decoder (:958) on split operands."""
         H = trans.shape[-1]
-        t3 = ops.split_bf16x3(trans.reshape(-1, H), 0)
+        t3 = ops.split_bf16x3(self._rb(trans.reshape(-1, H), "head_s"), 0)
         out = _e((rows.numel(), ids.numel()), F32, trans.device)
-        ops.gemm_nt(t3, self.w3([word_name]), out, a_rows=rows, b_rows=ids, bias=self.st.m(bias_name), bias_by_brow=True)
+        ops.gemm_nt(t3, self.w3([word_name], rounded="head_s" in self.degrade), out, a_rows=rows, b_rows=ids, bias=self.st.m(bias_name), bias_by_brow=True)
         return out
 
 

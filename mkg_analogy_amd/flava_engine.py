@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -213,11 +215,20 @@ class FlavaEngine:
             xm, _, sv[f"m{l}"] = self._layer_fwd(f"flava.multimodal_model.encoder.layer.{l}.", xm, Mm, mkw, False)
         # ---- final multimodal layernorm, text positions, MLM head transform (:1209, :2187-2188, :1676-1680)
         mm_b, mmean, mrstd = _e((Mm, H), BF, dev), _e((Mm,), F32, dev), _e((Mm,), F32, dev)
+        split = os.environ.get("MART_HEAD_SPLIT", "1") == "1"        # head transform on two-term operand splits (engine.UnimoEngine.head_split)
+        mm_f = _e((Mm, H), F32, dev) if split else None
         ops.ln_fwd(x_f32=xm, gamma=st.m("flava.multimodal_model.layernorm.weight"), beta=st.m("flava.multimodal_model.layernorm.bias"),
-                   eps=self.eps, M=Mm, H=H, mean=mmean, rstd=mrstd, out_bf16=mm_b)
+                   eps=self.eps, M=Mm, H=H, mean=mmean, rstd=mrstd, out_bf16=mm_b, out_f32=mm_f)
         rows = (torch.arange(B, device=dev, dtype=torch.int32)[:, None] * Sm + (1 + Nv) + torch.arange(Lq, device=dev, dtype=torch.int32)[None]).reshape(-1).contiguous()
         y, zh = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-        ops.gemm_nt(mm_b, st.w("cls.transform.dense.weight"), y, a_rows=rows, bias=st.m("cls.transform.dense.bias"), act=ops.ACT_GELU, preact=zh)
+        if split:
+            ver, w3 = getattr(self, "_head_w3", (-1, None))
+            if ver != st.version:
+                w3 = ops.split_bf16x3(st.m("cls.transform.dense.weight"), 1)
+                self._head_w3 = (st.version, w3)
+            ops.gemm_nt(ops.split_bf16x3_rows(mm_f, rows, 0), w3, y, bias=st.m("cls.transform.dense.bias"), act=ops.ACT_GELU, preact=zh)
+        else:
+            ops.gemm_nt(mm_b, st.w("cls.transform.dense.weight"), y, a_rows=rows, bias=st.m("cls.transform.dense.bias"), act=ops.ACT_GELU, preact=zh)
         trans, transb = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
         hm, hr = _e((Mt,), F32, dev), _e((Mt,), F32, dev)
         ops.ln_fwd(x_f32=y, gamma=st.m("cls.transform.LayerNorm.weight"), beta=st.m("cls.transform.LayerNorm.bias"), eps=self.eps, M=Mt, H=H,

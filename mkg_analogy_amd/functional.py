@@ -6,6 +6,7 @@ into ``FlatStore.grad`` (which ``p.grad`` views), the way fused wgrad accumulati
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -14,6 +15,7 @@ from . import ops
 
 BF, F32 = torch.bfloat16, torch.float32
 WORD, BIAS = "unimo.text_embeddings.word_embeddings.weight", "cls.predictions.bias"
+HEAD_SPLIT = os.environ.get("MART_HEAD_SPLIT", "1") == "1"       # see engine.UnimoEngine.head_split
 
 
 class _MKGformerFn(torch.autograd.Function):
@@ -37,6 +39,21 @@ class _MKGformerFn(torch.autograd.Function):
         return (None,) * 12
 
 
+_UNIQUE_OK: dict = {}
+
+
+def _require_unique(ids: torch.Tensor) -> None:
+    """The deterministic weight-gradient reduction adds each scored vocabulary row with a plain read-modify-write
+    (mart_gemm_tn with a workspace: out_rows must not repeat); checked once per id tensor (one device sync)."""
+    key = (ids.data_ptr(), ids.numel(), ids._version)
+    if key not in _UNIQUE_OK:
+        if int(torch.unique(ids).numel()) != ids.numel():
+            raise ValueError("scored vocabulary ids must be unique (the tied-embedding gradient rows are scattered without atomics)")
+        if len(_UNIQUE_OK) > 64:
+            _UNIQUE_OK.clear()
+        _UNIQUE_OK[key] = True
+
+
 class _ScoreFn(torch.autograd.Function):
     """logits[rows][:, ids] of the tied decoder: trans[rows] @ word_emb[ids]^T + bias[ids]
     (modeling_unimo.py:958 restricted to what lit_models/transformer.py:75-95,131-160 actually read)."""
@@ -44,9 +61,18 @@ class _ScoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, trans, transb, rows, ids, store, word_name=WORD, bias_name=BIAS):
         R, A = rows.numel(), ids.numel()
-        W = store.w(word_name)
+        if trans.requires_grad:
+            _require_unique(ids)
         out = torch.empty((R, A), device=trans.device, dtype=F32)
-        ops.gemm_nt(transb, W, out, a_rows=rows, b_rows=ids, bias=store.m(bias_name), bias_by_brow=True)
+        if HEAD_SPLIT:
+            # two-term bf16 splits of the f32 rows on both sides (K' = 3K, csrc/precise.hip): the scoring GEMM is ~0.01 % of the
+            # step's FLOPs and was 16 % of the bf16 logit error variance (tools/error_budget.py)
+            H = trans.shape[-1]
+            t3 = ops.split_bf16x3_rows(trans.detach().reshape(-1, H), rows, 0)
+            w3 = ops.split_bf16x3_rows(store.m(word_name), ids, 1)
+            ops.gemm_nt(t3, w3, out, bias=store.m(bias_name).index_select(0, ids.long()))
+        else:
+            ops.gemm_nt(transb, store.w(word_name), out, a_rows=rows, b_rows=ids, bias=store.m(bias_name), bias_by_brow=True)
         ctx.store, ctx.rows, ctx.ids, ctx.transb, ctx.shape = store, rows, ids, transb, trans.shape
         ctx.names = (word_name, bias_name)
         return out

@@ -220,6 +220,7 @@ class FlavaForMaskedLM(nn.Module):
         self._engine = FlavaEngine(self._store, c)
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._step = 0
+        self.base_seed = 0x5EED          # dropout stream; distributed.GradSync hashes the rank into it
         return self._store
 
     @property
@@ -277,7 +278,7 @@ class FlavaForMaskedLM(nn.Module):
         holder: Dict[str, torch.Tensor] = {}
         self._engine.save_for_backward = torch.is_grad_enabled()
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx,
-                                      bool(self.training), self._step, holder)
+                                      bool(self.training), (self.base_seed * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFF, holder)
         logits = Fn.LazyLogits(trans, holder["trans_bf16"], st, word_name="flava.text_model.embeddings.word_embeddings.weight",
                                bias_name="cls.bias")
         loss = None

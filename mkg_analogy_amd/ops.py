@@ -97,10 +97,11 @@ def gemm_tn(X, Y, out, *, M=None, NX=None, NY=None, out_rows=None, colsum=None, 
     return out
 
 
-def ln_fwd(*, x_f32=None, y_bf16=None, gamma, beta, eps, M, H, mean, rstd, s_out=None, out_f32=None, out_bf16=None,
+def ln_fwd(*, x_f32=None, y_bf16=None, y_f32=None, gamma, beta, eps, M, H, mean, rstd, s_out=None, out_f32=None, out_bf16=None,
            p_drop=0.0, seed=0):
     d = L.LnFwd()
     d.x_f32, d.y_bf16, d.p_drop, d.seed = _p(x_f32), _p(y_bf16), p_drop, seed
+    d.y_f32 = _p(y_f32)
     d.gamma, d.beta, d.eps, d.M, d.H = _p(gamma), _p(beta), eps, M, H
     d.s_out, d.out_f32, d.out_bf16, d.mean, d.rstd = _p(s_out), _p(out_f32), _p(out_bf16), _p(mean), _p(rstd)
     L.check(L.lib().mart_ln_fwd(C.byref(d), _stream()), "mart_ln_fwd")
@@ -211,6 +212,17 @@ def split_bf16x3(src, role, out=None):
     if out is None:
         out = torch.empty((rows, 3 * K), device=src.device, dtype=BF16)
     L.check(L.lib().mart_split_bf16x3(_p(src), _rows2d(src), _p(out), rows, K, role, _stream()), "mart_split_bf16x3")
+    return out
+
+
+def split_bf16x3_rows(src, gather, role, out=None):
+    """Same split of the gathered rows ``src[gather]`` (gather int32 [R]) -> bf16 [R, 3K]."""
+    K = src.shape[1]
+    R = gather.numel()
+    assert gather.dtype == torch.int32 and gather.is_contiguous()
+    if out is None:
+        out = torch.empty((R, 3 * K), device=src.device, dtype=BF16)
+    L.check(L.lib().mart_split_bf16x3_rows(_p(src), _rows2d(src), _p(gather), _p(out), R, K, role, _stream()), "mart_split_bf16x3_rows")
     return out
 
 

@@ -335,22 +335,30 @@ def g3(lit, out_dir):
     print("G3 ok", float(loss), ranks, (t2 + 1).numpy())
 
 
-def g5_flava(out_dir):
-    """G5: tiny FLAVA end-to-end (FlavaForMaskedLM as MarT runs it): trans_hidden, mask-row logits, fine-tune loss, gradients.
-    Extra shims (SURVEY 8(c)): prune helpers stubbed into transformers.modeling_utils; get_head_mask / get_extended_attention_mask
-    of FlavaPreTrainedModel overridden with the transformers==4.19.0 semantics the reference was written against."""
+def load_reference_flava():
+    """The reference's FLAVA module imported in place, with the extra shims of SURVEY 8(c): prune helpers stubbed into
+    transformers.modeling_utils; get_head_mask / get_extended_attention_mask of FlavaPreTrainedModel overridden with the
+    transformers==4.19.0 semantics the reference was written against."""
     import transformers.modeling_utils as mu
     if not hasattr(mu, "find_pruneable_heads_and_indices"):
         mu.find_pruneable_heads_and_indices = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
     if not hasattr(mu, "prune_linear_layer"):
         mu.prune_linear_layer = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
-    from oracle import flava_oracle as FO
     spec = importlib.util.spec_from_file_location("ref_flava", os.path.join(REF, "models/modeling_flava.py"))
     fl = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fl)
     fl.FlavaPreTrainedModel.get_head_mask = lambda self, head_mask, n, *a, **k: [None] * n
     fl.FlavaPreTrainedModel.get_extended_attention_mask = \
         lambda self, mask, shape=None, device=None, *a, **k: (1.0 - mask[:, None, None, :].to(torch.float32)) * -10000.0
+    return fl
+
+
+def g5_flava(out_dir):
+    """G5: tiny FLAVA end-to-end (FlavaForMaskedLM as MarT runs it): trans_hidden, mask-row logits, fine-tune loss, gradients.
+    Extra shims (SURVEY 8(c)): prune helpers stubbed into transformers.modeling_utils; get_head_mask / get_extended_attention_mask
+    of FlavaPreTrainedModel overridden with the transformers==4.19.0 semantics the reference was written against."""
+    from oracle import flava_oracle as FO
+    fl = load_reference_flava()
     from transformers import FlavaConfig
     V = TINY_BASE + TINY_E + TINY_R + 1
     c = FO.FlavaCfg(vocab_size=V, hidden_size=64, text_layers=3, image_layers=3, mm_layers=2, num_attention_heads=4,

@@ -14,6 +14,8 @@ G7  BASELINE configs[1] shape: the first 32 examples of bench.py's rank-0 batch 
     Stored: mask logits [32,2063], trans_hidden at the five rows the loss reads, loss, ranks, metrics, all 451
     gradient norms, strided samples of ~45 gradient tensors, and per-layer hidden states (reference forward hooks)
     of layers 0, 7, 8, 11 for examples 0-1 (pins the oracle's per-layer taps at real dimensions).
+G8b the same pre-train step at P=196 (ViT-B/16 patches, 393 vision tokens), B=8, conditioned weights.
+G9  BASELINE configs[3]: the reference's FlavaForMaskedLM at real dimensions, B=2 (see g9_flava).
 G8  BASELINE configs[4] shape: MarKG pre-train step, L=96, no sep_idx, mixed pre_type, B=8, CLIP-B/32 patches
     (P=49, the geometry of the reference's pre-train script), full E=11292 / R=192 heads: loss, entity and relation
     ranks, gradient norms and samples (incl. the tied word-embedding rows of the entity slice and cls.predictions.bias).
@@ -93,10 +95,11 @@ def run(lit, unimo, out_dir, tag, patch, B, L, pretrain, conditioned, weight_see
     batch = {k: v[:B].clone() for k, v in full.items()}
     del full
     res = evaluate(lit, unimo, patch, sd0, pretrain, cfg, batch, B, taps)
-    if not conditioned:
+    if True:
         # sensitivity control: the SAME reference run with only its weight matrices rounded to bf16 (fp32 math otherwise).  How far
         # that moves every output is the intrinsic bf16 sensitivity of the network at these weights; the GPU tests hold the
-        # bf16 HIP path to a small multiple of it instead of to hand-picked numbers.
+        # bf16 HIP path to a small multiple of it instead of to hand-picked numbers.  (Round 3: also for the conditioned weights,
+        # so that the distance of the bf16 path from its floor is a number there too.)
         sdb = {k: (v.to(torch.bfloat16).float() if v.dim() >= 2 and "embeddings" not in k else v) for k, v in sd0.items()}
         ctl = evaluate(lit, unimo, patch, sdb, pretrain, cfg, batch, B, False)
         for k, v in ctl.items():
@@ -179,6 +182,76 @@ def evaluate(lit, unimo, patch, sd0, pretrain, cfg, batch, B, taps):
     return out
 
 
+def g9_flava(out_dir):
+    """G9 (round 3): the reference's FlavaForMaskedLM at REAL dimensions (flava-full: 768 wide, 12 + 12 + 6 layers, 393 image
+    tokens, L = 64, vocabulary 42007), B = 2, eval mode, fine-tune loss (alpha 0.45, scripts/run_finetune_flava.sh).  Weights
+    from flava_oracle.init_params(seed 13) + the [R] row = mean of the analogy-relation rows (lit_models/transformer.py:41-54),
+    exactly what tests/test_flava_gpu.py builds on the HIP side.  Stored: trans_hidden rows the loss reads, mask logits over the
+    2063 analogy entities, loss, every gradient norm, strided samples of ~70 gradient tensors."""
+    from oracle import flava_oracle as FO
+    from oracle.gen_goldens import load_reference_flava
+    from transformers import FlavaConfig
+    t0 = time.time()
+    fl = load_reference_flava()
+    cfgd = D.data_config(seed=1234)
+    c0 = FO.FlavaCfg(vocab_size=D.VOCAB - 1)
+    sd0 = FO.init_params(c0, seed=13)
+    W = sd0["flava.text_model.embeddings.word_embeddings.weight"]
+    sd = dict(sd0)
+    sd["flava.text_model.embeddings.word_embeddings.weight"] = torch.cat([W, W[torch.tensor(cfgd["analogy_relation_ids"])].mean(0, keepdim=True)], 0)
+    sd["cls.bias"] = torch.cat([sd0["cls.bias"], torch.zeros(1)])
+    cfg = FlavaConfig(text_config=dict(vocab_size=D.VOCAB), image_config=dict(), multimodal_config=dict())
+    assert cfg.text_config.hidden_size == 768 and cfg.image_config.patch_size == 16 and cfg.multimodal_config.num_hidden_layers == 6
+    torch.manual_seed(0)
+    model = fl.FlavaForMaskedLM(cfg)
+    model.cls.decoder.weight = model.flava.text_model.embeddings.word_embeddings.weight      # tie manually (no resize under 5.x)
+    model.flava.text_model.embeddings.word_embeddings.padding_idx = None                      # 4.19.0 resize drops padding_idx (see g5)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("position_ids" in m or "decoder" in m or "token_type_ids" in m) for m in missing), missing
+    named = dict(model.named_parameters())
+    assert set(named) == set(sd), (set(named) ^ set(sd))
+    model.eval()
+    B, L = 2, 64
+    batch = D.make_batch(B, L, seed=17)
+    ids = torch.tensor(cfgd["analogy_entity_ids"])
+    out, trans = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], token_type_ids=batch["token_type_ids"],
+                       pixel_values=batch["pixel_values"], sep_idx=batch["sep_idx"], return_dict=True)
+    ar = torch.arange(B)
+    _, mask_idx = (batch["input_ids"] == 103).nonzero(as_tuple=True)
+    mask_logits = out.logits[ar, mask_idx][:, ids]
+    loss = O.label_smooth_ce(mask_logits, batch["label"], 0.1) + 0.45 * O.relaxation_loss(trans, batch["rel_idx"], batch["q_head_idx"],
+                                                                                          batch["a_head_idx"])
+    loss.backward()
+    rows = torch.stack([mask_idx, batch["q_head_idx"], batch["a_head_idx"], batch["rel_idx"][:, 0], batch["rel_idx"][:, 1]], 1)
+    none_grad = sorted(n for n, p in named.items() if p.grad is None)
+    norms = {n: float(p.grad.double().norm()) for n, p in named.items() if p.grad is not None}
+    names = ["cls.transform.dense.weight", "cls.bias", "flava.text_model.embeddings.word_embeddings.weight",
+             "flava.image_model.embeddings.position_embeddings", "flava.image_model.embeddings.cls_token",
+             "flava.image_model.embeddings.patch_embeddings.projection.weight", "flava.image_model.embeddings.patch_embeddings.projection.bias",
+             "flava.multimodal_model.cls_token", "flava.image_to_mm_projection.weight", "flava.text_to_mm_projection.bias",
+             "flava.multimodal_model.layernorm.weight", "flava.text_model.embeddings.LayerNorm.bias"]
+    for mod, ls in (("text_model", (0, 6, 11)), ("image_model", (0, 11)), ("multimodal_model", (0, 5))):
+        for l in ls:
+            p = f"flava.{mod}.encoder.layer.{l}."
+            names += [p + "attention.attention.query.weight", p + "attention.attention.key.bias", p + "attention.attention.value.weight",
+                      p + "attention.output.dense.weight", p + "layernorm_before.weight", p + "intermediate.dense.weight",
+                      p + "output.dense.bias", p + "layernorm_after.bias"]
+            if mod == "text_model":
+                names += [p + "attention.attention.adaptive_weight.0", p + "attention.attention.adaptive_weight.1"]
+    samples = {"gs::" + n: grad_sample(named[n].grad) for n in names if named[n].grad is not None}
+    ranks = O.ranks_double_sort(mask_logits.detach(), batch["label"])
+    pix = batch["pixel_values"]
+    np.savez_compressed(
+        os.path.join(out_dir, "g9_flava_real.npz"), B=np.int64(B), L=np.int64(L), weight_seed=np.int64(13), batch_seed=np.int64(17),
+        pixel_sum=np.float64(float(pix.double().sum())), pixel_abs_sum=np.float64(float(pix.double().abs().sum())),
+        **{"in::" + k: v.numpy() for k, v in batch.items() if k != "pixel_values"},
+        mask_logits=mask_logits.detach().numpy(), trans_rows=trans.detach()[ar[:, None], rows].numpy(), trans_row_index=rows.numpy(),
+        loss=np.float64(float(loss.detach())), ranks=np.asarray(ranks), none_grad=np.array(none_grad),
+        grad_norm_names=np.array(sorted(norms)), grad_norm_vals=np.array([norms[k] for k in sorted(norms)]), **samples)
+    print(f"g9_flava_real: loss {float(loss):.6f} ranks {np.asarray(ranks).tolist()} none-grad {len(none_grad)} ({time.time() - t0:.1f} s)", flush=True)
+
+
 def main():
     p = ap.ArgumentParser()
     p.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -191,11 +264,15 @@ def main():
         dict(tag="g7_bench_cond", patch=16, B=32, L=64, pretrain=False, conditioned=True, weight_seed=0, batch_seed=1234, batch_total=256, taps=False),
         dict(tag="g8_pretrain_cond", patch=32, B=8, L=96, pretrain=True, conditioned=True, weight_seed=0, batch_seed=1234, batch_total=8, taps=False),
         dict(tag="g8_pretrain_plain", patch=32, B=8, L=96, pretrain=True, conditioned=False, weight_seed=0, batch_seed=1234, batch_total=8, taps=False),
+        # G8b (round 3): the pre-train step at the ViT-B/16 geometry of BASELINE configs[1]/[4] (P=196, 393 vision tokens)
+        dict(tag="g8b_pretrain_p196_cond", patch=16, B=8, L=96, pretrain=True, conditioned=True, weight_seed=0, batch_seed=1234, batch_total=8, taps=False),
     ]
     for j in jobs:
         if a.only and a.only not in j["tag"]:
             continue
         run(lit, unimo, a.out, **j)
+    if not a.only or a.only in "g9_flava_real":
+        g9_flava(a.out)
 
 
 if __name__ == "__main__":

@@ -106,3 +106,97 @@ def test_flava_forward_backward_vs_oracle():
     safe = (gap.min(1).values > 2 * e32).numpy()
     assert np.array_equal(ev32["entity_ranks"][safe], np.asarray(O.ranks_count(ml_ref.detach(), batch["label"]))[safe])
     model.set_precision("bf16")
+
+
+def test_flava_vs_reference_at_real_dimensions():
+    """G9 (oracle/gen_goldens_full.py:g9_flava): the UNMODIFIED reference FlavaForMaskedLM at real dimensions (B=2, 393 image
+    tokens, L=64, V=42007) against the HIP path directly -- no oracle in between."""
+    import os
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.lit_models import TransformerLitModel
+    from mkg_analogy_amd.models import FlavaKGC, flava_config
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_flava_real.npz"), allow_pickle=False))
+    c = FO.FlavaCfg(vocab_size=D.VOCAB - 1)
+    torch.manual_seed(0)
+    model = FlavaKGC(flava_config(vocab_size=30522))
+    cfg = D.data_config(seed=1234)
+    args = argparse.Namespace(label_smoothing=0.1, alpha=0.45, pretrain=0, lr=5e-5, weight_decay=0.01, optimizer="AdamW", warm_up_radio=0.1)
+    lit = TransformerLitModel(model=model, args=args, tokenizer=D.FakeTokenizer(), data_config=cfg)      # resize -> 42006
+    sd0 = FO.init_params(c, seed=int(g["weight_seed"]))
+    missing, unexpected = model.load_state_dict(sd0, strict=False)
+    assert not unexpected and all(("position_ids" in m or "decoder" in m) for m in missing), (missing, unexpected)
+    model.cuda()
+    lit._init_relation_word()                                                                            # -> 42007, [R] = mean of the relation rows
+    B = int(g["B"])
+    batch = D.make_batch(B, int(g["L"]), seed=int(g["batch_seed"]))
+    for k, v in batch.items():
+        if k != "pixel_values":
+            assert np.array_equal(v.numpy(), g["in::" + k]), k
+    assert abs(float(batch["pixel_values"].double().sum()) - float(g["pixel_sum"])) < 1e-6 * float(g["pixel_abs_sum"])
+    gb = {k: v.cuda() for k, v in batch.items()}
+    ids = torch.tensor(cfg["analogy_entity_ids"], device="cuda")
+    ar = torch.arange(B, device="cuda")
+    rows = torch.from_numpy(g["trans_row_index"]).cuda()
+    ref_l, ref_t = torch.from_numpy(g["mask_logits"]), torch.from_numpy(g["trans_rows"])
+    model.eval()
+    keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
+
+    def forward():
+        with torch.no_grad():
+            out, trans = model(**{k: gb[k] for k in keys}, return_dict=True)
+            return out.logits[ar, rows[:, 0]][:, ids].float().cpu(), trans[ar[:, None], rows].float().cpu()
+
+    model.set_precision("fp32")
+    ml32, tr32 = forward()
+    ev32 = lit._eval(dict(gb), 0)
+    model.set_precision("bf16")
+    e32 = float((ml32 - ref_l).abs().max())
+    print(f"\ng9 flava: fp32-accurate path max|dlogit| {e32:.3e}  trans rows max|err| {float((tr32 - ref_t).abs().max()):.3e}")
+    assert e32 < 1e-3
+    lab = ref_l[torch.arange(B), batch["label"]]
+    near = ((ref_l - lab[:, None]).abs() < 2 * e32).sum(1).numpy() - 1
+    assert np.all(np.abs(ev32["entity_ranks"] - g["ranks"]) <= near), (ev32["entity_ranks"], g["ranks"])
+    ml, tr = forward()
+    e_l, rms = float((ml - ref_l).abs().max()), float((ml - ref_l).pow(2).mean().sqrt())
+    scale = max(1.0, float(ref_l.abs().max()))
+    r_t = float((tr - ref_t).norm() / ref_t.norm())
+    print(f"   bf16 path max|dlogit| {e_l:.3e} rms {rms:.3e} (logit scale {scale:.2f}) trans rows rel-L2 {r_t:.3e}")
+    assert r_t < 2e-2 and e_l < 1.5e-2 * scale
+    st = model.store
+    st.zero_grad()
+    loss = lit.training_step(dict(gb), 1)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f"   loss hip {float(loss.detach()):.5f} reference {float(g['loss']):.5f}")
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-2
+    norms = dict(zip(g["grad_norm_names"].tolist(), g["grad_norm_vals"].tolist()))
+    worst = 0.0
+    for n, ref in norms.items():
+        if n.endswith("decoder.weight") or "adaptive_weight" in n or n not in st.slots:
+            continue
+        got = float(st.g(n).double().norm())
+        if ref < 1e-7:
+            assert got < 1e-3, (n, got, ref)
+            continue
+        worst = max(worst, abs(got - ref) / ref)
+        assert abs(got - ref) / ref < 0.10, (n, got, ref)
+    bad = []
+    for k in g:
+        if not k.startswith("gs::"):
+            continue
+        n, ref = k[4:], g[k]
+        f = st.g(n).detach().reshape(-1)
+        step = max(1, f.numel() // 1024)
+        got = f[::step][:1024].float().cpu().numpy()
+        if np.linalg.norm(ref) < 1e-7:
+            continue
+        if ref.size == 1:
+            if abs(float(got[0]) - float(ref[0])) > 0.12 * abs(float(ref[0])) + 3e-3:
+                bad.append((n, float(got[0]), float(ref[0])))
+            continue
+        rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref)))
+        if rel > 0.12 or cos < 0.99:
+            bad.append((n, rel, cos))
+    print(f"   gradients: worst |norm| deviation {worst:.3e} over {len(norms)} tensors; {sum(k.startswith('gs::') for k in g)} sampled tensors")
+    assert not bad, bad

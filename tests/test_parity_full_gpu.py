@@ -3,7 +3,8 @@
   G7  BASELINE configs[1] shape (first 32 examples of bench.py's rank-0 batch, P=196, L=64, V=42007), plain N(0,0.02) weights --
       the network bench.py times -- and the well-conditioned variant; compared DIRECTLY with the HIP path (no oracle run on the
       GPU box): mask logits, trans_hidden rows, loss, ranks, every gradient norm and strided gradient samples.
-  G8  BASELINE configs[4] shape (MarKG pre-train step, L=96, no sep_idx, mixed pre_type, full E=11292 / R=192 heads).
+  G8  BASELINE configs[4] shape (MarKG pre-train step, L=96, no sep_idx, mixed pre_type, full E=11292 / R=192 heads); G8b = the
+      same step at the ViT-B/16 geometry (P=196, 393 vision tokens).
   +   teacher-forced per-layer parity on PLAIN weights: every layer is fed the oracle's inputs and upstream gradients, so the
       reported error is that layer's own bf16 rounding and not the chaos of the unscaled fusion softmax downstream.
 
@@ -199,7 +200,15 @@ def test_finetune_step_vs_reference_at_bench_shape(tag):
     amb = ((ref_logits - lab[:, None]).abs() < 2 * e_l).sum(1).numpy() - 1
     assert np.all(np.abs(ev["entity_ranks"] - ref_ranks) <= amb), (ev["entity_ranks"], ref_ranks, amb)
     if cond:
-        assert rms < 5e-3 and e_l < 2.5e-2, "bf16 logits: rms 5e-3 / max 2.5e-2 absolute"
+        # The bf16 floor at these weights is a NUMBER (round 3): the reference itself, fp32 math, with nothing but its weight matrices
+        # rounded to bf16 moves its logits by ctl (max 1.02e-2, rms 2.2e-3 -- already past north_star's 1e-2 in max norm).  The bf16
+        # training path (bf16 activations as well) is held to 1.5 x that control in both norms; tools/error_budget.py splits the
+        # distance by component, and test_text_split_mode_vs_reference below asserts north_star's absolute 1e-2 for the split-precision
+        # text stream.
+        c_l = float(np.abs(g["ctl::mask_logits"] - ref_logits.numpy()).max())
+        c_rms = float(np.sqrt(((g["ctl::mask_logits"] - ref_logits.numpy()) ** 2).mean()))
+        print(f"   control (reference, bf16-rounded weight matrices): max|dlogit| {c_l:.3e} rms {c_rms:.3e}  ->  bf16 path = {e_l / c_l:.2f} x / {rms / c_rms:.2f} x")
+        assert e_l <= 1.5 * c_l and rms <= 1.5 * c_rms, (e_l, c_l, rms, c_rms)
         assert r_t < 1.5e-2 and dl < 5e-3
         _grad_report(st, g, tol_rel=0.12, tol_cos=0.99, tol_norm=0.08)
     else:
@@ -217,7 +226,49 @@ def test_finetune_step_vs_reference_at_bench_shape(tag):
         _grad_report(st, g, tol_rel=0.03, tol_cos=0.0, tol_norm=0.03, ctl_mult=4.0)
 
 
-@pytest.mark.parametrize("tag", ["g8_pretrain_cond", "g8_pretrain_plain"])
+@pytest.mark.parametrize("tag", ["g7_bench_cond", "g7_bench_plain"])
+def test_text_split_mode_vs_reference(tag):
+    """engine.text_split (MART_TEXT_SPLIT=1): the text stream's forward products on two-term operand splits.  Conditioned weights:
+    north_star's absolute 1e-2 on the bf16 path's logits, asserted as such (and the training step still matches the reference's
+    loss and gradients).  Plain weights: closer to the reference than the reference's own one-rounding control."""
+    g = _load(tag)
+    cond = bool(int(g["conditioned"]))
+    model, lit, cfg = _product(g)
+    assert model.engine.text_split is False, "default is the plain bf16 text stream"
+    model.engine.text_split = True
+    batch = _batch(g)
+    B = int(g["B"])
+    gb = {k: v.cuda() for k, v in batch.items()}
+    ids = torch.tensor(cfg["analogy_entity_ids"], device="cuda")
+    ar = torch.arange(B, device="cuda")
+    rows = torch.from_numpy(g["trans_row_index"]).cuda()
+    ref_logits, ref_trans = torch.from_numpy(g["mask_logits"]), torch.from_numpy(g["trans_rows"])
+    model.eval()
+    with torch.no_grad():
+        out, trans = model(**{k: gb[k] for k in ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")}, return_dict=True)
+        ml = out.logits[ar, rows[:, 0]][:, ids].float().cpu()
+        tr = trans[ar[:, None], rows].float().cpu()
+    e_l, rms = float((ml - ref_logits).abs().max()), float((ml - ref_logits).pow(2).mean().sqrt())
+    c_l = float(np.abs(g["ctl::mask_logits"] - ref_logits.numpy()).max())
+    c_rms = float(np.sqrt(((g["ctl::mask_logits"] - ref_logits.numpy()) ** 2).mean()))
+    print(f"\n{tag} text_split: max|dlogit| {e_l:.3e} rms {rms:.3e}  (control {c_l:.3e} / {c_rms:.3e}); trans rows rel-L2 {_rel(tr.numpy(), ref_trans.numpy()):.3e}")
+    st = model.store
+    st.zero_grad()
+    loss = lit.training_step(dict(gb), 1)
+    loss.backward()
+    torch.cuda.synchronize()
+    print(f"   loss hip {float(loss):.6f} reference {float(g['loss']):.6f}")
+    if cond:
+        assert e_l < 1e-2, "north_star: bf16 logits within 1e-2 of the reference CPU path"
+        assert rms < c_rms
+        assert abs(float(loss) - float(g["loss"])) < 5e-3
+        _grad_report(st, g, tol_rel=0.12, tol_cos=0.99, tol_norm=0.08)
+    else:
+        assert e_l < c_l and rms < c_rms, "plain weights: closer to the reference than its own bf16-weight control"
+        _grad_report(st, g, tol_rel=0.03, tol_cos=0.0, tol_norm=0.03, ctl_mult=4.0)
+
+
+@pytest.mark.parametrize("tag", ["g8_pretrain_cond", "g8_pretrain_plain", "g8b_pretrain_p196_cond"])
 def test_pretrain_step_vs_reference(tag):
     """BASELINE configs[4]: L=96, no sep_idx (no reweight; adaptive weights get no gradient), mixed pre_type, LSCE over the
     full entity / relation slices (lit_models/transformer.py:72-90,129-156)."""
@@ -260,7 +311,11 @@ def test_pretrain_step_vs_reference(tag):
     print(f"   tied-embedding gradient rows: entity slice rel-L2 {r_e:.3e}, relation slice {r_r:.3e}; decoder bias gradient {r_b:.3e}")
     if cond:
         assert abs(float(loss) - float(g["loss"])) < 1e-2
-        assert rms < 5e-3 and e_e < 2.5e-2 and e_r < 2.5e-2
+        c_e = float(np.abs(g["ctl::entity_logits"] - g["entity_logits"]).max())
+        c_rms = float(np.sqrt(((g["ctl::entity_logits"] - g["entity_logits"]) ** 2).mean()))
+        c_r = float(np.abs(g["ctl::relation_logits"] - g["relation_logits"]).max())
+        print(f"   control: entity logits max {c_e:.3e} rms {c_rms:.3e}; relation logits max {c_r:.3e}")
+        assert rms <= 1.5 * c_rms and e_e <= 1.5 * c_e and e_r <= 1.5 * max(c_r, c_e), "within 1.5 x the reference's bf16-weight control"
         assert r_e < 0.05 and r_r < 0.05 and r_b < 0.02
         _grad_report(st, g, tol_rel=0.12, tol_cos=0.99, tol_norm=0.08)
     else:
@@ -450,15 +505,27 @@ def test_full_bench_batch_forward_vs_oracle():
 
     ml = forward()
     e_l, rms = float((ml - ml_ref).abs().max()), float((ml - ml_ref).pow(2).mean().sqrt())
+    model.engine.text_split = True                              # split-precision text stream (MART_TEXT_SPLIT=1)
+    mls = forward()
+    model.engine.text_split = False
+    e_s, rms_s = float((mls - ml_ref).abs().max()), float((mls - ml_ref).pow(2).mean().sqrt())
     model.set_precision("fp32")
     ml32 = forward()
     model.set_precision("bf16")
     e32 = float((ml32 - ml_ref).abs().max())
     rank = lambda x: (x > x[torch.arange(B), batch["label"]][:, None]).sum(1) + 1
     same32 = int((rank(ml32) == rank(ml_ref)).sum())
-    print(f"\nB=256 P=196: bf16 path max|dlogit| {e_l:.3e} rms {rms:.3e}; fp32-accurate path max|dlogit| {e32:.3e}, {same32}/256 ranks identical "
+    # the reference's own one-rounding control exists for the first 32 examples (G7): the max norm is compared on that slice, the rms
+    # (independent of the sample size) on all 528 128 logits
+    ctl = torch.from_numpy(g["ctl::mask_logits"]) - torch.from_numpy(g["mask_logits"])
+    c_l, c_rms = float(ctl.abs().max()), float(ctl.pow(2).mean().sqrt())
+    e_l32 = float((ml[:32] - ml_ref[:32]).abs().max())
+    print(f"\nB=256 P=196: bf16 path max|dlogit| {e_l:.3e} (first 32 examples {e_l32:.3e}) rms {rms:.3e}  [control on the first 32: {c_l:.3e} / {c_rms:.3e}]; "
+          f"split-precision text stream max {e_s:.3e} rms {rms_s:.3e}; fp32-accurate path max|dlogit| {e32:.3e}, {same32}/256 ranks identical "
           f"(logit scale {float(ml_ref.abs().max()):.2f})")
-    assert e32 < 1e-3 and rms < 5e-3 and e_l < 3e-2
+    assert e32 < 1e-3
+    assert rms <= 1.5 * c_rms and e_l32 <= 1.5 * c_l and e_l < 2.5e-2, "bf16 path: within 1.5 x the reference's bf16-weight control"
+    assert e_s < 1e-2, "north_star's 1e-2 on bf16 logits (split-precision text stream), all 256 examples"
     lab = ml_ref[torch.arange(B), batch["label"]]
     near = ((ml_ref - lab[:, None]).abs() < 2 * e32).sum(1) - 1
     assert bool(((rank(ml32) - rank(ml_ref)).abs() <= near).all())

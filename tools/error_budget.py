@@ -1,0 +1,77 @@
+"""Per-component bf16 error budget of the mask-row logits.
+
+Runs the fp32-accurate forward (engine_precise) on the golden batch G7 with ONE component class at a time degraded to bf16 operands
+(``PreciseUnimoForward.degrade``) and prints how far the mask logits move from the reference's (tests/golden/g7_bench_*.npz), next to
+the reference's own one-rounding control (``ctl::``: fp32 math, weight matrices rounded to bf16) and the real bf16 training path.
+
+    python tools/error_budget.py [g7_bench_cond|g7_bench_plain]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_parity_full_gpu as T  # noqa: E402  (golden loader + product builder of the parity tests)
+
+TAGS = ["vis_lin", "vis_attn", "txt_lin_lo", "txt_lin_hi", "txt_attn", "fusion", "head_t", "head_s"]
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "g7_bench_cond"
+    g = T._load(tag)
+    model, lit, cfg = T._product(g)
+    batch = T._batch(g)
+    B = int(g["B"])
+    gb = {k: v.cuda() for k, v in batch.items()}
+    ids = torch.tensor(cfg["analogy_entity_ids"], device="cuda")
+    ar = torch.arange(B, device="cuda")
+    rows = torch.from_numpy(g["trans_row_index"]).cuda()
+    ref = torch.from_numpy(g["mask_logits"])
+    keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
+    model.eval()
+
+    def forward():
+        with torch.no_grad():
+            out, trans = model(**{k: gb[k] for k in keys}, return_dict=True)
+            return out.logits[ar, rows[:, 0]][:, ids].float().cpu()
+
+    def report(name, ml):
+        d = ml - ref
+        print(f"{name:34s} max|dlogit| {float(d.abs().max()):.3e}   rms {float(d.pow(2).mean().sqrt()):.3e}", flush=True)
+        return float(d.pow(2).mean().sqrt())
+
+    print(f"{tag}: logit scale {float(ref.abs().max()):.2f}, {ref.numel()} logits")
+    if "ctl::mask_logits" in g:
+        report("reference control (bf16 weights)", torch.from_numpy(g["ctl::mask_logits"]))
+    report("bf16 training path", forward())
+    model.set_precision("fp32")
+    forward()
+    pr = model._precise
+    base = report("fp32-accurate path", forward())
+    var = {}
+    for t in TAGS:
+        pr.degrade = {t}
+        var[t] = report("  only " + t + " in bf16", forward()) ** 2 - base ** 2
+    pr.degrade = set(TAGS)
+    tot = report("  all components in bf16", forward())
+    pr.degrade = set(TAGS) - {"head_t", "head_s"}
+    report("  all but the head", forward())
+    pr.degrade = set(TAGS) - {"head_t", "head_s", "fusion"}
+    report("  all but head + fusion", forward())
+    pr.degrade = set(TAGS) - {"head_t", "head_s", "fusion", "txt_lin_hi", "txt_attn"}
+    report("  all but head/fusion/txt_hi/attn", forward())
+    pr.degrade = {"vis_lin", "vis_attn"}
+    report("  vision side only in bf16", forward())
+    pr.degrade = set()
+    s = sum(max(v, 0.0) for v in var.values())
+    print("variance shares (independent-error model): " + ", ".join(f"{t} {100 * max(v, 0) / s:.0f}%" for t, v in var.items()))
+    print(f"sqrt(sum of the parts) {s ** 0.5:.3e} vs all-in-bf16 {tot:.3e}")
+    model.set_precision("bf16")
+
+
+if __name__ == "__main__":
+    main()

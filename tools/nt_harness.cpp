@@ -1,6 +1,7 @@
 // Standalone driver for mart_gemm_nt (no torch): correctness of the 8-phase K loop against the round-1 loop (bitwise) and a
 // naive reference, a run-to-run race screen, and interleaved A/B timing on the step's shapes.
-//   hipcc --offload-arch=gfx950 -O2 -Iinclude tools/nt_harness.cpp -o tools/nt_harness -Lmkg_analogy_amd/lib -lmart_hip -Wl,-rpath,'$ORIGIN/../mkg_analogy_amd/lib'
+//   tools/build_variant.sh gemm_nt.hip tools/variants/libmart_hip.so -DMART_EXPERIMENTS      (the experiment tile_cfg codes live only in this build)
+//   hipcc --offload-arch=gfx950 -O2 -Iinclude tools/nt_harness.cpp -o tools/nt_harness -Ltools/variants -lmart_hip -Wl,-rpath,'$ORIGIN/variants'
 //   tools/nt_harness [check|time|all] [rounds]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
