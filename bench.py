@@ -339,8 +339,54 @@ def main():
                 "timing": "HIP events around every launch, one step with the side streams (weight gradients, text layers) off: kernel alone on the GPU",
                 "achieved_with_wgrad_overlap": round(fl_ov / (kms_ov * 1e-3) / 1e12, 1) if kms_ov > 0 else None,
                 "avg_launch_ms_with_wgrad_overlap": round(kms_ov / max(n_ov, 1), 4), "other_kernels": others}
+    comm = None
+    if world > 1 and getattr(tr.sync, "reducer", None) is not None and not a.train_only:
+        # Communication diagnostics (outside the timed region: the statistics need one host sync per step): per-bucket start / end events
+        # on the collective stream against the end of the backward pass on the compute stream
+        red = tr.sync.reducer
+        red.timing = True
+        red.stats(reset=True)
+        for i in range(3):
+            tr.train_step(lit, batch, a.warmup + a.steps + 2 + i)
+        barrier()
+        st_ = red.stats(reset=True)
+        red.timing = False
+        comm = {"rccl_world": dist.get_world_size(), "backend": dist.get_backend(), "buckets": st_["buckets"], "bucket_mb": st_["bucket_mb"],
+                "bucket_dtype": st_["bucket_dtype"], "comm_ms_per_step": round(st_["comm_ms"], 3), "comm_exposed_ms": round(st_["comm_exposed_ms"], 3),
+                "steps_measured": st_["steps"],
+                "what": "all-reduce time per step (sum over buckets, collective stream) and the part still running after the backward pass had ended"}
     # Hits@1 of the (untrained, random-init) model on the same batch -- reported to exercise the ranking eval path
     metrics = tr.validate(lit, [batch]) if not a.train_only else {}
+    evalb = None
+    if world == 1 and not a.train_only and not a.no_kernel_timing:
+        # Evaluation-path throughput (lit_models/transformer.py:115-166: forward + scoring + rank of the label), per precision mode
+        def time_eval(prec, split, n=3):
+            lit.args.eval_precision = prec
+            eng_ = getattr(model, "engine", None)
+            old_split = getattr(eng_, "text_split", False)
+            if eng_ is not None and hasattr(eng_, "text_split"):
+                eng_.text_split = split
+            try:
+                m = tr.validate(lit, [batch])
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    m = tr.validate(lit, [batch])
+                barrier()
+                return {"examples_per_s": round(a.batch * n / (time.perf_counter() - t1), 1), "hits1": m.get("Eval_entity/hits1"),
+                        "mean_rank": m.get("Eval_entity/mean_rank")}
+            finally:
+                if eng_ is not None and hasattr(eng_, "text_split"):
+                    eng_.text_split = old_split
+                lit.args.eval_precision = None
+        default_prec = getattr(lit.args, "eval_precision", None) or "bf16"
+        evalb = {"what": "validation pass over the timed batch: forward, scoring head, device-side rank of the label", "default_eval_precision": default_prec,
+                 "bf16": time_eval("bf16", False)}
+        if a.model == "mkgformer":
+            evalb["bf16_text_split"] = time_eval("bf16", True)
+        evalb["fp32"] = time_eval("fp32", False)
+        evalb["eval_examples_per_s"] = evalb[default_prec if default_prec in evalb else "bf16"]["examples_per_s"]
+        evalb["eval_precision"] = default_prec
     parity = None
     if world == 1 and a.model == "mkgformer" and not pre and not a.no_kernel_timing and not a.train_only:
         # the bf16 training path against the fp32-accurate evaluation path (engine_precise: held to the reference at 1e-3 on logits
@@ -349,20 +395,44 @@ def main():
         ids = torch.tensor(cfg["analogy_entity_ids"], device=dev)
         keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
         lg = {}
+        split0 = model.engine.text_split
         with torch.no_grad():
-            for prec in ("bf16", "fp32"):
-                model.set_precision(prec)
+            for prec in ("bf16", "bf16_text_split", "fp32"):
+                model.set_precision("fp32" if prec == "fp32" else "bf16")
+                model.engine.text_split = prec == "bf16_text_split"
                 o, _ = model(**{k: batch[k] for k in keys}, return_dict=True)
                 lg[prec] = o.logits.mask_rows(batch["input_ids"], D.MASK)[:, ids].float()
             model.set_precision("bf16")
-        dl = (lg["bf16"] - lg["fp32"])
+            model.engine.text_split = split0
         lab = batch["label"]
         rk = {k: ((v > v.gather(1, lab[:, None])).sum(1) + 1) for k, v in lg.items()}
-        parity = {"what": "bf16 training path vs fp32-accurate path, mask-row logits of the timed batch and weights (eval mode)",
-                  "max_abs_dlogit": round(float(dl.abs().max()), 5), "rms_dlogit": round(float(dl.pow(2).mean().sqrt()), 6),
-                  "logit_abs_max": round(float(lg["fp32"].abs().max()), 3), "ranks_identical_frac": round(float((rk["bf16"] == rk["fp32"]).float().mean()), 4),
-                  "median_abs_rank_diff": float((rk["bf16"] - rk["fp32"]).abs().float().median()), "entity_head": head,
-                  "note": "plain N(0,0.02) weights: the unscaled fusion softmax of layers 8-11 makes the map chaotic (DESIGN section 5); per-layer parity is in tests/test_parity_full_gpu.py"}
+
+        def cmp(k):
+            dl = lg[k] - lg["fp32"]
+            return {"max_abs_dlogit": round(float(dl.abs().max()), 5), "rms_dlogit": round(float(dl.pow(2).mean().sqrt()), 6),
+                    "ranks_identical_frac": round(float((rk[k] == rk["fp32"]).float().mean()), 4),
+                    "median_abs_rank_diff": float((rk[k] - rk["fp32"]).abs().float().median())}
+        parity = {"what": "bf16 training path vs fp32-accurate path (held to the reference at 1e-3 in tests/test_parity_full_gpu.py), mask-row logits of the timed batch and weights (eval mode)",
+                  **cmp("bf16"), "logit_abs_max": round(float(lg["fp32"].abs().max()), 3), "entity_head": head,
+                  "text_split": {"what": "the same with the text stream's forward products on two-term operand splits (MART_TEXT_SPLIT=1)", **cmp("bf16_text_split")},
+                  "timed_mode": "bf16_text_split" if split0 else "bf16",
+                  "note": "plain N(0,0.02) weights: the unscaled fusion softmax of layers 8-11 makes the map chaotic (DESIGN section 5): the reference itself with only its weight "
+                          "matrices rounded to bf16 moves its logits by 0.50 max / 2.8e-2 rms on this batch (tests/golden/g7_bench_plain.npz ctl::)"}
+    tsplit = None
+    if world == 1 and a.model == "mkgformer" and not a.no_kernel_timing and not a.train_only:
+        # the training step with the text stream in the other precision mode, timed briefly on the same network
+        eng_ = model.engine
+        eng_.text_split = not eng_.text_split
+        for i in range(2):
+            tr.train_step(lit, batch, a.warmup + a.steps + 20 + i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(5):
+            tr.train_step(lit, batch, a.warmup + a.steps + 22 + i)
+        barrier()
+        d3 = time.perf_counter() - t1
+        tsplit = {"text_split": eng_.text_split, "steps": 5, "ms_per_step": round(1000.0 * d3 / 5, 3), "value": round(a.batch * 5 / d3, 2)}
+        eng_.text_split = not eng_.text_split
     alt = None
     if world == 1 and a.model == "mkgformer" and not pre and not a.no_kernel_timing and not a.train_only:
         # the other scoring head, timed briefly on the same network (the head is 0.03 % of the step's FLOPs either way)
@@ -407,6 +477,17 @@ def main():
             out["parity"] = parity
         if alt is not None:
             out["alt_entity_head"] = alt
+        if tsplit is not None:
+            out["alt_text_precision"] = tsplit
+        if evalb is not None:
+            out["eval"] = evalb
+            out["eval_examples_per_s"] = evalb["eval_examples_per_s"]
+            out["eval_precision"] = evalb["eval_precision"]
+        if comm is not None:
+            out["comm"] = comm
+            out["comm_exposed_ms"] = comm["comm_exposed_ms"]
+            out["rccl_world"] = comm["rccl_world"]
+        out["metric_detail"] = f"entity_head={head}, text_split={int(getattr(getattr(model, 'engine', None), 'text_split', False))}"
         if not a.no_cpu_baseline and world == 1 and a.model == "mkgformer" and not pre:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.patch, a.seq_len)

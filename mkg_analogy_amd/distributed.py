@@ -15,18 +15,56 @@ import torch.distributed as dist
 
 
 class BucketedAllReduce:
-    """All-reduce(sum) of ``flat[s:e]`` slices, launched in order as ``ready(upto)`` advances."""
+    """All-reduce(sum) of ``flat[s:e]`` slices, launched in order as ``ready(upto)`` advances.
 
-    def __init__(self, flat: torch.Tensor, buckets: List[Tuple[int, int]], group=None):
+    ``bucket_dtype="bf16"`` (env MART_GRAD_BUCKET_DTYPE=bf16): every bucket is cast to a bf16 staging buffer, reduced, and cast
+    back -- half the bytes per xGMI link (the fallback if RCCL picks a ring, which is per-link bound); fp32 is the
+    default.  ``timing=True`` (MART_COMM_TIMING=1, bench.py for N > 1): start / end events per bucket on the collective stream and
+    an end-of-backward event on the producer's stream give ``stats()``: the total time inside the collectives and the part of it
+    that was EXPOSED (still running after the backward pass had finished: what the step actually waited for)."""
+
+    def __init__(self, flat: torch.Tensor, buckets: List[Tuple[int, int]], group=None, bucket_dtype: Optional[str] = None,
+                 timing: Optional[bool] = None):
+        import os
         self.flat, self.buckets, self.group = flat, buckets, group
         self.next = 0
         self.handles = []
         self.side: Optional[torch.cuda.Stream] = torch.cuda.Stream() if flat.is_cuda else None
         self.on_bucket = None          # optional callback(end_offset): runs right after a bucket's all-reduce, on the stream that waits for it
+        self.bucket_dtype = (bucket_dtype or os.environ.get("MART_GRAD_BUCKET_DTYPE", "fp32")).lower()
+        assert self.bucket_dtype in ("fp32", "bf16"), "MART_GRAD_BUCKET_DTYPE: fp32 or bf16"
+        self.timing = (os.environ.get("MART_COMM_TIMING", "0") == "1") if timing is None else bool(timing)
+        self._stage = None
+        self._ev: List[tuple] = []
+        self._bwd_end = None
+        self._stats = dict(steps=0, comm_ms=0.0, exposed_ms=0.0)
 
     def begin(self) -> None:
         self.next = 0
         self.handles = []
+        self._ev = []
+
+    def _reduce(self, s: int, e: int):
+        """One bucket on the current stream: the collective (and the casts around it in bf16 mode)."""
+        seg = self.flat[s:e]
+        if self.bucket_dtype == "bf16":
+            if self._stage is None:
+                self._stage = torch.empty(max(b - a for a, b in self.buckets), device=self.flat.device, dtype=torch.bfloat16)
+            st = self._stage[:e - s]
+            if seg.is_cuda:
+                from . import ops
+                ops.cast_f32_bf16(seg, st)
+            else:
+                st.copy_(seg)
+            h = dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            h.wait()                                               # stream-side on CUDA; the staging buffer is reused by the next bucket
+            if seg.is_cuda:
+                from . import ops
+                ops.cast_bf16_f32(st, seg)
+            else:
+                seg.copy_(st)
+            return None
+        return dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def ready(self, upto: int, events=()) -> None:
         """Gradients below ``upto`` are final once the current stream and ``events`` (recorded on the producer's other
@@ -41,25 +79,56 @@ class BucketedAllReduce:
                     self.side.wait_event(ev)
                     for x in events:
                         self.side.wait_event(x)
-                    h = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                    self.handles.append(h)
+                    if self.timing:
+                        t0 = torch.cuda.Event(enable_timing=True)
+                        t0.record(self.side)
+                    h = self._reduce(s, e)
+                    if h is not None:
+                        self.handles.append(h)
+                    if self.on_bucket is not None or self.timing:
+                        if h is not None:
+                            h.wait()                               # stream-side wait (the side stream, not the host)
+                    if self.timing:
+                        t1 = torch.cuda.Event(enable_timing=True)
+                        t1.record(self.side)
+                        self._ev.append((t0, t1))
                     if self.on_bucket is not None:
-                        h.wait()                                   # stream-side wait (the side stream, not the host)
                         self.on_bucket(e)
             else:
-                h = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self.handles.append(h)
+                h = self._reduce(s, e)
+                if h is not None:
+                    self.handles.append(h)
                 if self.on_bucket is not None:
-                    h.wait()
+                    if h is not None:
+                        h.wait()
                     self.on_bucket(e)
 
     def finish(self) -> None:
+        if self.timing and self.side is not None:
+            self._bwd_end = torch.cuda.Event(enable_timing=True)
+            self._bwd_end.record(torch.cuda.current_stream())     # the backward pass (on the producer's stream) ends here
         self.ready(self.flat.numel())
         for h in self.handles:
             h.wait()
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         self.handles = []
+        if self.timing and self.side is not None and self._ev:
+            torch.cuda.current_stream().synchronize()
+            comm = sum(a.elapsed_time(b) for a, b in self._ev)
+            exposed = max(0.0, self._bwd_end.elapsed_time(self._ev[-1][1]))
+            self._stats["steps"] += 1
+            self._stats["comm_ms"] += comm
+            self._stats["exposed_ms"] += min(exposed, comm)
+
+    def stats(self, reset: bool = False) -> dict:
+        """Per-step averages since the last reset: time inside the collectives / time the step waited for them after the backward pass."""
+        n = max(1, self._stats["steps"])
+        out = dict(steps=self._stats["steps"], comm_ms=self._stats["comm_ms"] / n, comm_exposed_ms=self._stats["exposed_ms"] / n,
+                   buckets=len(self.buckets), bucket_mb=round(4e-6 * max(b - a for a, b in self.buckets), 1), bucket_dtype=self.bucket_dtype)
+        if reset:
+            self._stats = dict(steps=0, comm_ms=0.0, exposed_ms=0.0)
+        return out
 
 
 def rank_seed(base_seed: int, rank: int) -> int:

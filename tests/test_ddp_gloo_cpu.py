@@ -38,6 +38,16 @@ def _worker(rank, world, port, q):
     assert red.next == 3
     other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)))
     ok = torch.allclose(flat, mine + other, atol=1e-6)
+    # bf16 gradient buckets (MART_GRAD_BUCKET_DTYPE=bf16: half the bytes per link) and the communication statistics bench.py reports
+    flat2 = mine.clone()
+    red2 = BucketedAllReduce(flat2, buckets, bucket_dtype="bf16", timing=True)
+    red2.begin()
+    red2.ready(6500)
+    red2.finish()
+    want = mine.to(torch.bfloat16).float() + other.to(torch.bfloat16).float()
+    ok = ok and torch.allclose(flat2, want.to(torch.bfloat16).float(), atol=1e-6)
+    st = red2.stats()
+    ok = ok and set(st) >= {"steps", "comm_ms", "comm_exposed_ms", "buckets", "bucket_mb", "bucket_dtype"} and st["bucket_dtype"] == "bf16" and st["buckets"] == 3
     ranks = all_gather_ranks(np.array([rank * 10 + 1, rank * 10 + 2]))
     q.put((rank, ok, ranks.tolist()))
     dist.destroy_process_group()

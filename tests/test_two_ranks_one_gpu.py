@@ -27,3 +27,6 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["loss"] == d["loss"]
     assert d["replica_param_checksum_spread"] == 0.0, d
+    # communication diagnostics of the N > 1 path
+    assert d["rccl_world"] == 2 and d["comm"]["buckets"] >= 1 and d["comm"]["bucket_dtype"] == "fp32"
+    assert d["comm"]["comm_ms_per_step"] > 0 and 0 <= d["comm_exposed_ms"] <= d["comm"]["comm_ms_per_step"] + 1e-6

@@ -22,16 +22,38 @@ TAGS = ["vis_lin", "vis_attn", "txt_lin_lo", "txt_lin_hi", "txt_attn", "fusion",
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "g7_bench_cond"
-    g = T._load(tag)
-    model, lit, cfg = T._product(g)
-    batch = T._batch(g)
-    B = int(g["B"])
-    gb = {k: v.cuda() for k, v in batch.items()}
-    ids = torch.tensor(cfg["analogy_entity_ids"], device="cuda")
-    ar = torch.arange(B, device="cuda")
-    rows = torch.from_numpy(g["trans_row_index"]).cuda()
-    ref = torch.from_numpy(g["mask_logits"])
     keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
+    if tag == "bench":
+        # the network bench.py times (torch-initialised N(0,0.02) weights, 11292-entity head), first 64 examples of its batch; no reference
+        # run exists for it, so the fp32-accurate path (held to the reference at 1e-3 elsewhere) is the yardstick
+        import bench
+        from mkg_analogy_amd import data_synth as D
+        model, lit, cfg = bench.build(16, seed=0, device=torch.device("cuda", 0), entity_head=D.N_ENT)
+        model.finalize()
+        full = D.make_batch(256, 64, seed=1234, n_labels=D.N_ENT)
+        B = 64
+        gb = {k: v[:B].cuda() for k, v in full.items()}
+        g = {}
+        ids = torch.tensor(cfg["analogy_entity_ids"], device="cuda")
+        ar = torch.arange(B, device="cuda")
+        _, mi = (gb["input_ids"] == 103).nonzero(as_tuple=True)
+        rows = mi[:, None]
+        model.eval()
+        model.set_precision("fp32")
+        with torch.no_grad():
+            out, _ = model(**{k: gb[k] for k in keys}, return_dict=True)
+            ref = out.logits[ar, rows[:, 0]][:, ids].float().cpu()
+        model.set_precision("bf16")
+    else:
+        g = T._load(tag)
+        model, lit, cfg = T._product(g)
+        batch = T._batch(g)
+        B = int(g["B"])
+        gb = {k: v.cuda() for k, v in batch.items()}
+        ids = torch.tensor(cfg["analogy_entity_ids"], device="cuda")
+        ar = torch.arange(B, device="cuda")
+        rows = torch.from_numpy(g["trans_row_index"]).cuda()
+        ref = torch.from_numpy(g["mask_logits"])
     model.eval()
 
     def forward():
@@ -48,6 +70,9 @@ def main():
     if "ctl::mask_logits" in g:
         report("reference control (bf16 weights)", torch.from_numpy(g["ctl::mask_logits"]))
     report("bf16 training path", forward())
+    model.engine.text_split = True
+    report("bf16 path, split-precision text", forward())
+    model.engine.text_split = False
     model.set_precision("fp32")
     forward()
     pr = model._precise
