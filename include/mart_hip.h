@@ -280,11 +280,12 @@ int mart_block_table(const void* src_bf16, void* dst_bf16, const int64_t* table,
  * The reference is fp32 end to end.  Precise mode keeps activations in fp32 and runs every dense contraction through
  * mart_gemm_nt on two-term bf16 splits laid out K-concatenated (K' = 3K):  role 0 (activations) [hi|lo|hi],
  * role 1 (weights) [hi|hi|lo]  =>  hi*hi + lo*hi + hi*lo accumulated in fp32. */
-int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16 /* [rows, 3K] */, int rows, int K, int role, void* stream);
+int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16 /* [rows, 3K] (terms 2) or [rows, 6K] (terms 3) */, int rows, int K, int role, int terms, void* stream);
+/* terms = 3 (verification mode): x = h + m + l, six products hh + hm + mh + mm + hl + lh (exact to ~2^-24): role 0 [h|h|m|m|h|l], role 1 [h|m|h|m|l|h] */
 /* ... of gathered source rows: dst row r = split(src[gather[r]]).  The scoring head of the TRAINING path runs on these too (mask rows of
  * trans_hidden x the scored rows of the tied embedding, modeling_unimo.py:958): 2 x 768 x (B + ids) extra MFMA flops per step buy back the
  * third of the bf16 logit error that the head alone contributed (tools/error_budget.py). */
-int mart_split_bf16x3_rows(const float* src, long long ld, const int32_t* gather, void* dst_bf16 /* [rows, 3K] */, int rows, int K, int role, void* stream);
+int mart_split_bf16x3_rows(const float* src, long long ld, const int32_t* gather, void* dst_bf16 /* [rows, 3K | 6K] */, int rows, int K, int role, int terms, void* stream);
 /* f32 twins of mart_patchify / mart_patchify_gather (index NULL: pixels are [B,2,3,S,S]; else table rows, -1 = zero image) and mart_vision_assemble */
 int mart_patchify_f32(const float* pixels_or_table, const int32_t* index, float* out, int B, int S, int p, void* stream);
 int mart_vision_assemble_f32(const float* patch, const float* cls, const float* pos, float* s, int B, int P, int H, int tail_shift, void* stream);
@@ -299,6 +300,24 @@ typedef struct {
   float* ctx; long long ldctx;
 } mart_attn_f32_desc;
 int mart_attn_fwd_f32(const mart_attn_f32_desc* d, void* stream);
+
+/* ---- fp32-accurate backward (verification mode: model.set_precision("fp32") in a training step; engine_precise.PreciseUnimoTrain).
+ * Autograd of the same reference lines as the forward entry points above.  dq is written; dk / dv / dpk / dpv are ACCUMULATED (atomics: zero
+ * them first; the prefix gradients land in the text layer's k / v gradient blocks); dw[2] accumulates d(adaptive_weight.0 / .1) with
+ * torch.clamp's sub-gradient (modeling_unimo.py:342-349). */
+typedef struct {
+  mart_attn_f32_desc f;                                            /* the forward call (ctx unused) */
+  const float* dctx; long long lddctx;
+  float* dq; float* dk; float* dv; long long lddq, lddk, lddv;
+  float* dpk; float* dpv; long long lddp;
+  float* dw;
+} mart_attn_bwd_f32_desc;
+int mart_attn_bwd_f32(const mart_attn_bwd_f32_desc* d, void* stream);
+/* row-stacked two-term splits for weight gradients through mart_gemm_tn (contraction over 3M rows): role 0 (X) [hi;lo;hi], role 1 (Y) [hi;hi;lo] */
+int mart_split_bf16x3_stack(const float* src, long long ld, void* dst_bf16 /* [3M | 6M, K] */, int M, int K, int role, int terms, void* stream);
+int mart_act_f32(const float* z, float* a, int act, long long n, void* stream);                       /* a = act(z), erf GELU / quick-GELU in f32 */
+int mart_act_bwd_f32(const float* dy, const float* z, int act, float* dz, long long n, void* stream);  /* dz = dy * act'(z) */
+int mart_colsum_f32(const float* src, long long ld, float* out /* [C], accumulated */, int R, int C, void* stream);
 
 #ifdef __cplusplus
 }

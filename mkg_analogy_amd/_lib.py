@@ -67,6 +67,11 @@ class AttnF32(C.Structure):
                 ("ctx", vp), ("ldctx", i64)]
 
 
+class AttnBwdF32(C.Structure):
+    _fields_ = [("f", AttnF32), ("dctx", vp), ("lddctx", i64), ("dq", vp), ("dk", vp), ("dv", vp), ("lddq", i64), ("lddk", i64), ("lddv", i64),
+                ("dpk", vp), ("dpv", vp), ("lddp", i64), ("dw", vp)]
+
+
 class AttnBwd(C.Structure):
     _fields_ = [("f", AttnFwd), ("dctx", vp), ("lddctx", i32), ("delta", vp),
                 ("dq", vp), ("dk", vp), ("dv", vp), ("lddq", i32), ("lddk", i32), ("lddv", i32),
@@ -135,8 +140,13 @@ _SIGS = {
     "mart_adamw": (i32, [C.POINTER(AdamW), vp]),
     "mart_transpose_table": (i32, [vp, vp, vp, i32, vp]),
     "mart_block_table": (i32, [vp, vp, vp, i32, vp]),
-    "mart_split_bf16x3": (i32, [vp, i64, vp, i32, i32, i32, vp]),
-    "mart_split_bf16x3_rows": (i32, [vp, i64, vp, vp, i32, i32, i32, vp]),
+    "mart_split_bf16x3": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
+    "mart_split_bf16x3_rows": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp]),
+    "mart_split_bf16x3_stack": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
+    "mart_act_f32": (i32, [vp, vp, i32, i64, vp]),
+    "mart_act_bwd_f32": (i32, [vp, vp, i32, vp, i64, vp]),
+    "mart_colsum_f32": (i32, [vp, i64, vp, i32, i32, vp]),
+    "mart_attn_bwd_f32": (i32, [C.POINTER(AttnBwdF32), vp]),
     "mart_patchify_f32": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "mart_vision_assemble_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "mart_attn_fwd_f32": (i32, [vp, vp]),

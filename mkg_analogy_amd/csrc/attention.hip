@@ -15,6 +15,9 @@
 
 namespace {
 
+#ifndef ATTN_PK
+#define ATTN_PK 1                        // packed f32x2 softmax arithmetic (0: one scalar VALU instruction per score)
+#endif
 constexpr int NTH = 256;                 // 4 waves
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int TILE_BYTES = 64 * 128;     // 64 rows x 64 bf16
@@ -250,6 +253,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_fwd_k(mart_attn_fwd_desc p) {
         }
         // two scores per VALU instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32): a wave64 VALU
         // instruction occupies the SIMD for 4 cycles, and this loop -- not the MFMAs -- is what bounds the kernel
+#if ATTN_PK
         f32x2 rs2 = {0.f, 0.f};
         const f32x2 c22 = {c2, c2}, mn2 = {m_new, m_new};
 #pragma unroll
@@ -262,6 +266,20 @@ __global__ __launch_bounds__(NTH, 2) void attn_fwd_k(mart_attn_fwd_desc p) {
             pv[u][t][r] = e[0]; pv[u][t][r + 1] = e[1];
           }
         rs = rs2[0] + rs2[1];
+#else
+        float rsa = 0.f, rsb = 0.f;
+        const float nm = -m_new;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], c2, nm));
+            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r + 1], c2, nm));
+            rsa += e0; rsb += e1;
+            pv[u][t][r] = e0; pv[u][t][r + 1] = e1;
+          }
+        rs = rsa + rsb;
+#endif
         m_run[u] = m_new;
       } else {
         float mx = -1.0e30f;
@@ -856,6 +874,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
           const int qd = 2 * a + q2;
           const f32x4 l4 = *(const f32x4*)(sLse + t * FQ + 8 * qd + 4 * hh);
           const f32x4 d4 = *(const f32x4*)(sDel + t * FQ + 8 * qd + 4 * hh);
+#if ATTN_PK
           const f32x2 c22 = {c2, c2};
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
@@ -866,6 +885,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
             pd8[4 * q2 + e] = pr[0]; pd8[4 * q2 + e + 1] = pr[1];
             ds8[4 * q2 + e] = ds[0]; ds8[4 * q2 + e + 1] = ds[1];
           }
+#else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * qd + e;
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -l4[e]));
+            pd8[4 * q2 + e] = pr;
+            ds8[4 * q2 + e] = pr * (dp[r] - d4[e]);
+          }
+#endif
         }
         const bf16x8 pf = pack8(pd8);
         const bf16x8 df = pack8(ds8);

@@ -7,27 +7,43 @@
 //     A' = [ hi | lo | hi ]   (activations, role 0)        B' = [ hi | hi | lo ]   (weights, role 1)
 // (the dropped lo*lo term is 2^-16 relative).  Attention and the image-text fusion softmax(ctx vis^T) vis run in plain
 // fp32 FMA arithmetic in attn_f32_k (no MFMA: 7 % of the FLOPs, and the softmax path is the precision-critical part).
-// Forward only: this mode exists for evaluation / parity, training stays on the bf16 path.
+// Evaluation runs the forward half; the backward half (end of this file) exists for verification: gradients against the fp32 reference.
 #include "common.h"
 #include "mart_hip.h"
 
 namespace {
 
+// terms = 2: the layout above (3 blocks).  terms = 3 (verification mode: gradients on chaotic weights need products exact to ~2^-24):
+// x = h + m + l (24 mantissa bits), six products  hh + hm + mh + mm + hl + lh  =>  role 0 [h|h|m|m|h|l], role 1 [h|m|h|m|l|h]  (K' = 6K).
+__device__ __forceinline__ void split_terms(const f32x4 x, bf16x4& h, bf16x4& m, bf16x4& l) {
+  h = f4_to_bf4(x);
+  const f32x4 hf = bf4_to_f4(h);
+  const f32x4 r1 = {x[0] - hf[0], x[1] - hf[1], x[2] - hf[2], x[3] - hf[3]};
+  m = f4_to_bf4(r1);
+  const f32x4 mf = bf4_to_f4(m);
+  l = f4_to_bf4(f32x4{r1[0] - mf[0], r1[1] - mf[1], r1[2] - mf[2], r1[3] - mf[3]});
+}
 __global__ void split3_k(const float* __restrict__ src, long long ld, bf16* __restrict__ dst, int rows, int K, int role,
-                         const int32_t* __restrict__ gather) {
+                         const int32_t* __restrict__ gather, int terms) {
   const long long total = (long long)rows * (K / 4);
+  const int W = terms == 3 ? 6 : 3;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / (K / 4);
     const int c = (int)(i % (K / 4)) * 4;
     const long long sr = gather ? (long long)gather[r] : r;
     const f32x4 x = *(const f32x4*)(src + sr * ld + c);
-    const bf16x4 hi = f4_to_bf4(x);
-    const f32x4 hf = bf4_to_f4(hi);
-    const bf16x4 lo = f4_to_bf4(f32x4{x[0] - hf[0], x[1] - hf[1], x[2] - hf[2], x[3] - hf[3]});
-    bf16* o = dst + r * 3LL * K + c;
-    *(bf16x4*)(o) = hi;
-    *(bf16x4*)(o + K) = role == 0 ? lo : hi;
-    *(bf16x4*)(o + 2 * K) = role == 0 ? hi : lo;
+    bf16x4 h, m, l;
+    split_terms(x, h, m, l);
+    bf16* o = dst + r * (long long)W * K + c;
+    if (terms == 3) {
+      const bf16x4 a[6] = {h, h, m, m, h, l}, b[6] = {h, m, h, m, l, h};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) *(bf16x4*)(o + (long long)t * K) = role == 0 ? a[t] : b[t];
+    } else {
+      *(bf16x4*)(o) = h;
+      *(bf16x4*)(o + K) = role == 0 ? m : h;
+      *(bf16x4*)(o + 2 * K) = role == 0 ? h : m;
+    }
   }
 }
 
@@ -155,6 +171,208 @@ __global__ __launch_bounds__(256) void attn_f32_k(mart_attn_f32_desc p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- fp32-accurate BACKWARD (verification mode)
+// Gradients of the precise forward, so that the training step can be held to the fp32 reference at ~1e-3 where the bf16 path can only be
+// compared with a control (plain N(0,0.02) weights: tests/test_parity_full_gpu.py).  Dense contractions reuse the split-operand GEMMs
+// (dgrad: K-concatenated splits through mart_gemm_nt; wgrad: ROW-concatenated splits through mart_gemm_tn, contraction over 3M rows); the
+// kernels below are the pieces without an MFMA form.  Speed is not a goal here (atomics, plain FMA loops).
+
+// dst[3M, K] bf16: role 0 (X of X^T Y) = [hi ; lo ; hi], role 1 (Y) = [hi ; hi ; lo]  =>  X'^T Y' = hi^T hi + lo^T hi + hi^T lo
+__global__ void split3_rows_k(const float* __restrict__ src, long long ld, bf16* __restrict__ dst, int M, int K, int role, int terms) {
+  const long long total = (long long)M * (K / 4);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / (K / 4);
+    const int c = (int)(i % (K / 4)) * 4;
+    const f32x4 x = *(const f32x4*)(src + r * ld + c);
+    bf16x4 h, m, l;
+    split_terms(x, h, m, l);
+    if (terms == 3) {
+      const bf16x4 a[6] = {h, h, m, m, h, l}, b[6] = {h, m, h, m, l, h};
+#pragma unroll
+      for (int t = 0; t < 6; ++t) *(bf16x4*)(dst + ((long long)t * M + r) * K + c) = role == 0 ? a[t] : b[t];
+    } else {
+      *(bf16x4*)(dst + r * K + c) = h;
+      *(bf16x4*)(dst + ((long long)M + r) * K + c) = role == 0 ? m : h;
+      *(bf16x4*)(dst + (2LL * M + r) * K + c) = role == 0 ? h : m;
+    }
+  }
+}
+__global__ void act_f32_k(const float* __restrict__ z, float* __restrict__ a, int act, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) a[i] = act_fwd(z[i], act);
+}
+__global__ void act_bwd_f32_k(const float* __restrict__ dy, const float* __restrict__ z, int act, float* __restrict__ dz, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dz[i] = dy[i] * act_grad(z[i], act);
+}
+// out[c] += sum_r src[r, c]   (bias gradients; 64 columns x 4 row lanes per workgroup, one atomic per column and workgroup)
+__global__ __launch_bounds__(256) void colsum_f32_k(const float* __restrict__ src, long long ld, float* __restrict__ out, int R, int C) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int per = (R + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per, r1 = min(R, r0 + per);
+  float acc = 0.f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) acc += src[(long long)r * ld + c];
+  part[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// Backward of attn_f32_k: one workgroup = QTB query rows of one (batch, head); probabilities are recomputed exactly as the forward does.
+//   P = softmax(v), v = s * scale * f (+ mask);  dP = dctx V^T;  dv_ = P o (dP - rowsum(P o dP));  d(q.k) = dv_ * f * scale
+//   dq (written), dk / dv / prefix gradients (atomically accumulated: callers zero them), d(adaptive weights) (atomically accumulated,
+//   clamp sub-gradient = 1 inside AND at the bounds, as torch.clamp's backward, modeling_unimo.py:342-349).
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_f32_k(mart_attn_bwd_f32_desc pb) {
+  constexpr int QTB = D >= 256 ? 8 : 16;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const mart_attn_f32_desc& p = pb.f;
+  const int Stot = p.Lp + p.Sk;
+  float* qs = sm;                        // [QTB][D] queries
+  float* gs = qs + QTB * D;              // [QTB][D] d(ctx)
+  float* pr = gs + QTB * D;              // [QTB][Stot] probabilities
+  float* ds = pr + QTB * Stot;           // [QTB][Stot] dP, then d(q.k)
+  float* sp = ds + QTB * Stot;           // [QTB][Stot] scaled raw scores (for the adaptive-weight gradients)
+  const int q0 = blockIdx.x * QTB, h = blockIdx.y;
+  const long long b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int nq = min(QTB, p.Sq - q0);
+  for (int i = tid; i < QTB * D; i += 256) {
+    const int r = i / D, d = i % D;
+    qs[i] = r < nq ? p.q[(b * p.Sq + q0 + r) * p.ldq + h * D + d] : 0.f;
+    gs[i] = r < nq ? pb.dctx[(b * p.Sq + q0 + r) * pb.lddctx + h * D + d] : 0.f;
+  }
+  __syncthreads();
+  for (int j = tid; j < Stot; j += 256) {
+    const float* kr = j < p.Lp ? p.pk + (b * p.Lp + j) * p.ldp + h * D : p.k + (b * p.Sk + (j - p.Lp)) * p.ldk + h * D;
+    const float* vr = j < p.Lp ? p.pv + (b * p.Lp + j) * p.ldp + h * D : p.v + (b * p.Sk + (j - p.Lp)) * p.ldv + h * D;
+    float acc[QTB], dpa[QTB];
+#pragma unroll
+    for (int r = 0; r < QTB; ++r) { acc[r] = 0.f; dpa[r] = 0.f; }
+    for (int d = 0; d < D; d += 4) {
+      const f32x4 kv = *(const f32x4*)(kr + d), vv = *(const f32x4*)(vr + d);
+#pragma unroll
+      for (int r = 0; r < QTB; ++r) {
+        const f32x4 qv = *(const f32x4*)(qs + r * D + d), gv = *(const f32x4*)(gs + r * D + d);
+        acc[r] = fmaf(qv[0], kv[0], acc[r]); acc[r] = fmaf(qv[1], kv[1], acc[r]);
+        acc[r] = fmaf(qv[2], kv[2], acc[r]); acc[r] = fmaf(qv[3], kv[3], acc[r]);
+        dpa[r] = fmaf(gv[0], vv[0], dpa[r]); dpa[r] = fmaf(gv[1], vv[1], dpa[r]);
+        dpa[r] = fmaf(gv[2], vv[2], dpa[r]); dpa[r] = fmaf(gv[3], vv[3], dpa[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < QTB; ++r) { pr[r * Stot + j] = acc[r]; ds[r * Stot + j] = dpa[r]; }
+  }
+  __syncthreads();
+  {
+    const int wave = tid >> 6, lane = tid & 63;
+    float w0 = 1.f, w1 = 1.f; int s = 0x7fffffff;
+    if (p.sep) {
+      s = (int)p.sep[b * p.sep_stride];
+      w0 = fminf(fmaxf(*p.w0, 0.f), 0.5f);
+      w1 = fminf(fmaxf(*p.w1, 0.5f), 1.f);
+    }
+    float dc0 = 0.f, dc1 = 0.f;
+    for (int r = wave; r < nq; r += 4) {
+      const int qi = q0 + r;
+      float mx = -3.0e38f;
+      for (int j = lane; j < Stot; j += 64) {
+        const float spre = pr[r * Stot + j] * p.scale;
+        float v = spre;
+        if (p.sep && j >= s && !(p.rw_skip_row0 && qi == 0)) v *= (qi < s ? w0 : w1);
+        if (p.attn_mask && p.attn_mask[b * p.Sk + j] == 0) v += -10000.0f;
+        sp[r * Stot + j] = spre;
+        pr[r * Stot + j] = v;
+        mx = fmaxf(mx, v);
+      }
+      mx = wave_max(mx);
+      float sum = 0.f;
+      for (int j = lane; j < Stot; j += 64) {
+        const float e = expf(pr[r * Stot + j] - mx);
+        pr[r * Stot + j] = e;
+        sum += e;
+      }
+      sum = wave_sum(sum);
+      const float inv = 1.f / sum;
+      float dl = 0.f;
+      for (int j = lane; j < Stot; j += 64) {
+        const float pj = pr[r * Stot + j] * inv;
+        pr[r * Stot + j] = pj;
+        dl += pj * ds[r * Stot + j];
+      }
+      dl = wave_sum(dl);
+      for (int j = lane; j < Stot; j += 64) {
+        const float dv_ = pr[r * Stot + j] * (ds[r * Stot + j] - dl);        // gradient w.r.t. the post-reweight score
+        float f = 1.f;
+        if (p.sep && j >= s && !(p.rw_skip_row0 && qi == 0)) {
+          f = qi < s ? w0 : w1;
+          if (qi < s) dc0 += dv_ * sp[r * Stot + j]; else dc1 += dv_ * sp[r * Stot + j];
+        }
+        ds[r * Stot + j] = dv_ * f * p.scale;                               // gradient w.r.t. q . k
+      }
+    }
+    if (p.sep && pb.dw) {
+      dc0 = wave_sum(dc0); dc1 = wave_sum(dc1);
+      if (lane == 0) {
+        const float r0 = *p.w0, r1 = *p.w1;
+        if (r0 >= 0.f && r0 <= 0.5f && dc0 != 0.f) atomicAdd(pb.dw, dc0);
+        if (r1 >= 0.5f && r1 <= 1.f && dc1 != 0.f) atomicAdd(pb.dw + 1, dc1);
+      }
+    }
+  }
+  __syncthreads();
+  // dq[r][d] = sum_j ds[r][j] key_j[d]   (thread = column d)
+  for (int d = tid; d < D; d += 256) {
+    float acc[QTB];
+#pragma unroll
+    for (int r = 0; r < QTB; ++r) acc[r] = 0.f;
+    for (int j = 0; j < Stot; ++j) {
+      const float kk = j < p.Lp ? p.pk[(b * p.Lp + j) * p.ldp + h * D + d] : p.k[(b * p.Sk + (j - p.Lp)) * p.ldk + h * D + d];
+#pragma unroll
+      for (int r = 0; r < QTB; ++r) acc[r] = fmaf(ds[r * Stot + j], kk, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < QTB; ++r)
+      if (r < nq) pb.dq[(b * p.Sq + q0 + r) * pb.lddq + h * D + d] = acc[r];
+  }
+  // dk_j[d] += sum_r ds[r][j] q_r[d];  dv_j[d] += sum_r P[r][j] dctx_r[d]
+  for (long long i = tid; i < (long long)Stot * D; i += 256) {
+    const int j = (int)(i / D), d = (int)(i % D);
+    float ak = 0.f, av = 0.f;
+#pragma unroll
+    for (int r = 0; r < QTB; ++r) {
+      ak = fmaf(ds[r * Stot + j], qs[r * D + d], ak);
+      av = fmaf(pr[r * Stot + j], gs[r * D + d], av);
+    }
+    if (j < p.Lp) {
+      atomicAdd(pb.dpk + (b * p.Lp + j) * pb.lddp + h * D + d, ak);
+      atomicAdd(pb.dpv + (b * p.Lp + j) * pb.lddp + h * D + d, av);
+    } else {
+      atomicAdd(pb.dk + (b * p.Sk + (j - p.Lp)) * pb.lddk + h * D + d, ak);
+      atomicAdd(pb.dv + (b * p.Sk + (j - p.Lp)) * pb.lddv + h * D + d, av);
+    }
+  }
+}
+
+template <int D>
+int launch_attn_bwd(const mart_attn_bwd_f32_desc* d, hipStream_t st) {
+  constexpr int QTB = D >= 256 ? 8 : 16;
+  const int Stot = d->f.Lp + d->f.Sk;
+  const size_t lds = (size_t)(2 * QTB * D + 3 * QTB * Stot) * sizeof(float);
+  MART_CHECK(lds <= 160 * 1024, "attn_bwd_f32: keys do not fit the LDS score tiles");
+  static MartAttrOnce once;
+  bool* attr_set = once.slot();
+  auto kern = attn_bwd_f32_k<D>;
+  if (!*attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      mart_set_error("attn_bwd_f32: hipFuncSetAttribute failed");
+      return -2;
+    }
+    *attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((d->f.Sq + QTB - 1) / QTB, d->f.nh, d->f.B), dim3(256), lds, st, *d);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int D>
 int launch_attn(const mart_attn_f32_desc* d, hipStream_t st) {
   const int Stot = d->Lp + d->Sk;
@@ -177,20 +395,20 @@ int launch_attn(const mart_attn_f32_desc* d, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mart_split_bf16x3_rows(const float* src, long long ld, const int32_t* gather, void* dst_bf16, int rows, int K, int role, void* stream) {
-  MART_CHECK(src && gather && dst_bf16 && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3_rows: bad args");
+extern "C" int mart_split_bf16x3_rows(const float* src, long long ld, const int32_t* gather, void* dst_bf16, int rows, int K, int role, int terms, void* stream) {
+  MART_CHECK((terms == 2 || terms == 3) && src && gather && dst_bf16 && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3_rows: bad args");
   const long long total = (long long)rows * (K / 4);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(split3_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role, gather);
+  hipLaunchKernelGGL(split3_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role, gather, terms);
   MART_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16, int rows, int K, int role, void* stream) {
-  MART_CHECK(src && dst_bf16 && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3: bad args");
+extern "C" int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16, int rows, int K, int role, int terms, void* stream) {
+  MART_CHECK((terms == 2 || terms == 3) && src && dst_bf16 && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3: bad args");
   const long long total = (long long)rows * (K / 4);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(split3_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(split3_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role, (const int32_t*)nullptr, terms);
   MART_LAUNCH_CHECK();
   return 0;
 }
@@ -220,5 +438,43 @@ extern "C" int mart_attn_fwd_f32(const mart_attn_f32_desc* d, void* stream) {
   if (d->D == 64) return launch_attn<64>(d, (hipStream_t)stream);
   if (d->D == 768) return launch_attn<768>(d, (hipStream_t)stream);
   mart_set_error("attn_f32: head dim must be 64 (multi-head attention) or 768 (fusion)");
+  return -1;
+}
+
+extern "C" int mart_split_bf16x3_stack(const float* src, long long ld, void* dst_bf16, int M, int K, int role, int terms, void* stream) {
+  MART_CHECK((terms == 2 || terms == 3) && src && dst_bf16 && M > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3_stack: bad args");
+  const long long total = (long long)M * (K / 4);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(split3_rows_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, M, K, role, terms);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_act_f32(const float* z, float* a, int act, long long n, void* stream) {
+  MART_CHECK(z && a && n > 0 && act >= ACT_NONE && act <= ACT_QGELU, "act_f32: bad args");
+  hipLaunchKernelGGL(act_f32_k, dim3((int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream, z, a, act, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_act_bwd_f32(const float* dy, const float* z, int act, float* dz, long long n, void* stream) {
+  MART_CHECK(dy && z && dz && n > 0 && act >= ACT_NONE && act <= ACT_QGELU, "act_bwd_f32: bad args");
+  hipLaunchKernelGGL(act_bwd_f32_k, dim3((int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192)), dim3(256), 0, (hipStream_t)stream, dy, z, act, dz, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_colsum_f32(const float* src, long long ld, float* out, int R, int C, void* stream) {
+  MART_CHECK(src && out && R > 0 && C > 0 && ld >= C, "colsum_f32: bad args");
+  const int slices = R >= 4096 ? 64 : (R >= 256 ? 8 : 1);
+  hipLaunchKernelGGL(colsum_f32_k, dim3((C + 63) / 64, slices), dim3(256), 0, (hipStream_t)stream, src, ld, out, R, C);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_attn_bwd_f32(const mart_attn_bwd_f32_desc* d, void* stream) {
+  MART_CHECK(d && d->f.q && d->f.k && d->f.v && d->dctx && d->dq && d->dk && d->dv, "attn_bwd_f32: null pointer");
+  MART_CHECK(d->f.B > 0 && d->f.nh > 0 && d->f.Sq > 0 && d->f.Sk > 0 && d->f.Lp >= 0, "attn_bwd_f32: bad shape");
+  MART_CHECK(d->f.ldq % 4 == 0 && d->f.ldk % 4 == 0 && d->f.ldv % 4 == 0 && (d->f.Lp == 0 || (d->f.pk && d->f.pv && d->dpk && d->dpv && d->f.ldp % 4 == 0)), "attn_bwd_f32: bad strides / prefix");
+  MART_CHECK((d->f.w0 == nullptr) == (d->f.w1 == nullptr) && (!d->f.sep || (d->f.w0 && d->f.Lp == 0)), "attn_bwd_f32: reweight needs w0/w1 and no prefix");
+  if (d->f.D == 64) return launch_attn_bwd<64>(d, (hipStream_t)stream);
+  if (d->f.D == 768) return launch_attn_bwd<768>(d, (hipStream_t)stream);
+  mart_set_error("attn_bwd_f32: head dim must be 64 or 768");
   return -1;
 }

@@ -187,6 +187,8 @@ class LazyRows:
             rows = rows[rsel].contiguous()
         o = self.owner
         if o.precise is not None:
+            if o.trans.requires_grad and hasattr(o.precise, "score_train"):
+                return o.precise.score_train(o.trans, rows, self._ids(csel), o.word_name, o.bias_name)
             return o.precise.score(o.trans, rows, self._ids(csel), o.word_name, o.bias_name)
         return _ScoreFn.apply(o.trans, o.trans_bf16, rows, self._ids(csel), o.store, o.word_name, o.bias_name)
 

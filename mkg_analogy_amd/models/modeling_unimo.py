@@ -190,6 +190,7 @@ class UnimoForMaskedLM(nn.Module):
         self.base_seed = 0x5EED
         self.precision = "bf16"                     # "fp32": fp32-accurate evaluation path (engine_precise), forward only
         self._precise = None
+        self._precise_train = None
         self.tie_weights()
 
     # ------------------------------------------------------------------ embedding surgery (modeling_unimo.py:895-930)
@@ -267,8 +268,9 @@ class UnimoForMaskedLM(nn.Module):
 
     def set_precision(self, precision: str):
         """"bf16" (default: bf16 MFMA operands, fp32 accumulation / residual streams; training + eval) or "fp32"
-        (evaluation only: fp32 activations, split-bf16 MFMA contractions, fp32 attention -- meets the reference's fp32
-        results to ~1e-4 on logits; see engine_precise.py)."""
+        (fp32 activations, split-bf16 MFMA contractions, fp32 attention -- meets the reference's fp32 results to ~1e-4 on
+        logits; evaluation under no_grad, and a verification-mode training step (eval-mode gradients, no dropout replay) when
+        gradients are enabled; see engine_precise.py)."""
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         self.precision = precision
@@ -309,8 +311,20 @@ class UnimoForMaskedLM(nn.Module):
             pixel_values = pixel_values.to(dev, torch.float32)
         train = bool(self.training)
         if self.precision == "fp32":
-            if train or labels is not None:
-                raise NotImplementedError("precision='fp32' is the evaluation path (forward only, no labels); call model.eval() or set_precision('bf16')")
+            if labels is not None:
+                raise NotImplementedError("precision='fp32': no full-vocabulary labels path; score slices of .logits instead")
+            if torch.is_grad_enabled():
+                # verification mode: fp32-accurate forward AND backward (engine_precise.PreciseUnimoTrain); eval-mode gradients only
+                if self._precise_train is None or self._precise_train.st is not st:
+                    from ..engine_precise import PreciseUnimoTrain
+                    self._precise_train = PreciseUnimoTrain(st, self.vision_config, self.config)
+                holder: Dict[str, torch.Tensor] = {}
+                trans = Fn._MKGformerFn.apply(self._anchor, self._precise_train, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx,
+                                              train, 0, holder, image_table, image_index)
+                out = MaskedLMOutput(loss=None, logits=Fn.LazyLogits(trans, None, st, precise=self._precise_train), hidden_states=None, attentions=None)
+                return (out, trans) if return_dict else ((out.logits,), trans)
+            if train:
+                raise NotImplementedError("precision='fp32' under no_grad is the evaluation path: call model.eval() (or set_precision('bf16'))")
             if self._precise is None or self._precise.st is not st:
                 from ..engine_precise import PreciseUnimoForward
                 self._precise = PreciseUnimoForward(st, self.vision_config, self.config)

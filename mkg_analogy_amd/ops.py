@@ -206,23 +206,24 @@ def attn_bwd(*, dctx, delta, dq, dk, dv, dpk=None, dpv=None, accum_dkv=False, dw
 
 
 # ---------------------------------------------------------------- fp32-accurate evaluation path (csrc/precise.hip)
-def split_bf16x3(src, role, out=None):
-    """f32 [rows, K] (row stride = ld) -> bf16 [rows, 3K]: role 0 = [hi|lo|hi] (A operand), role 1 = [hi|hi|lo] (B operand)."""
+def split_bf16x3(src, role, out=None, terms=2):
+    """f32 [rows, K] (row stride = ld) -> bf16 [rows, 3K]: role 0 = [hi|lo|hi] (A operand), role 1 = [hi|hi|lo] (B operand).
+    ``terms=3``: three-term splits for six products, [rows, 6K] (csrc/precise.hip)."""
     rows, K = src.shape
     if out is None:
-        out = torch.empty((rows, 3 * K), device=src.device, dtype=BF16)
-    L.check(L.lib().mart_split_bf16x3(_p(src), _rows2d(src), _p(out), rows, K, role, _stream()), "mart_split_bf16x3")
+        out = torch.empty((rows, (6 if terms == 3 else 3) * K), device=src.device, dtype=BF16)
+    L.check(L.lib().mart_split_bf16x3(_p(src), _rows2d(src), _p(out), rows, K, role, terms, _stream()), "mart_split_bf16x3")
     return out
 
 
-def split_bf16x3_rows(src, gather, role, out=None):
-    """Same split of the gathered rows ``src[gather]`` (gather int32 [R]) -> bf16 [R, 3K]."""
+def split_bf16x3_rows(src, gather, role, out=None, terms=2):
+    """Same split of the gathered rows ``src[gather]`` (gather int32 [R]) -> bf16 [R, 3K] (or [R, 6K])."""
     K = src.shape[1]
     R = gather.numel()
     assert gather.dtype == torch.int32 and gather.is_contiguous()
     if out is None:
-        out = torch.empty((R, 3 * K), device=src.device, dtype=BF16)
-    L.check(L.lib().mart_split_bf16x3_rows(_p(src), _rows2d(src), _p(gather), _p(out), R, K, role, _stream()), "mart_split_bf16x3_rows")
+        out = torch.empty((R, (6 if terms == 3 else 3) * K), device=src.device, dtype=BF16)
+    L.check(L.lib().mart_split_bf16x3_rows(_p(src), _rows2d(src), _p(gather), _p(out), R, K, role, terms, _stream()), "mart_split_bf16x3_rows")
     return out
 
 
@@ -243,6 +244,49 @@ def attn_fwd_f32(*, q, k, v, ctx, B, nh, D, Sq, Sk, scale, pk=None, pv=None, Lp=
     d.attn_mask, d.sep, d.sep_stride, d.w0, d.w1, d.rw_skip_row0 = _p(attn_mask), _p(sep), sep_stride, _p(w0), _p(w1), int(rw_skip_row0)
     d.ctx, d.ldctx = _p(ctx), _rows2d(ctx)
     L.check(L.lib().mart_attn_fwd_f32(C.byref(d), _stream()), "mart_attn_fwd_f32")
+
+
+def attn_bwd_f32(*, dctx, dq, dk, dv, dpk=None, dpv=None, dw=None, q, k, v, B, nh, D, Sq, Sk, scale, pk=None, pv=None, Lp=0, attn_mask=None,
+                 sep=None, sep_stride=0, w0=None, w1=None, rw_skip_row0=False):
+    """fp32 attention backward (verification mode): dq written; dk / dv / dpk / dpv / dw accumulated -- zero them first."""
+    d = L.AttnBwdF32()
+    f = d.f
+    f.q, f.k, f.v, f.ldq, f.ldk, f.ldv = _p(q), _p(k), _p(v), _rows2d(q), _rows2d(k), _rows2d(v)
+    f.pk, f.pv, f.ldp, f.Lp = _p(pk), _p(pv), (_rows2d(pk) if pk is not None else 0), Lp
+    f.B, f.nh, f.D, f.Sq, f.Sk, f.scale = B, nh, D, Sq, Sk, scale
+    f.attn_mask, f.sep, f.sep_stride, f.w0, f.w1, f.rw_skip_row0 = _p(attn_mask), _p(sep), sep_stride, _p(w0), _p(w1), int(rw_skip_row0)
+    f.ctx, f.ldctx = None, 0
+    d.dctx, d.lddctx = _p(dctx), _rows2d(dctx)
+    d.dq, d.dk, d.dv, d.lddq, d.lddk, d.lddv = _p(dq), _p(dk), _p(dv), _rows2d(dq), _rows2d(dk), _rows2d(dv)
+    d.dpk, d.dpv, d.lddp = _p(dpk), _p(dpv), (_rows2d(dpk) if dpk is not None else 0)
+    d.dw = _p(dw)
+    L.check(L.lib().mart_attn_bwd_f32(C.byref(d), _stream()), "mart_attn_bwd_f32")
+
+
+def split_bf16x3_stack(src, role, terms=2):
+    """f32 [M, K] -> bf16 [3M, K] row-stacked two-term split: role 0 = [hi;lo;hi] (X of X^T Y), role 1 = [hi;hi;lo] (Y); terms=3: [6M, K]."""
+    M, K = src.shape
+    out = torch.empty(((6 if terms == 3 else 3) * M, K), device=src.device, dtype=BF16)
+    L.check(L.lib().mart_split_bf16x3_stack(_p(src), _rows2d(src), _p(out), M, K, role, terms, _stream()), "mart_split_bf16x3_stack")
+    return out
+
+
+def act_f32(z, act):
+    a = torch.empty_like(z)
+    L.check(L.lib().mart_act_f32(_p(z), _p(a), act, z.numel(), _stream()), "mart_act_f32")
+    return a
+
+
+def act_bwd_f32(dy, z, act):
+    dz = torch.empty_like(z)
+    L.check(L.lib().mart_act_bwd_f32(_p(dy), _p(z), act, _p(dz), z.numel(), _stream()), "mart_act_bwd_f32")
+    return dz
+
+
+def colsum_f32(src, out):
+    """out[C] += column sums of the f32 matrix ``src`` [R, C] (row stride = ld)."""
+    R, Cc = src.shape
+    L.check(L.lib().mart_colsum_f32(_p(src), _rows2d(src), _p(out), R, Cc, _stream()), "mart_colsum_f32")
 
 
 def fusion_supported(Lq, Nv, H) -> bool:

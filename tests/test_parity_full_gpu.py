@@ -226,6 +226,64 @@ def test_finetune_step_vs_reference_at_bench_shape(tag):
         _grad_report(st, g, tol_rel=0.03, tol_cos=0.0, tol_norm=0.03, ctl_mult=4.0)
 
 
+@pytest.mark.parametrize("tag", ["g7_bench_plain", "g7_bench_cond", "g8_pretrain_plain"])
+def test_fp32_training_step_vs_reference(tag):
+    """The fp32-accurate training step (set_precision("fp32") with gradients enabled: engine_precise.PreciseUnimoTrain) against the
+    reference's own fp32 step (PL precision 32, lit_models/transformer.py:59-113) -- loss and ALL gradient tensors, including the PLAIN
+    N(0,0.02) weights where the bf16 path can only be compared with a control."""
+    g = _load(tag)
+    pre = bool(int(g["pretrain"]))
+    model, lit, cfg = _product(g, pretrain=pre)
+    batch = _batch(g, pretrain=pre)
+    gb = {k: v.cuda() for k, v in batch.items()}
+    model.eval()
+    model.set_precision("fp32")
+    st = model.store
+    st.zero_grad()
+    loss = lit.training_step(dict(gb), 1)
+    loss.backward()
+    torch.cuda.synchronize()
+    model.set_precision("bf16")
+    dl = abs(float(loss) - float(g["loss"]))
+    norms = dict(zip(g["grad_norm_names"].tolist(), g["grad_norm_vals"].tolist()))
+    worst, worst_n, n_cmp = 0.0, "", 0
+    aw_ref, aw_got = [], []
+    for n, ref in norms.items():
+        if n.endswith("decoder.weight"):
+            continue
+        got = float(st.g(n).double().norm())
+        if ref < 1e-7:
+            assert got < 1e-5, (n, got, ref)
+            continue
+        if "adaptive_weight" in n:          # scalars: sums of signed score x d(score) terms with heavy cancellation -> compared as ONE vector
+            aw_ref.append(ref); aw_got.append(got)
+            continue
+        r = abs(got - ref) / ref
+        n_cmp += 1
+        if r > worst:
+            worst, worst_n = r, n
+    r_aw = _rel(aw_got, aw_ref) if aw_ref else 0.0
+    rels = []
+    for k in g:
+        if k.startswith("gs::") and np.linalg.norm(g[k]) >= 1e-7 and "adaptive_weight" not in k:
+            rels.append((_rel(_sample(st.g(k[4:])), g[k]), k[4:]))
+    rels.sort(reverse=True)
+    print(f"\n{tag} fp32 training step: loss hip {float(loss):.7f} reference {float(g['loss']):.7f} (|d| {dl:.2e}); worst gradient-norm deviation "
+          f"{worst:.3e} ({worst_n}) over {n_cmp} tensors; adaptive-weight gradients as a vector ({len(aw_ref)}) rel-L2 {r_aw:.3e}; "
+          f"worst sample rel-L2 {rels[0][0]:.3e} ({rels[0][1]}), median {rels[len(rels) // 2][0]:.3e}")
+    for n in g["none_grad"].tolist():
+        if n in st.slots and not n.endswith("decoder.weight"):
+            assert float(st.g(n).abs().max()) == 0.0, n
+    assert dl < 1e-4
+    if tag == "g7_bench_plain":
+        # the fine-tune network at plain weights is chaotic in the unscaled fusion softmax: the CPU oracle (the same math in another
+        # summation order) is itself only within 2e-3 of these gradient norms (tests/test_oracle_vs_golden.py); the bf16 path's median
+        # sample displacement on this golden is 0.55 and the reference's own bf16-weight control 1.9
+        assert worst < 5e-3 and rels[0][0] < 5e-3 and r_aw < 1e-2, (worst, worst_n, rels[:3], r_aw)
+    else:
+        assert worst < 1e-3 and rels[0][0] < 1e-3 and r_aw < 1e-3, (worst, worst_n, rels[:3], r_aw)
+
+
 @pytest.mark.parametrize("tag", ["g7_bench_cond", "g7_bench_plain"])
 def test_text_split_mode_vs_reference(tag):
     """engine.text_split (MART_TEXT_SPLIT=1): the text stream's forward products on two-term operand splits.  Conditioned weights:
