@@ -94,6 +94,52 @@ __device__ __forceinline__ void stage_tile(const Side& s, int b, int h, int r0, 
     }
   }
 }
+// ---- strength-reduced staging for the vision kernels (round 3).  The general stage_tile above compiles to ~20 VALU + ~25 SALU + 6 branches
+// per 1-KB copy (per-lane clamp, prefix / own select and a 64-bit multiply, if-converted into vector code): four copies per tile were a third
+// of the forward kernel's VALU and most of its SALU instructions (16.5 VALU + 7.3 SALU per MFMA, profiles/r03_pmc_attn_fwd.txt).  Here the
+// source of a 32-row half is a WAVE-UNIFORM pointer (scalar unit: prefix or own block, rows j0 ..) plus ONE loop-invariant 32-bit lane offset,
+// issued in the saddr form; only a half that is cut by the last key takes the per-lane clamp.  Needs the prefix length to be a multiple of 32.
+struct Stager {
+  const bf16* own_b; const bf16* pre_b;   // first row of this (batch, head) in the own / prefix block
+  unsigned voff_own, voff_pre;            // byte offset of this lane's chunk inside a 32-row half
+  int ld_own, ld_pre, n_own, n_pre;
+};
+__device__ __forceinline__ Stager make_stager(const Side& s, int b, int h, int tid) {
+  const int rowh = tid >> 3, pc = tid & 7, lc = pc ^ swz_key(rowh);
+  Stager g;
+  g.own_b = s.own + ((long long)b * s.n_own) * s.ld_own + h * 64;
+  g.pre_b = s.n_pre ? s.pre + ((long long)b * s.n_pre) * s.ld_pre + h * 64 : s.own;
+  g.voff_own = (unsigned)(rowh * s.ld_own + lc * 8) * 2u;
+  g.voff_pre = (unsigned)(rowh * s.ld_pre + lc * 8) * 2u;
+  g.ld_own = s.ld_own; g.ld_pre = s.ld_pre; g.n_own = s.n_own; g.n_pre = s.n_pre;
+  return g;
+}
+__device__ __forceinline__ void dma_saddr(const bf16* sbase, unsigned voff, void* lds_wave_base) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)LDS_PTR(lds_wave_base));
+  const unsigned long long a = (unsigned long long)(__UINTPTR_TYPE__)sbase;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sb) : "memory", "m0");
+}
+__device__ __forceinline__ void stage_tile_fast(const Stager& g, int r0, char* lds, int tid, int wave) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int j0 = r0 + r * 32;                                                       // first row of this half (wave-uniform)
+    char* dst = lds + (r * NTH + wave * 64) * 16;
+    if (j0 < g.n_pre) {
+      dma_saddr(g.pre_b + (long long)j0 * g.ld_pre, g.voff_pre, dst);
+    } else {
+      const int jj = j0 - g.n_pre;
+      if (jj + 32 <= g.n_own) {
+        dma_saddr(g.own_b + (long long)jj * g.ld_own, g.voff_own, dst);
+      } else {                                                                        // half cut by (or past) the last key: clamped rows
+        const int rowh = tid >> 3, pc = tid & 7, lc = pc ^ swz_key(rowh);
+        const int row = min(jj + rowh, g.n_own - 1);
+        dma_saddr(g.own_b, (unsigned)(row * g.ld_own + lc * 8) * 2u, dst);
+      }
+    }
+  }
+}
 // Per-lane byte offsets of the fragment reads inside a 64x64 tile -- loop invariant, computed once per kernel so the
 // tile loops carry no address arithmetic (the first version spent 36 VALU instructions per MFMA, mostly on this).
 struct LaneOffs {
@@ -160,8 +206,15 @@ __device__ __forceinline__ float reweight(const TextCtl& c, int qi, int kj) {
 // TPW = query tiles (32 rows) per wave.  With TPW = 2 a wave carries two independent softmax / accumulator chains, so the
 // exp-heavy VALU work of one tile overlaps the MFMAs of the other inside the wave, a workgroup covers 256 query rows, and
 // the K/V stream of a head is read by half as many workgroups.
+// Vision forward, round 3: ONE query tile per wave compiled for FOUR waves per SIMD (128 VGPRs, no spills) beats two tiles per wave at two
+// waves per SIMD (256 VGPRs, 6 spills) by 6-7 % (0.263 vs 0.283 ms at 393 keys, tools/ab_attn2.sh): twice the K/V streams, but four
+// independent dependence chains per SIMD instead of two hide more of the MFMA -> exp -> cvt -> MFMA latency.  (One tile per wave at 168 VGPRs
+// = three waves per SIMD: 0.275-0.279.)  The text instantiation (mask, reweight, dropout state) would spill at 128 and stays at two.
+#ifndef ATTN_FWD_MINW1
+#define ATTN_FWD_MINW1 4
+#endif
 template <bool TEXT, int TPW>
-__global__ __launch_bounds__(NTH, 2) void attn_fwd_k(mart_attn_fwd_desc p) {
+__global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void attn_fwd_k(mart_attn_fwd_desc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -194,15 +247,20 @@ __global__ __launch_bounds__(NTH, 2) void attn_fwd_k(mart_attn_fwd_desc p) {
   const float c2 = p.scale * LOG2E;
 
   const int ntiles = (Stot + 63) / 64;
-  stage_tile(K, b, h, 0, smem, tid, wave);
-  stage_tile(V, b, h, 0, smem + TILE_BYTES, tid, wave);
+  const Stager gK = make_stager(K, b, h, tid), gV = make_stager(V, b, h, tid);
+  auto stage_kv = [&](int r0, char* buf) {
+    if constexpr (!TEXT) {                              // vision: uniform-pointer staging (the host routes prefix lengths that are not multiples of 32 to the general instantiation)
+      stage_tile_fast(gK, r0, buf, tid, wave);
+      stage_tile_fast(gV, r0, buf + TILE_BYTES, tid, wave);
+    } else {
+      stage_tile(K, b, h, r0, buf, tid, wave);
+      stage_tile(V, b, h, r0, buf + TILE_BYTES, tid, wave);
+    }
+  };
+  stage_kv(0, smem);
   for (int kt = 0; kt < ntiles; ++kt) {
     tile_barrier();
-    if (kt + 1 < ntiles) {
-      char* nb = smem + ((kt + 1) & 1) * STAGE_BYTES;
-      stage_tile(K, b, h, (kt + 1) * 64, nb, tid, wave);
-      stage_tile(V, b, h, (kt + 1) * 64, nb + TILE_BYTES, tid, wave);
-    }
+    if (kt + 1 < ntiles) stage_kv((kt + 1) * 64, smem + ((kt + 1) & 1) * STAGE_BYTES);
     const char* sK = smem + (kt & 1) * STAGE_BYTES;
     const char* sV = sK + TILE_BYTES;
     if (!active[0]) continue;                         // wave past the last query row: only stages tiles and keeps the barriers
@@ -706,6 +764,9 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
 //     (db, qb) computes the 16(d) x 16(q) sub-block of dQ^T = K^T dS^T over ALL keys with v_mfma_f32_16x16x32_bf16, both
 //     operands by transposed LDS reads: no cross-wave reduction, no atomics, results independent of scheduling.
 //     The dQ of tile t-1 is computed at the start of iteration t (dS image double-buffered): one barrier per tile.
+#ifndef FUSED_STRAIGHT
+#define FUSED_STRAIGHT 0                      // 1: no early-out for key blocks past the end (both blocks of a wave in one basic block)
+#endif
 constexpr int FQ = 32;                        // query rows per tile
 constexpr int F_KIMG = 512 * 128;             // K image
 constexpr int F_QT = FQ * 128;                // one 32-row tile
@@ -847,7 +908,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
     char* sD = smem + F_OFF_DS + (t & 1) * F_DS;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+#if !FUSED_STRAIGHT
       if (nval[kb] == 0) continue;                   // wave-uniform: key block past the end
+#endif
       const int key = wave * 64 + kb * 32 + l31;
       const char* krow = sK + key * 128;
       const int kkey = swz_key(key);
@@ -985,8 +1048,8 @@ int set_attrs() {
 extern "C" int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream) {
   if (int rc = check_fwd(d)) return rc;
   if (int rc = set_attrs()) return rc;
-  const bool text = d->attn_mask || d->sep || d->p_drop > 0.f;
-  static const int tpw = getenv("MART_ATTN_TPW") ? atoi(getenv("MART_ATTN_TPW")) : 2;
+  const bool text = d->attn_mask || d->sep || d->p_drop > 0.f || (d->Lp & 31) != 0;   // general instantiation: every option, any prefix length
+  static const int tpw = getenv("MART_ATTN_TPW") ? atoi(getenv("MART_ATTN_TPW")) : 1;
   if (text) hipLaunchKernelGGL((attn_fwd_k<true, 1>), dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
   else if (tpw == 2 && d->Sq > 128) hipLaunchKernelGGL((attn_fwd_k<false, 2>), dim3((d->Sq + 255) / 256, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL((attn_fwd_k<false, 1>), dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
