@@ -52,6 +52,9 @@ def _product(g, pretrain=False):
     assert not unexpected and all(("position_ids" in m or "decoder" in m) for m in missing), (missing, unexpected)
     model.cuda()
     lit._init_relation_word()
+    # these tests measure the TRAINING configuration of the text stream (plain bf16) in their eval-mode forward passes too; the split-precision
+    # text stream that evaluation passes use by default (engine.text_split_eval) is switched on explicitly where it is the subject
+    model.engine.text_split_eval = False
     return model, lit, cfg
 
 
@@ -282,6 +285,41 @@ def test_fp32_training_step_vs_reference(tag):
         assert worst < 5e-3 and rels[0][0] < 5e-3 and r_aw < 1e-2, (worst, worst_n, rels[:3], r_aw)
     else:
         assert worst < 1e-3 and rels[0][0] < 1e-3 and r_aw < 1e-3, (worst, worst_n, rels[:3], r_aw)
+
+
+def test_evaluation_default_is_the_split_precision_text_stream():
+    """Evaluation passes (eval mode under no_grad: validation / test ranking) run the text stream on operand splits by default
+    (engine.text_split_eval): identical to text_split=True, closer to the reference than the training-path forward; a forward that
+    saves activations for a backward pass (the training step) stays on the plain bf16 text stream."""
+    g = _load("g7_bench_cond")
+    model, lit, cfg = _product(g)
+    eng = model.engine
+    batch = _batch(g)
+    B = int(g["B"])
+    gb = {k: v.cuda() for k, v in batch.items()}
+    ids = torch.tensor(cfg["analogy_entity_ids"], device="cuda")
+    ar = torch.arange(B, device="cuda")
+    rows = torch.from_numpy(g["trans_row_index"]).cuda()
+    ref = torch.from_numpy(g["mask_logits"])
+    model.eval()
+    keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
+
+    def logits(grad):
+        with torch.enable_grad() if grad else torch.no_grad():
+            out, _ = model(**{k: gb[k] for k in keys}, return_dict=True)
+            return out.logits[ar, rows[:, 0]][:, ids].detach().float().cpu()
+
+    plain = logits(False)                                 # _product switched the evaluation default off
+    eng.text_split_eval = True
+    ev, tr = logits(False), logits(True)
+    eng.text_split, eng.text_split_eval = True, False
+    sp = logits(False)
+    eng.text_split = False
+    assert torch.equal(ev, sp), "evaluation default == text_split"
+    assert torch.equal(tr, plain), "a forward with saved activations keeps the training configuration"
+    e_ev, e_pl = float((ev - ref).abs().max()), float((plain - ref).abs().max())
+    print(f"\nevaluation default: max|dlogit| {e_ev:.3e} (plain bf16 text stream {e_pl:.3e})")
+    assert e_ev < 1e-2 and e_ev < e_pl
 
 
 @pytest.mark.parametrize("tag", ["g7_bench_cond", "g7_bench_plain"])
