@@ -247,16 +247,19 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
   const float c2 = p.scale * LOG2E;
 
   const int ntiles = (Stot + 63) / 64;
-  const Stager gK = make_stager(K, b, h, tid), gV = make_stager(V, b, h, tid);
-  auto stage_kv = [&](int r0, char* buf) {
-    if constexpr (!TEXT) {                              // vision: uniform-pointer staging (the host routes prefix lengths that are not multiples of 32 to the general instantiation)
-      stage_tile_fast(gK, r0, buf, tid, wave);
-      stage_tile_fast(gV, r0, buf + TILE_BYTES, tid, wave);
-    } else {
-      stage_tile(K, b, h, r0, buf, tid, wave);
-      stage_tile(V, b, h, r0, buf + TILE_BYTES, tid, wave);
-    }
-  };
+  Stager gK, gV;
+  if constexpr (!TEXT) { gK = make_stager(K, b, h, tid); gV = make_stager(V, b, h, tid); }
+  // vision: uniform-pointer staging (the host routes prefix lengths that are not multiples of 32 to the general instantiation)
+#define stage_kv(r0_, buf_)                                                                           \
+  do {                                                                                                 \
+    if constexpr (!TEXT) {                                                                             \
+      stage_tile_fast(gK, (r0_), (buf_), tid, wave);                                                   \
+      stage_tile_fast(gV, (r0_), (buf_) + TILE_BYTES, tid, wave);                                      \
+    } else {                                                                                           \
+      stage_tile(K, b, h, (r0_), (buf_), tid, wave);                                                   \
+      stage_tile(V, b, h, (r0_), (buf_) + TILE_BYTES, tid, wave);                                      \
+    }                                                                                                  \
+  } while (0)
   stage_kv(0, smem);
   for (int kt = 0; kt < ntiles; ++kt) {
     tile_barrier();
@@ -415,6 +418,8 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
     }
   }
 }
+
+#undef stage_kv
 
 // =========================================================================== backward, dQ pass (owner = queries)
 // TPW query tiles per wave as in the forward kernel (two independent exp / dS chains per wave, half the K/V streams).

@@ -130,9 +130,10 @@ class TransformerLitModel(BaseLitModel):
     def _eval_at(self, batch, batch_idx):
         """``args.eval_precision = "fp32"`` scores validation / test batches on the fp32-accurate path (engine_precise)."""
         prec = getattr(self.args, "eval_precision", None)
-        if not prec or prec == self.model.precision:
+        cur = getattr(self.model, "precision", "bf16")
+        if not prec or prec == cur:
             return self._eval(batch, batch_idx)
-        old = self.model.precision
+        old = cur
         self.model.set_precision(prec)
         try:
             return self._eval(batch, batch_idx)

@@ -221,6 +221,8 @@ class FlavaForMaskedLM(nn.Module):
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._step = 0
         self.base_seed = 0x5EED          # dropout stream; distributed.GradSync hashes the rank into it
+        if not hasattr(self, "precision"):
+            self.precision = "bf16"
         return self._store
 
     @property
