@@ -363,9 +363,9 @@ def main():
         def time_eval(prec, split, n=3):
             lit.args.eval_precision = prec
             eng_ = getattr(model, "engine", None)
-            old_split = getattr(eng_, "text_split", False)
-            if eng_ is not None and hasattr(eng_, "text_split"):
-                eng_.text_split = split
+            old_split = getattr(eng_, "text_split_eval", False)
+            if eng_ is not None and hasattr(eng_, "text_split_eval"):
+                eng_.text_split_eval = split          # the switch evaluation passes obey (engine.text_split_eval; default on)
             try:
                 m = tr.validate(lit, [batch])
                 barrier()
@@ -376,17 +376,18 @@ def main():
                 return {"examples_per_s": round(a.batch * n / (time.perf_counter() - t1), 1), "hits1": m.get("Eval_entity/hits1"),
                         "mean_rank": m.get("Eval_entity/mean_rank")}
             finally:
-                if eng_ is not None and hasattr(eng_, "text_split"):
-                    eng_.text_split = old_split
+                if eng_ is not None and hasattr(eng_, "text_split_eval"):
+                    eng_.text_split_eval = old_split
                 lit.args.eval_precision = None
-        default_prec = getattr(lit.args, "eval_precision", None) or "bf16"
-        evalb = {"what": "validation pass over the timed batch: forward, scoring head, device-side rank of the label", "default_eval_precision": default_prec,
-                 "bf16": time_eval("bf16", False)}
+        split_default = bool(getattr(getattr(model, "engine", None), "text_split_eval", False)) and a.model == "mkgformer"
+        default_mode = "bf16_text_split" if split_default else "bf16"
+        evalb = {"what": "validation pass over the timed batch: forward, scoring head, device-side rank of the label",
+                 "bf16": time_eval("bf16", False)}                      # the training configuration of the text stream
         if a.model == "mkgformer":
-            evalb["bf16_text_split"] = time_eval("bf16", True)
-        evalb["fp32"] = time_eval("fp32", False)
-        evalb["eval_examples_per_s"] = evalb[default_prec if default_prec in evalb else "bf16"]["examples_per_s"]
-        evalb["eval_precision"] = default_prec
+            evalb["bf16_text_split"] = time_eval("bf16", True)        # evaluation default: split-precision text stream (engine.text_split_eval)
+        evalb["fp32"] = time_eval("fp32", split_default)
+        evalb["eval_examples_per_s"] = evalb[default_mode]["examples_per_s"]
+        evalb["eval_precision"] = default_mode
     parity = None
     if world == 1 and a.model == "mkgformer" and not pre and not a.no_kernel_timing and not a.train_only:
         # the bf16 training path against the fp32-accurate evaluation path (engine_precise: held to the reference at 1e-3 on logits
@@ -395,7 +396,8 @@ def main():
         ids = torch.tensor(cfg["analogy_entity_ids"], device=dev)
         keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
         lg = {}
-        split0 = model.engine.text_split
+        split0, spliteval0 = model.engine.text_split, model.engine.text_split_eval
+        model.engine.text_split_eval = False                    # the modes are selected explicitly below
         with torch.no_grad():
             for prec in ("bf16", "bf16_text_split", "fp32"):
                 model.set_precision("fp32" if prec == "fp32" else "bf16")
@@ -403,7 +405,7 @@ def main():
                 o, _ = model(**{k: batch[k] for k in keys}, return_dict=True)
                 lg[prec] = o.logits.mask_rows(batch["input_ids"], D.MASK)[:, ids].float()
             model.set_precision("bf16")
-            model.engine.text_split = split0
+            model.engine.text_split, model.engine.text_split_eval = split0, spliteval0
         lab = batch["label"]
         rk = {k: ((v > v.gather(1, lab[:, None])).sum(1) + 1) for k, v in lg.items()}
 

@@ -185,6 +185,7 @@ struct TextCtl {                          // per-(b) text controls, all optional
   int skip0;                              // FLAVA: query row 0 keeps factor 1
   float c0, c1;
   float p_drop, inv_keep; uint64_t seed;
+  uint32_t s2, thr;                       // dropout: folded seed and 16-bit threshold (common.h: dropout_keep32)
 };
 __device__ __forceinline__ TextCtl make_ctl(const mart_attn_fwd_desc& p, int b, int Sk) {
   TextCtl c;
@@ -194,6 +195,7 @@ __device__ __forceinline__ TextCtl make_ctl(const mart_attn_fwd_desc& p, int b, 
   c.c0 = p.w0 ? fminf(fmaxf(p.w0[0], 0.f), 0.5f) : 1.f;
   c.c1 = p.w1 ? fminf(fmaxf(p.w1[0], 0.5f), 1.f) : 1.f;
   c.p_drop = p.p_drop; c.inv_keep = 1.f / (1.f - p.p_drop); c.seed = p.seed;
+  c.s2 = rng_seedmix(p.seed, 0); c.thr = dropout_thr16(p.p_drop);
   return c;
 }
 __device__ __forceinline__ float reweight(const TextCtl& c, int qi, int kj) {
@@ -362,19 +364,28 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run[u], mx);
         alpha[u] = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+        // dropout on the probabilities: index = ((b nh + h) Sq + q) Stot + key (< 2^32, host-checked); registers r, r + 1 (r even) are
+        // adjacent keys, so with an even Stot they share one hash (common.h)
+        const uint32_t rowbase = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq + (uint32_t)qi[u]) * (uint32_t)Stot;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float e = __builtin_amdgcn_exp2f(pv[u][t][r] - m_new);
-            rs += e;
-            float used = e;
+          for (int r = 0; r < 16; r += 2) {
+            const float e0 = __builtin_amdgcn_exp2f(pv[u][t][r] - m_new), e1 = __builtin_amdgcn_exp2f(pv[u][t][r + 1] - m_new);
+            rs += e0 + e1;
+            float u0 = e0, u1 = e1;
             if (TEXT && ctl.p_drop > 0.f) {
-              const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
-              const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi[u]) * (uint64_t)Stot + (uint64_t)kj;
-              used = dropout_keep(ctl.seed, idx, ctl.p_drop) ? e * ctl.inv_keep : 0.f;
+              const uint32_t idx = rowbase + (uint32_t)(kt * 64 + t * 32 + mfma_row(r, hh));
+              bool k0, k1;
+              if ((Stot & 1) == 0) {                       // wave-uniform: idx is even, idx + 1 its pair partner
+                const uint32_t hsh = rng_pair(ctl.s2, idx >> 1);
+                k0 = (hsh & 0xffffU) >= ctl.thr; k1 = (hsh >> 16) >= ctl.thr;
+              } else {
+                k0 = dropout_keep32(ctl.s2, idx, ctl.thr); k1 = dropout_keep32(ctl.s2, idx + 1, ctl.thr);
+              }
+              u0 = k0 ? e0 * ctl.inv_keep : 0.f; u1 = k1 ? e1 * ctl.inv_keep : 0.f;
             }
-            pv[u][t][r] = used;
+            pv[u][t][r] = u0; pv[u][t][r + 1] = u1;
           }
         m_run[u] = m_new;
       }
@@ -533,8 +544,8 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
             float pr = (kj < Stot && qvalid[u]) ? __builtin_amdgcn_exp2f(sc * LOG2E - lse[u]) : 0.f;
             float dpd = dp[r];
             if (TEXT && ctl.p_drop > 0.f) {
-              const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi[u]) * (uint64_t)Stot + (uint64_t)kj;
-              dpd = dropout_keep(ctl.seed, idx, ctl.p_drop) ? dpd * ctl.inv_keep : 0.f;
+              const uint32_t idx = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq + (uint32_t)qi[u]) * (uint32_t)Stot + (uint32_t)kj;
+              dpd = dropout_keep32(ctl.s2, idx, ctl.thr) ? dpd * ctl.inv_keep : 0.f;
             }
             const float ds = pr * (dpd - delta[u]);        // d/d(post-reweight, pre-mask score)
             if (TEXT && ctl.sep >= 0 && kj >= ctl.sep) { if (qi[u] >= ctl.sep) dc1 += ds * spre; else if (!(ctl.skip0 && qi[u] == 0)) dc0 += ds * spre; }
@@ -716,8 +727,8 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
             const float pr = (kvalid && qi < p.Sq) ? __builtin_amdgcn_exp2f(sc * LOG2E - sLse[ql]) : 0.f;
             float keep = 1.f;
             if (TEXT && ctl.p_drop > 0.f) {
-              const uint64_t idx = (((uint64_t)b * p.nh + h) * p.Sq + (uint64_t)qi) * (uint64_t)Stot + (uint64_t)kj;
-              keep = dropout_keep(ctl.seed, idx, ctl.p_drop) ? ctl.inv_keep : 0.f;
+              const uint32_t idx = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq + (uint32_t)qi) * (uint32_t)Stot + (uint32_t)kj;
+              keep = dropout_keep32(ctl.s2, idx, ctl.thr) ? ctl.inv_keep : 0.f;
             }
             pd8[i] = pr * keep;
             ds8[i] = pr * (dp[r] * keep - sDel[ql]) * f;
@@ -1029,6 +1040,7 @@ int check_fwd(const mart_attn_fwd_desc* d) {
   MART_CHECK(!d->sep || (d->w0 && d->Lp == 0), "attn: reweight needs w0/w1 and no prefix");
   MART_CHECK(!d->attn_mask || d->Lp == 0, "attn: mask with prefix unsupported");
   MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "attn: bad dropout p");
+  MART_CHECK(d->p_drop == 0.f || (long long)d->B * d->nh * d->Sq * (d->Lp + d->Sk) < (1LL << 32), "attn: dropout indices are 32-bit (B nh Sq Sk < 2^32)");
   return 0;
 }
 MartAttrOnce g_attr_once;

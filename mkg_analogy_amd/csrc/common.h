@@ -186,15 +186,22 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ float rng_uniform(uint64_t seed, uint64_t idx) {
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-  uint32_t h = mix32(lo ^ (uint32_t)seed);
-  h = mix32(h + hi * 0x9e3779b9U + (uint32_t)(seed >> 32));
-  h = mix32(h ^ 0x85ebca6bU);
-  return (float)(h >> 8) * (1.0f / 16777216.0f);
+// Round 3: ONE hash per PAIR of element indices, 16 bits each (the three-round 64-bit form cost ~35 VALU instructions per element and made
+// the 64 x 64 text attention kernels -- 64 dropout decisions per lane -- VALU-bound on the hash): element idx takes the low half of
+// mix32((idx >> 1) ^ s2) when idx is even and the high half when odd; s2 folds the 64-bit seed and the upper index bits.  keep <=> u16 >= thr,
+// thr = round(p * 65536) (p = 0.1 -> 0.100006).
+__device__ __forceinline__ uint32_t rng_seedmix(uint64_t seed, uint32_t hi) { return mix32((uint32_t)(seed >> 32) + hi * 0x9e3779b9U) ^ (uint32_t)seed; }
+__device__ __forceinline__ uint32_t dropout_thr16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+__device__ __forceinline__ uint32_t rng_pair(uint32_t s2, uint32_t pair) { return mix32(pair ^ s2); }
+// 32-bit index form (the caller guarantees idx < 2^32 and passes s2 = rng_seedmix(seed, 0), thr = dropout_thr16(p)): identical decisions
+__device__ __forceinline__ bool dropout_keep32(uint32_t s2, uint32_t idx, uint32_t thr) {
+  const uint32_t h = rng_pair(s2, idx >> 1);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xffffU)) >= thr;
 }
 __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, float p) {
-  return rng_uniform(seed, idx) >= p;
+  const uint64_t pair = idx >> 1;
+  const uint32_t h = rng_pair(rng_seedmix(seed, (uint32_t)(pair >> 32)), (uint32_t)pair);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xffffU)) >= dropout_thr16(p);
 }
 
 // ---- XCD-aware, bijective remap of a linear workgroup id (8 XCDs; block b runs on XCD b%8):
