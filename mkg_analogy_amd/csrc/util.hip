@@ -9,7 +9,7 @@ extern "C" void mart_set_error(const char* msg) {
   g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* mart_last_error(void) { return g_err; }
-extern "C" int mart_abi_version(void) { return 1; }
+extern "C" int mart_abi_version(void) { return 3; }   // round 3: mart_ln_fwd_desc.y_f32, mart_split_bf16x3*(terms), fp32 backward entry points
 extern "C" int mart_check_device(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { mart_set_error("no HIP device"); return -2; }
