@@ -322,6 +322,39 @@ def test_evaluation_default_is_the_split_precision_text_stream():
     assert e_ev < 1e-2 and e_ev < e_pl
 
 
+def test_text_split_training_step_with_dropout_matches_the_plain_step():
+    """Train mode (dropout on): the split-precision text stream draws the SAME dropout masks as the plain bf16 text stream (the f32 branch of
+    mart_ln_fwd hashes the same element indices), so with equal seeds the two steps agree to bf16 rounding: loss within 2e-2, gradients
+    of the sampled tensors within 10 %, everything finite."""
+    g = _load("g7_bench_cond")
+    model, lit, cfg = _product(g)
+    batch = _batch(g)
+    gb = {k: v[:8].cuda() for k, v in batch.items()}
+    st = model.store
+    model.train()
+    res = []
+    for split in (False, True):
+        model.engine.text_split = split
+        model._step = 100                                  # same dropout stream for both passes
+        st.zero_grad()
+        loss = lit.training_step(dict(gb), 1)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(st.grad).all()) and bool(torch.isfinite(loss.detach()))
+        res.append((float(loss.detach()), st.grad.clone()))
+    model.engine.text_split = False
+    (l0, g0), (l1, g1) = res
+    names = ["unimo.encoder.text_layer.0.attention.self.query.weight", "unimo.encoder.text_layer.11.output.dense.weight",
+             "unimo.encoder.vision_layers.5.mlp.fc1.weight", "cls.predictions.transform.dense.weight", "unimo.text_embeddings.word_embeddings.weight"]
+    worst = 0.0
+    for n in names:
+        sl = st.slots[n]
+        a, b = g0[sl.offset:sl.offset + sl.numel], g1[sl.offset:sl.offset + sl.numel]
+        worst = max(worst, float((a - b).norm() / a.norm()))
+    print(f"\ntrain-mode step, dropout on: loss plain {l0:.5f} split-precision text {l1:.5f}; worst gradient rel-L2 difference {worst:.3e}")
+    assert abs(l0 - l1) < 2e-2 and worst < 0.10
+
+
 @pytest.mark.parametrize("tag", ["g7_bench_cond", "g7_bench_plain"])
 def test_text_split_mode_vs_reference(tag):
     """engine.text_split (MART_TEXT_SPLIT=1): the text stream's forward products on two-term operand splits.  Conditioned weights:
