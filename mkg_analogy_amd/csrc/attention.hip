@@ -204,6 +204,20 @@ __device__ __forceinline__ float reweight(const TextCtl& c, int qi, int kj) {
   return (c.skip0 && qi == 0) ? 1.f : c.c0;
 }
 
+// Key-padding mask of one 64-key tile as a wave-uniform bit set (bit j = key kt*64 + j is attended; keys past the end: 1, they are handled by
+// the caller).  Lane j loads mask[kt*64 + j] once (one coalesced 512-byte request); `mask_row[kj]` per score -- 32 loads per lane whose address
+// depends on the lane only through one bit -- had been scalarised by the compiler into waterfall loops of scalar loads (86 v_readlane + 160
+// scalar multiplies in the text forward kernel) and made the 64 x 64 text attention kernels latency-bound on them.  The mask holds 0 / 1
+// (extended mask (1 - m) * -10000, modeling_unimo.py:55-56): any non-zero value counts as 1.
+__device__ __forceinline__ uint64_t mask_bits(const TextCtl& c, int kt, int Stot, int lane) {
+  if (!c.mask_row) return ~0ull;
+  const int kl = kt * 64 + lane;
+  const long long mv = kl < Stot ? c.mask_row[kl] : 1;
+  return __ballot(mv != 0);
+}
+// additive mask term of key (t*32 + row-in-block) for this lane: hsel = the lane's half select (mfma_row adds 4 * hh)
+__device__ __forceinline__ float mask_add(uint64_t mb_lane, int c) { return ((mb_lane >> c) & 1ull) ? 0.f : -10000.0f; }
+
 // =========================================================================== forward
 // TPW = query tiles (32 rows) per wave.  With TPW = 2 a wave carries two independent softmax / accumulator chains, so the
 // exp-heavy VALU work of one tile overlaps the MFMAs of the other inside the wave, a workgroup covers 256 query rows, and
@@ -346,6 +360,7 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
         m_run[u] = m_new;
       } else {
         float mx = -1.0e30f;
+        const uint64_t mb = mask_bits(ctl, kt, Stot, lane) >> (4 * hh);   // this lane's keys: bit (t*32 + (r&3) + 8*(r>>2))
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
             float s = st[u][t][r] * p.scale;
             if (text) {
               s *= reweight(ctl, qi[u], kj);
-              if (ctl.mask_row && kj < Stot) s += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+              s += mask_add(mb, t * 32 + (r & 3) + 8 * (r >> 2));
             }
             s *= LOG2E;
             if (kj >= Stot) s = -1.0e30f;
@@ -531,6 +546,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
             dsv[r] = ds[0]; dsv[r + 1] = ds[1];
           }
         } else {
+          const uint64_t mb = mask_bits(ctl, kt, Stot, lane) >> (4 * hh);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
@@ -539,7 +555,7 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
             if (text) {
               f = reweight(ctl, qi[u], kj);
               sc *= f;
-              if (ctl.mask_row && kj < Stot) sc += (1.0f - (float)ctl.mask_row[kj]) * -10000.0f;
+              sc += mask_add(mb, t * 32 + (r & 3) + 8 * (r >> 2));
             }
             float pr = (kj < Stot && qvalid[u]) ? __builtin_amdgcn_exp2f(sc * LOG2E - lse[u]) : 0.f;
             float dpd = dp[r];
