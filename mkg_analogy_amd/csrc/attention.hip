@@ -204,6 +204,18 @@ __device__ __forceinline__ float reweight(const TextCtl& c, int qi, int kj) {
   return (c.skip0 && qi == 0) ? 1.f : c.c0;
 }
 
+// Query-owner kernels (forward, dQ): everything about the adaptive reweight that depends on the QUERY is lane-constant -- the factor this
+// query applies to keys >= sep and the two selectors of the d(w0) / d(w1) sums -- so a score costs one compare + select instead of the
+// branches of reweight() (the per-score divergent `if`s compiled to ~80 s_and_saveexec in the text dQ kernel).
+struct QueryRw { float fq, sel0, sel1; int sep; };
+__device__ __forceinline__ QueryRw make_qrw(const TextCtl& c, int qi) {
+  QueryRw q;
+  q.sep = c.sep < 0 ? 0x7fffffff : c.sep;                    // no reweight: no key is >= sep
+  const bool hi = qi >= q.sep, lo_ok = !hi && !(c.skip0 && qi == 0);
+  q.fq = hi ? c.c1 : (lo_ok ? c.c0 : 1.f);
+  q.sel1 = hi ? 1.f : 0.f; q.sel0 = lo_ok ? 1.f : 0.f;
+  return q;
+}
 // Key-padding mask of one 64-key tile as a wave-uniform bit set (bit j = key kt*64 + j is attended; keys past the end: 1, they are handled by
 // the caller).  Lane j loads mask[kt*64 + j] once (one coalesced 512-byte request); `mask_row[kj]` per score -- 32 loads per lane whose address
 // depends on the lane only through one bit -- had been scalarised by the compiler into waterfall loops of scalar loads (86 v_readlane + 160
@@ -361,6 +373,7 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
       } else {
         float mx = -1.0e30f;
         const uint64_t mb = mask_bits(ctl, kt, Stot, lane) >> (4 * hh);   // this lane's keys: bit (t*32 + (r&3) + 8*(r>>2))
+        const QueryRw qr = make_qrw(ctl, qi[u]);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
             const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
             float s = st[u][t][r] * p.scale;
             if (text) {
-              s *= reweight(ctl, qi[u], kj);
+              s *= kj >= qr.sep ? qr.fq : 1.f;
               s += mask_add(mb, t * 32 + (r & 3) + 8 * (r >> 2));
             }
             s *= LOG2E;
@@ -547,24 +560,22 @@ __global__ __launch_bounds__(NTH) void attn_bwd_dq_k(mart_attn_bwd_desc pb) {
           }
         } else {
           const uint64_t mb = mask_bits(ctl, kt, Stot, lane) >> (4 * hh);
+          const QueryRw qr = make_qrw(ctl, qi[u]);
+          const uint32_t rowbase = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq + (uint32_t)qi[u]) * (uint32_t)Stot;
+          const float lse_u = qvalid[u] ? lse[u] : 1.0e30f;    // rows past Sq: p = exp2(x - 1e30) = 0
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
             const float spre = st[r] * p.scale;
-            float f = 1.f, sc = spre;
-            if (text) {
-              f = reweight(ctl, qi[u], kj);
-              sc *= f;
-              sc += mask_add(mb, t * 32 + (r & 3) + 8 * (r >> 2));
-            }
-            float pr = (kj < Stot && qvalid[u]) ? __builtin_amdgcn_exp2f(sc * LOG2E - lse[u]) : 0.f;
+            const bool rw = kj >= qr.sep;                      // key in the reweighted block
+            const float f = rw ? qr.fq : 1.f;
+            const float sc = spre * f + mask_add(mb, t * 32 + (r & 3) + 8 * (r >> 2));
+            const float pr = kj < Stot ? __builtin_amdgcn_exp2f(sc * LOG2E - lse_u) : 0.f;
             float dpd = dp[r];
-            if (TEXT && ctl.p_drop > 0.f) {
-              const uint32_t idx = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq + (uint32_t)qi[u]) * (uint32_t)Stot + (uint32_t)kj;
-              dpd = dropout_keep32(ctl.s2, idx, ctl.thr) ? dpd * ctl.inv_keep : 0.f;
-            }
+            if (TEXT && ctl.p_drop > 0.f) dpd = dropout_keep32(ctl.s2, rowbase + (uint32_t)kj, ctl.thr) ? dpd * ctl.inv_keep : 0.f;
             const float ds = pr * (dpd - delta[u]);        // d/d(post-reweight, pre-mask score)
-            if (TEXT && ctl.sep >= 0 && kj >= ctl.sep) { if (qi[u] >= ctl.sep) dc1 += ds * spre; else if (!(ctl.skip0 && qi[u] == 0)) dc0 += ds * spre; }
+            const float tw = rw ? ds * spre : 0.f;           // branch-free d(w0) / d(w1) sums: the selectors are lane constants
+            dc1 = __builtin_fmaf(tw, qr.sel1, dc1); dc0 = __builtin_fmaf(tw, qr.sel0, dc0);
             dsv[r] = ds * f;
           }
         }
@@ -734,18 +745,23 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
           }
         } else {
 #pragma unroll
+          // key-owner lanes: "this key is in the reweighted block" is a lane constant, the query side of the factor one compare + select
+          // per score; the dropout index = kbase + q * Stot with kbase hoisted out of the loops
+          const bool krw = ctl.sep >= 0 && kj >= ctl.sep;
+          const uint32_t kbase = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq) * (uint32_t)Stot + (uint32_t)kj;
           for (int i = 0; i < 8; ++i) {
             const int r = 8 * a + i;
             const int ql = t * 32 + mfma_row(r, hh);
             const int qi = qt * 64 + ql;
             float f = 1.f, sc = st[r] * p.scale;
-            if (text) { f = reweight(ctl, qi, kj); sc = sc * f + maskadd; }
+            if (text) {
+              const float fq = qi >= ctl.sep ? ctl.c1 : ((ctl.skip0 && qi == 0) ? 1.f : ctl.c0);
+              f = krw ? fq : 1.f;
+              sc = sc * f + maskadd;
+            }
             const float pr = (kvalid && qi < p.Sq) ? __builtin_amdgcn_exp2f(sc * LOG2E - sLse[ql]) : 0.f;
             float keep = 1.f;
-            if (TEXT && ctl.p_drop > 0.f) {
-              const uint32_t idx = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq + (uint32_t)qi) * (uint32_t)Stot + (uint32_t)kj;
-              keep = dropout_keep32(ctl.s2, idx, ctl.thr) ? ctl.inv_keep : 0.f;
-            }
+            if (TEXT && ctl.p_drop > 0.f) keep = dropout_keep32(ctl.s2, kbase + (uint32_t)qi * (uint32_t)Stot, ctl.thr) ? ctl.inv_keep : 0.f;
             pd8[i] = pr * keep;
             ds8[i] = pr * (dp[r] * keep - sDel[ql]) * f;
           }
