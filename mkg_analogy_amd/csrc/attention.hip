@@ -744,11 +744,11 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
             }
           }
         } else {
-#pragma unroll
           // key-owner lanes: "this key is in the reweighted block" is a lane constant, the query side of the factor one compare + select
           // per score; the dropout index = kbase + q * Stot with kbase hoisted out of the loops
           const bool krw = ctl.sep >= 0 && kj >= ctl.sep;
           const uint32_t kbase = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq) * (uint32_t)Stot + (uint32_t)kj;
+#pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int r = 8 * a + i;
             const int ql = t * 32 + mfma_row(r, hh);
