@@ -744,24 +744,19 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
             }
           }
         } else {
-          // key-owner lanes: "this key is in the reweighted block" is a lane constant, the query side of the factor one compare + select
-          // per score; the dropout index = kbase + q * Stot with kbase hoisted out of the loops
-          const bool krw = ctl.sep >= 0 && kj >= ctl.sep;
-          const uint32_t kbase = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq) * (uint32_t)Stot + (uint32_t)kj;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int r = 8 * a + i;
             const int ql = t * 32 + mfma_row(r, hh);
             const int qi = qt * 64 + ql;
             float f = 1.f, sc = st[r] * p.scale;
-            if (text) {
-              const float fq = qi >= ctl.sep ? ctl.c1 : ((ctl.skip0 && qi == 0) ? 1.f : ctl.c0);
-              f = krw ? fq : 1.f;
-              sc = sc * f + maskadd;
-            }
+            if (text) { f = reweight(ctl, qi, kj); sc = sc * f + maskadd; }
             const float pr = (kvalid && qi < p.Sq) ? __builtin_amdgcn_exp2f(sc * LOG2E - sLse[ql]) : 0.f;
             float keep = 1.f;
-            if (TEXT && ctl.p_drop > 0.f) keep = dropout_keep32(ctl.s2, kbase + (uint32_t)qi * (uint32_t)Stot, ctl.thr) ? ctl.inv_keep : 0.f;
+            if (TEXT && ctl.p_drop > 0.f) {
+              const uint32_t idx = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq + (uint32_t)qi) * (uint32_t)Stot + (uint32_t)kj;
+              keep = dropout_keep32(ctl.s2, idx, ctl.thr) ? ctl.inv_keep : 0.f;
+            }
             pd8[i] = pr * keep;
             ds8[i] = pr * (dp[r] * keep - sDel[ql]) * f;
           }
