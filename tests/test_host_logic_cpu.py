@@ -263,3 +263,22 @@ def test_collator_rejects_prompts_without_exactly_one_mask():
         col([dict(input_ids=[101, 103, 103, 102], attention_mask=[1] * 4, token_type_ids=[0] * 4, label=3)])
     with pytest.raises(ValueError):
         col([dict(input_ids=[101, 5, 103, 102], attention_mask=[1] * 4, token_type_ids=[0] * 4, label=-100)])  # ignore_index unsupported
+
+
+def test_rank_seed_is_a_hash_of_base_seed_and_rank():
+    """distributed.rank_seed: rank 0 keeps the single-process dropout stream, every other rank gets a distinct hashed base
+    seed small enough that the model's per-step seed (base * 1000003 + step * 7919 + per-layer offsets < 64) never collides across
+    (rank, step, offset) for realistic step counts."""
+    from mkg_analogy_amd.distributed import rank_seed
+    base = 0x5EED
+    seeds = [rank_seed(base, r) for r in range(8)]
+    assert seeds[0] == base and len(set(seeds)) == 8
+    assert all(0 < s < (1 << 26) + 1 for s in seeds[1:])
+    assert rank_seed(base, 3) == rank_seed(base, 3) and rank_seed(base + 1, 3) != rank_seed(base, 3)
+    used = set()
+    for s in seeds:
+        for step in range(0, 2000, 7):
+            for off in (0, 1, 10, 11, 12, 57):
+                v = (s * 1000003 + step * 7919) & 0x7FFFFFFFFFFF
+                assert (v + off) not in used
+                used.add(v + off)
