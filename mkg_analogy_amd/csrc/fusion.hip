@@ -62,7 +62,10 @@ __device__ __forceinline__ bf16x8 frag(const char* img, int half, int ks, const 
 }
 // X^T[i = column dt*32 + l31][k = rows base + 8 hh + 0..7] (columns on lanes); base a multiple of 16
 __device__ __forceinline__ bf16x8 frag_tr(const char* img, int base, int dt, const Offs& o) {
-  return join_tr(lds_tr_read(img + base * 128 + o.trl[dt]), lds_tr_read(img + base * 128 + o.trh[dt]));
+  // dt is a run-time value in the d-tile loops (d tile = wave * DT + i): indexing o.trl[dt] put the four offsets into scratch memory and a
+  // scratch_load in front of every transposed read; a select keeps them in registers
+  const int lo_ = dt ? o.trl[1] : o.trl[0], hi_ = dt ? o.trh[1] : o.trh[0];
+  return join_tr(lds_tr_read(img + base * 128 + lo_), lds_tr_read(img + base * 128 + hi_));
 }
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
