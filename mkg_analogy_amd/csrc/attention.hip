@@ -78,6 +78,12 @@ __device__ __forceinline__ int swz_key(int row) {
 // (Measured and dropped, twice each: the copy as opaque assembly -- no compiler-forced vmcnt(0) in front of the
 // transposed reads -- is 2 % slower; a 4-stage ring with three tiles in flight and counted waits changes nothing:
 // the loop does not wait for the DMA)
+#ifndef STAGE_RAW
+#define STAGE_RAW 0
+#endif
+__device__ __forceinline__ void stage16(const void* src, void* dst) {
+  if (STAGE_RAW) glds16_raw(src, dst); else glds16(src, dst);
+}
 __device__ __forceinline__ void stage_tile(const Side& s, int b, int h, int r0, char* lds, int tid, int wave) {
   const int rowh = tid >> 3, pc = tid & 7, lc = pc ^ swz_key(rowh);               // the key is the same for row and row + 32
   const unsigned off_own = (unsigned)(rowh * s.ld_own + lc * 8), off_pre = (unsigned)(rowh * s.ld_pre + lc * 8);
@@ -87,10 +93,10 @@ __device__ __forceinline__ void stage_tile(const Side& s, int b, int h, int r0, 
     const int j0 = r0 + r * 32;                                                       // first row of this half (wave-uniform)
     char* dst = lds + (r * NTH + wave * 64) * 16;
     if ((s.n_pre & 31) == 0 && j0 + 32 <= n_tot) {
-      if (j0 < s.n_pre) glds16(s.pre + ((long long)b * s.n_pre + j0) * s.ld_pre + h * 64 + off_pre, dst);
-      else glds16(s.own + ((long long)b * s.n_own + (j0 - s.n_pre)) * s.ld_own + h * 64 + off_own, dst);
+      if (j0 < s.n_pre) stage16(s.pre + ((long long)b * s.n_pre + j0) * s.ld_pre + h * 64 + off_pre, dst);
+      else stage16(s.own + ((long long)b * s.n_own + (j0 - s.n_pre)) * s.ld_own + h * 64 + off_own, dst);
     } else {
-      glds16(side_row(s, b, h, j0 + rowh) + lc * 8, dst);
+      stage16(side_row(s, b, h, j0 + rowh) + lc * 8, dst);
     }
   }
 }
@@ -681,7 +687,12 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
   auto stage_stats = [&](int q0, char* base) {       // 64 lse + 64 delta floats via 4-byte LDS-DMA (waves 0,1)
     if (wave < 2) {
       const float* src = (wave == 0 ? lse_b : del_b) + min(q0 + lane, p.Sq - 1);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + 2 * TILE_BYTES + wave * 256), 4, 0, 0);
+      if (STAGE_RAW) {
+        const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)LDS_PTR(base + 2 * TILE_BYTES + wave * 256));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(dst), "v"(src) : "memory", "m0");
+      } else {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + 2 * TILE_BYTES + wave * 256), 4, 0, 0);
+      }
     }
   };
 
@@ -853,7 +864,11 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
     const int q = min(t * FQ + row, p.Sq - 1);
     const bf16* src = wave < 4 ? (const bf16*)p.q + ((long long)b * p.Sq + q) * p.ldq + h * 64 + lc * 8
                                : (const bf16*)pb.dctx + ((long long)b * p.Sq + q) * pb.lddctx + h * 64 + lc * 8;
-    glds16(src, smem + F_OFF_Q + ((wave < 4 ? 0 : 2) + buf) * F_QT + ((wave & 3) * 64) * 16);
+#ifndef FUSED_RAW_Q
+#define FUSED_RAW_Q 1
+#endif
+    char* dstq = smem + F_OFF_Q + ((wave < 4 ? 0 : 2) + buf) * F_QT + ((wave & 3) * 64) * 16;
+    if (FUSED_RAW_Q) glds16_raw(src, dstq); else glds16(src, dstq);
   };
   stage_q(0, 0);
   {
