@@ -1085,6 +1085,282 @@ int check_fwd(const mart_attn_fwd_desc* d) {
   MART_CHECK(d->p_drop == 0.f || (long long)d->B * d->nh * d->Sq * (d->Lp + d->Sk) < (1LL << 32), "attn: dropout indices are 32-bit (B nh Sq Sk < 2^32)");
   return 0;
 }
+
+// =========================================================================== backward, fused, text shape (<= 64 queries x <= 64 keys per head)
+// The two-pass kernels above are built for long key / query streams: at the text shape (BertSelfAttention at L = 64: ONE 64 x 64 score tile per
+// head) half of their waves own no rows, both passes stage tiles through the double-buffered ring behind two barriers, S and the exponentials
+// are computed twice and `delta` makes a round trip through HBM.  Here ONE 2-wave workgroup does a head in one pass:
+//   * Q, dO and K sit in LDS as swizzled 64 x 64 tiles (LDS-DMA, one barrier); lse and delta = rowsum(dO * O) of the 64 query rows beside them
+//   * wave w OWNS keys [32w, 32w + 32): S = Q k^T, dP = dO v^T (lane = key), the text options (reweight, key-padding mask, dropout,
+//     d(w0) / d(w1)) exactly as in the two-pass kernels, dV += dO^T Pd, dK += Q^T dS; dS goes transposed-ready into a fourth tile [key][q]
+//   * after the second barrier wave w OWNS queries [32w, 32w + 32): dQ^T = K^T dS^T over all 64 keys, both operands by transposed LDS reads
+// No atomics, no cross-wave reduction: results are independent of scheduling.
+constexpr int T64_LDS = 3 * TILE_BYTES + 512;
+// swap a value between lanes 2m and 2m + 1 (DPP quad_perm [1,0,3,2]: a full-rate VALU move, no LDS)
+__device__ __forceinline__ uint32_t pair_swap(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
+#ifndef T64_MINW
+#define T64_MINW 3
+#endif
+template <bool DROP>
+__global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd_desc pb) {
+  __shared__ __attribute__((aligned(16))) char smem[T64_LDS];
+  const mart_attn_fwd_desc& p = pb.f;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int Stot = p.Sk;                                  // host: no prefix, Sq <= 64, Sk <= 64
+  const TextCtl ctl = make_ctl(p, b, p.Sk);
+  const LaneOffs lo = make_offs(lane);
+  char* sQ = smem;
+  char* sG = smem + TILE_BYTES;
+  char* sD = smem + 2 * TILE_BYTES;
+  float* sLse = (float*)(smem + 3 * TILE_BYTES);
+  float* sDel = sLse + 64;
+
+  const int rowh = tid >> 3, lc = (tid & 7) ^ swz_key(rowh);             // staging: 16 rows per DMA instruction of the workgroup; the key repeats every 16 rows
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                           // Q, dO tiles (rows past the end: clamped copies)
+    const long long rq = (long long)b * p.Sq + min(16 * i + rowh, p.Sq - 1);
+    const int doff = (i * 128 + wave * 64) * 16;
+    glds16_raw((const bf16*)p.q + rq * p.ldq + h * 64 + lc * 8, sQ + doff);
+    glds16_raw((const bf16*)pb.dctx + rq * pb.lddctx + h * 64 + lc * 8, sG + doff);
+  }
+  {                                                       // row statistics: two threads per query row (32 head dims each)
+    const int q = tid >> 1, half = tid & 1;
+    float l = 1.0e30f, dsum = 0.f;                        // rows past Sq: p = exp2(x - 1e30) = 0
+    const long long li = ((long long)b * p.nh + h) * p.Sq + q;
+    if (q < p.Sq) {
+      l = p.lse[li];
+      const bf16* op = (const bf16*)p.ctx + ((long long)b * p.Sq + q) * p.ldctx + h * 64 + half * 32;
+      const bf16* gp = (const bf16*)pb.dctx + ((long long)b * p.Sq + q) * pb.lddctx + h * 64 + half * 32;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 o = *(const bf16x8*)(op + c * 8), g = *(const bf16x8*)(gp + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)o[e] * (float)g[e];
+      }
+    }
+    dsum += __builtin_bit_cast(float, pair_swap(__builtin_bit_cast(uint32_t, dsum)));
+    if (half == 0) {
+      if (q < p.Sq) pb.delta[li] = dsum;
+      sLse[q] = l; sDel[q] = dsum;
+    }
+  }
+  // own keys
+  const int kj = wave * 32 + l31;
+  const bool kvalid = kj < Stot;
+  // K / V fragments of the own keys: loaded for each query half (the second time from L1 / L2) instead of held across the softmax arithmetic --
+  // 32 VGPRs that decide between two and three waves per SIMD
+  bf16x8 kf[4], vf[4];
+  const bf16* kp = (const bf16*)p.k + ((long long)b * p.Sk + min(kj, p.Sk - 1)) * p.ldk + h * 64 + hh * 8;
+  const bf16* vp = (const bf16*)p.v + ((long long)b * p.Sk + min(kj, p.Sk - 1)) * p.ldv + h * 64 + hh * 8;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const bf16x8*)(kp + ks * 16); vf[ks] = *(const bf16x8*)(vp + ks * 16); }
+  // lane constants of the key: additive mask in the log2 domain (keys past the end: p = 0), membership in the reweighted block
+  const float madd2 = !kvalid ? -1.0e30f : (ctl.mask_row ? (1.0f - (float)ctl.mask_row[kj]) * (-10000.0f * LOG2E) : 0.f);
+  const int sep = ctl.sep < 0 ? 0x7fffffff : ctl.sep;
+  const bool rw = kj >= sep;                               // this lane's key is in the reweighted block
+  const float rwf = rw ? 1.f : 0.f;
+  // dropout (common.h dropout_keep32): element idx = (head row) * Stot + key takes the low / high 16 bits of ONE hash per index pair.  With an
+  // even key count the two keys of a pair sit in lanes 2m, 2m + 1 of the same query row: the even lane hashes rows 0-3 of each 8-row group, the
+  // odd lane rows 4-7, and a DPP swap hands each the other half -- four hashes per eight decisions.
+  const uint32_t headbase = ((uint32_t)b * p.nh + h) * (uint32_t)p.Sq;
+  const bool shared = (Stot & 1) == 0;                     // wave-uniform
+  const int odd = lane & 1;
+  const uint32_t ib_own = headbase * (uint32_t)Stot + (uint32_t)kj + (uint32_t)(4 * hh) * (uint32_t)Stot;                    // + row * Stot
+  const uint32_t ib_pair = headbase * (uint32_t)Stot + (uint32_t)(kj & ~1) + (uint32_t)(4 * hh + 8 * odd) * (uint32_t)Stot;  // this lane's four rows of a group
+  const uint32_t hsh = (uint32_t)(kj & 1) * 16u;
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+  float dc0 = 0.f, dc1 = 0.f;
+  tile_barrier();
+
+  const int dkey = swz_key(kj);
+  char* drow = sD + kj * 128 + 8 * hh;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t * 32 >= p.Sq) continue;                          // wave-uniform: no query in this half (its dS columns are never read)
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      st = mfma32(tile_frag(sQ, t, ks, lo), kf[ks], st);
+      dp = mfma32(tile_frag(sG, t, ks, lo), vf[ks], dp);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float pd8[8], ds8[8], l8[8], d8[8];
+      {
+        const f32x4 la = *(const f32x4*)(sLse + t * 32 + 16 * a + 4 * hh), lb = *(const f32x4*)(sLse + t * 32 + 16 * a + 8 + 4 * hh);
+        const f32x4 da = *(const f32x4*)(sDel + t * 32 + 16 * a + 4 * hh), db = *(const f32x4*)(sDel + t * 32 + 16 * a + 8 + 4 * hh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { l8[e] = la[e]; l8[4 + e] = lb[e]; d8[e] = da[e]; d8[4 + e] = db[e]; }
+      }
+      float keep8[8];
+      if (DROP) {
+        const int g0 = t * 32 + 16 * a;                    // first query row of the group (rows g0 + 4hh + {0..3, 8..11})
+        uint32_t hv[8];
+        if (shared) {
+          uint32_t mine[4], other[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mine[j] = rng_pair(ctl.s2, (ib_pair + (uint32_t)(g0 + j) * (uint32_t)Stot) >> 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) other[j] = pair_swap(mine[j]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { hv[j] = odd ? other[j] : mine[j]; hv[4 + j] = odd ? mine[j] : other[j]; }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) hv[i] = rng_pair(ctl.s2, (ib_own + (uint32_t)(g0 + (i & 3) + 8 * (i >> 2)) * (uint32_t)Stot) >> 1);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t idx_par = shared ? 0u : ((ib_own + (uint32_t)(g0 + (i & 3) + 8 * (i >> 2)) * (uint32_t)Stot) & 1u) * 16u;
+          const uint32_t u = (hv[i] >> (shared ? hsh : idx_par)) & 0xffffu;
+          keep8[i] = u >= ctl.thr ? ctl.inv_keep : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 8 * a + i;
+        const int qi = t * 32 + mfma_row(r, hh);
+        const float spre = st[r] * p.scale;
+        const bool qhi = qi >= sep;
+        const bool qlo = !qhi && !(ctl.skip0 && qi == 0);
+        const float fq = qhi ? ctl.c1 : (qlo ? ctl.c0 : 1.f);
+        const float f = rw ? fq : 1.f;
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(spre * f, LOG2E, madd2 - l8[i]));
+        const float dpd = DROP ? dp[r] * keep8[i] : dp[r];
+        const float ds = pr * (dpd - d8[i]);               // d/d(post-reweight, pre-mask score)
+        const float tw = ds * (spre * rwf);
+        dc1 = __builtin_fmaf(tw, qhi ? 1.f : 0.f, dc1);
+        dc0 = __builtin_fmaf(tw, qlo ? 1.f : 0.f, dc0);
+        pd8[i] = DROP ? pr * keep8[i] : pr;
+        ds8[i] = ds * f;
+      }
+      const bf16x8 pf = pack8(pd8);
+      const bf16x8 df = pack8(ds8);
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+      const u32x4_t dw4 = __builtin_bit_cast(u32x4_t, df);
+      // dS tile [key][q]: elements 0-3 are queries t*32 + 16a + 4hh + 0..3 (16-byte chunk 4t + 2a), elements 4-7 the same rows of chunk 4t + 2a + 1
+      *(u32x2_t*)(drow + (((4 * t + 2 * a) ^ dkey) << 4)) = u32x2_t{dw4[0], dw4[1]};
+      *(u32x2_t*)(drow + (((4 * t + 2 * a + 1) ^ dkey) << 4)) = u32x2_t{dw4[2], dw4[3]};
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dv[dt] = mfma32(tile_frag_tr(sG, t * 32 + 16 * a, dt, lo), pf, dv[dt]);
+        dk[dt] = mfma32(tile_frag_tr(sQ, t * 32 + 16 * a, dt, lo), df, dk[dt]);
+      }
+    }
+    if (t == 0) {
+      // rows 0..31 of the Q and dO tiles are dead once BOTH waves are through the first query half: the K tile of the dQ contraction lands there
+      // (keys 0..31 over Q, 32..63 over dO) while the second half computes -- three tiles of LDS instead of four: six workgroups per CU
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const volatile bf16x8*)(kp + ks * 16); vf[ks] = *(const volatile bf16x8*)(vp + ks * 16); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long rk = (long long)b * p.Sk + min(16 * i + rowh, p.Sk - 1);
+        glds16_raw((const bf16*)p.k + rk * p.ldk + h * 64 + lc * 8, (i < 2 ? sQ : sG) + ((i & 1) * 128 + wave * 64) * 16);
+      }
+    }
+  }
+  // ---- d(w0), d(w1): one private slot per wave (slots 2, 3 of the head are the idle waves of the two-pass layout: zero)
+  if (pb.dw) {
+    const bool on = ctl.sep >= 0;
+    dc0 = wave_sum(dc0); dc1 = wave_sum(dc1);
+    if (lane == 0) {
+      if (pb.dw_ws) {
+        const long long slot = ((long long)b * p.nh + h) * 4 + wave;
+        pb.dw_ws[2 * slot] = on ? dc0 : 0.f; pb.dw_ws[2 * slot + 1] = on ? dc1 : 0.f;
+        pb.dw_ws[2 * (slot + 2)] = 0.f; pb.dw_ws[2 * (slot + 2) + 1] = 0.f;
+      } else if (on) {
+        const float w0 = p.w0[0], w1 = p.w1[0];
+        if (w0 >= 0.f && w0 <= 0.5f) atomicAdd(pb.dw + 0, dc0);     // clamp sub-gradient: passes inside and AT the bounds
+        if (w1 >= 0.5f && w1 <= 1.f) atomicAdd(pb.dw + 1, dc1);
+      }
+    }
+  }
+  tile_barrier();                                          // dS tile complete (LDS writes of both waves), K tile landed
+
+  // ---- dQ^T[d][q] = sum over keys K^T[d][key] dS^T[key][q] for the wave's 32 queries
+  const bool qwave = wave * 32 < p.Sq;                     // wave-uniform
+  f32x16 dq[2];
+  if (qwave) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    const int tq1 = wave ? lo.tr1[1] : lo.tr1[0], tq2 = wave ? lo.tr2[1] : lo.tr2[0];   // (a run-time index into the offset arrays would put them in scratch)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 df = join_tr(lds_tr_read(sD + 16 * kk * 128 + tq1), lds_tr_read(sD + 16 * kk * 128 + tq2));
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tile_frag_tr(kk < 2 ? sQ : sG, 16 * (kk & 1), dt, lo), df, dq[dt]);
+    }
+  }
+  // ---- results leave through LDS.  A result tile has "lane = row, registers = 4 consecutive head dims": stored from registers a wave instruction
+  // writes 8 bytes into each of 32 rows that lie 2 * ld bytes apart -- 32 partial cache lines per instruction, 24 such instructions per wave (the
+  // stores were 21 of the kernel's 57 us).  Staged [row][64 dims] in the tiles that are dead by now, eight lanes write one 128-byte row segment.
+  //   dQ: bf16 tile over the dS tile;  dK, then dV: f32 tiles over the Q | dO tiles (f32 so that the optional accumulation into the destination
+  //   rounds once, exactly as the two-pass kernels do)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                         // every LDS read of the dQ contraction is done
+  char* sF = smem;                                         // 64 rows x 256 bytes
+  const int fkey = (kj & 15);
+  auto stage_f32 = [&](const f32x16* acc2, float mul) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int c16 = 8 * dt + 2 * qd + hh;              // 16-byte chunk of dims dt*32 + 8qd + 4hh .. +3
+        *(f32x4*)(sF + kj * 256 + ((c16 ^ fkey) << 4)) =
+            f32x4{acc2[dt][4 * qd] * mul, acc2[dt][4 * qd + 1] * mul, acc2[dt][4 * qd + 2] * mul, acc2[dt][4 * qd + 3] * mul};
+      }
+  };
+  auto copy_f32 = [&](void* dst, int ld) {                 // thread: rows 16i + rowh, dims 8g .. 8g+7 (g = tid & 7)
+    const int g = tid & 7;
+    const bool acc = pb.accum_dkv != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * i + rowh;
+      if (row >= p.Sk) continue;
+      f32x4 a = *(const f32x4*)(sF + row * 256 + (((2 * g) ^ (row & 15)) << 4));
+      f32x4 c = *(const f32x4*)(sF + row * 256 + (((2 * g + 1) ^ (row & 15)) << 4));
+      bf16* op = (bf16*)dst + ((long long)b * p.Sk + row) * ld + h * 64 + 8 * g;
+      if (acc) {
+        const bf16x8 old = *(const bf16x8*)op;
+        a += f32x4{(float)old[0], (float)old[1], (float)old[2], (float)old[3]};
+        c += f32x4{(float)old[4], (float)old[5], (float)old[6], (float)old[7]};
+      }
+      const bf16x4 ra = f4_to_bf4(a), rc = f4_to_bf4(c);
+      *(bf16x8*)op = bf16x8{ra[0], ra[1], ra[2], ra[3], rc[0], rc[1], rc[2], rc[3]};
+    }
+  };
+  if (qwave) {
+    const int qi = wave * 32 + l31, qkey = swz_key(qi);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 v = {dq[dt][4 * qd] * p.scale, dq[dt][4 * qd + 1] * p.scale, dq[dt][4 * qd + 2] * p.scale, dq[dt][4 * qd + 3] * p.scale};
+        *(bf16x4*)(sD + qi * 128 + (((4 * dt + qd) ^ qkey) << 4) + 8 * hh) = f4_to_bf4(v);
+      }
+  }
+  stage_f32(dk, p.scale);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                            // dQ: physical chunk pc of row 16i + rowh holds the logical chunk lc (same map as the staging DMA)
+    const int row = 16 * i + rowh;
+    if (row < p.Sq) *(bf16x8*)((bf16*)pb.dq + ((long long)b * p.Sq + row) * pb.lddq + h * 64 + lc * 8) = *(const bf16x8*)(sD + row * 128 + (tid & 7) * 16);
+  }
+  copy_f32(pb.dk, pb.lddk);
+  __syncthreads();
+  stage_f32(dv, 1.f);
+  __syncthreads();
+  copy_f32(pb.dv, pb.lddv);
+}
+
 MartAttrOnce g_attr_once;
 int set_attrs() {
   bool* g_attr_set = g_attr_once.slot();
@@ -1131,6 +1407,18 @@ extern "C" int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream) {
   if (!text && fused && f.Lp + f.Sk <= 512 && f.Sq <= 512 && f.Sq > 128) {      // one workgroup per head: every key and query row fits
     hipLaunchKernelGGL(attn_bwd_fused_k, dim3(f.nh, f.B), dim3(512), F_LDS, st, *d);
     MART_LAUNCH_CHECK();
+    return 0;
+  }
+  static const int text_fused = getenv("MART_ATTN_TEXT_FUSED") ? atoi(getenv("MART_ATTN_TEXT_FUSED")) : 1;
+  const bool al16 = d->lddq % 8 == 0 && d->lddk % 8 == 0 && d->lddv % 8 == 0 && (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 15) == 0;
+  if (text && text_fused && al16 && f.Lp == 0 && f.Sq <= 64 && f.Sk <= 64) {            // one 64 x 64 score tile per head: one pass, one 2-wave workgroup per head
+    if (f.p_drop > 0.f) hipLaunchKernelGGL(attn_bwd_text64_k<true>, dim3(f.nh, f.B), dim3(128), 0, st, *d);
+    else hipLaunchKernelGGL(attn_bwd_text64_k<false>, dim3(f.nh, f.B), dim3(128), 0, st, *d);
+    MART_LAUNCH_CHECK();
+    if (d->dw && d->dw_ws && f.sep) {
+      hipLaunchKernelGGL(attn_dw_reduce_k, dim3(1), dim3(1024), 0, st, d->dw_ws, (long long)f.B * f.nh * 4, f.w0, f.w1, d->dw);
+      MART_LAUNCH_CHECK();
+    }
     return 0;
   }
   if (text) hipLaunchKernelGGL((attn_bwd_dq_k<true, 1>), dim3((f.Sq + 127) / 128, f.nh, f.B), dim3(NTH), LDS_BYTES, st, *d);

@@ -18,7 +18,7 @@ sep = torch.full((B, 6), 20, device="cuda", dtype=torch.int64)
 w0, w1 = torch.tensor([0.25], device="cuda"), torch.tensor([0.5], device="cuda")
 dw = torch.zeros(2, device="cuda")
 kw = dict(q=qkv[:, :H], k=qkv[:, H:2*H], v=qkv[:, 2*H:], ctx=ctx, lse=lse, B=B, nh=nh, Sq=L, Sk=L, scale=0.125, attn_mask=am, sep=sep[:, 2:], sep_stride=6,
-          w0=w0, w1=w1, p_drop=0.1, seed=1234)
+          w0=w0, w1=w1, p_drop=float(os.environ.get("P", 0.1)), seed=1234)
 print(f"text attn fwd: {timeit(lambda: ops.attn_fwd(**kw)) * 1e3:.1f} us")
 ops.attn_fwd(**kw)
 print(f"text attn bwd (dq + dw reduce + dkv): {timeit(lambda: ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2*H], dv=dqkv[:, 2*H:], dw=dw, **kw)) * 1e3:.1f} us")
