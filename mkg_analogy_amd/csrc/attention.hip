@@ -836,6 +836,8 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __
 // per pass, 8 of them in each 64-byte half of the 128-byte bank window: the key must be a bijection of (row >> 1) & 7.  Readers:
 // transposed reads of rows r..r+7 per 32-lane pass, 32 bytes each: rows r and r + 4 must use different 32-byte halves: bit 2 of
 // the key = bit 2 of the row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true)); }
 __device__ __forceinline__ int ds_swz(int row) { return (((row >> 2) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 1) & 1); }
 
 __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
@@ -877,21 +879,31 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
     for (int i = 0; i < (2 * F_DS / 16) / 512; ++i) z[i * 512 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   {
-    const int q = tid;                               // 512 threads >= Sq rows (host checks Sq <= 512)
-    float l = 1.0e30f, dsum = 0.f;                   // rows past Sq: p = exp2(x - 1e30) = 0, so they contribute nothing
-    if (q < p.Sq) {
-      l = p.lse[((long long)b * p.nh + h) * p.Sq + q];
-      const bf16* op = (const bf16*)p.ctx + ((long long)b * p.Sq + q) * p.ldctx + h * 64;
-      const bf16* gp = (const bf16*)pb.dctx + ((long long)b * p.Sq + q) * pb.lddctx + h * 64;
+    // row statistics.  delta = rowsum(dO * O): EIGHT lanes per query row, one 16-byte chunk of O and dO each, so that a load instruction reads whole
+    // 128-byte row segments (one thread per row = 64 partial cache lines per load instruction, 16 instructions per wave, in a prologue nothing overlaps)
+    const int pc = tid & 7;
+    bf16x8 ov[8], gv[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const bf16x8 o = *(const bf16x8*)(op + c * 8), g = *(const bf16x8*)(gp + c * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += (float)o[e] * (float)g[e];
-      }
-      if (pb.delta) pb.delta[((long long)b * p.nh + h) * p.Sq + q] = dsum;
+    for (int i = 0; i < 8; ++i) {                        // all loads first (rows past Sq: clamped, discarded below)
+      const long long r = (long long)b * p.Sq + min(64 * i + (tid >> 3), p.Sq - 1);
+      ov[i] = *(const bf16x8*)((const bf16*)p.ctx + r * p.ldctx + h * 64 + pc * 8);
+      gv[i] = *(const bf16x8*)((const bf16*)pb.dctx + r * pb.lddctx + h * 64 + pc * 8);
     }
-    sLse[q] = l; sDel[q] = dsum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = 64 * i + (tid >> 3);
+      float dsum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += (float)ov[i][e] * (float)gv[i][e];
+      dsum += dpp_f32<0xB1>(dsum);                     // lanes ^1, ^2 (quad permutes), then the other quad of the 8-lane group (row_half_mirror)
+      dsum += dpp_f32<0x4E>(dsum);
+      dsum += dpp_f32<0x141>(dsum);
+      if (pc == 0) {
+        sDel[q] = q < p.Sq ? dsum : 0.f;
+        if (pb.delta && q < p.Sq) pb.delta[((long long)b * p.nh + h) * p.Sq + q] = dsum;
+      }
+    }
+    sLse[tid] = tid < p.Sq ? p.lse[((long long)b * p.nh + h) * p.Sq + tid] : 1.0e30f;   // rows past Sq: p = exp2(x - 1e30) = 0, they contribute nothing
   }
   // own keys: V fragments in registers, validity
   bf16x8 vf[2][4];
@@ -1045,7 +1057,49 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
     tile_barrier();                                    // dS image of tile t complete, Q / dO tile t+1 landed, tile t's buffers free
   }
 
-  // ---- dK, dV of the wave's keys
+  // ---- dK, dV of the wave's keys.  From registers ("lane = key, registers = 4 consecutive head dims") a store instruction writes 8 bytes into each
+  // of 32 rows that lie 2 * ld bytes apart: 32 partial cache lines per instruction, 32 such instructions per wave, at the end of a workgroup that
+  // has the CU to itself.  Staged as bf16 rows in the K image (dK) and the dS images (dV) -- both dead by now -- eight lanes store one 128-byte row
+  // segment (8 lines per instruction).  The accumulating form (rounds once from f32) keeps the register path.
+#ifndef FUSED_LDS_EPI
+#define FUSED_LDS_EPI 1
+#endif
+  const bool al16 = ((((uintptr_t)pb.dk | (uintptr_t)pb.dv | (uintptr_t)pb.dpk | (uintptr_t)pb.dpv) & 15) == 0) && pb.lddk % 8 == 0 && pb.lddv % 8 == 0 &&
+                    (p.Lp == 0 || pb.lddp % 8 == 0);
+  if (FUSED_LDS_EPI && !pb.accum_dkv && al16) {
+    char* sV2 = smem + F_OFF_DS;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int kj = wave * 64 + kb * 32 + l31, kkey = swz_key(kj);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int off = kj * 128 + (((4 * dt + qd) ^ kkey) << 4) + 8 * hh;
+          *(bf16x4*)(sK + off) = f4_to_bf4(f32x4{dk[kb][dt][4 * qd] * p.scale, dk[kb][dt][4 * qd + 1] * p.scale, dk[kb][dt][4 * qd + 2] * p.scale, dk[kb][dt][4 * qd + 3] * p.scale});
+          *(bf16x4*)(sV2 + off) = f4_to_bf4(f32x4{dv[kb][dt][4 * qd], dv[kb][dt][4 * qd + 1], dv[kb][dt][4 * qd + 2], dv[kb][dt][4 * qd + 3]});
+        }
+    }
+    __syncthreads();
+    const int pc = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 64 * i + (tid >> 3);
+      if (row >= Stot) continue;
+      const int lc = pc ^ swz_key(row);
+      bf16 *okp, *ovp;
+      if (row < p.Lp) {
+        okp = (bf16*)pb.dpk + ((long long)b * p.Lp + row) * pb.lddp + h * 64;
+        ovp = (bf16*)pb.dpv + ((long long)b * p.Lp + row) * pb.lddp + h * 64;
+      } else {
+        okp = (bf16*)pb.dk + ((long long)b * p.Sk + (row - p.Lp)) * pb.lddk + h * 64;
+        ovp = (bf16*)pb.dv + ((long long)b * p.Sk + (row - p.Lp)) * pb.lddv + h * 64;
+      }
+      *(bf16x8*)(okp + lc * 8) = *(const bf16x8*)(sK + row * 128 + pc * 16);
+      *(bf16x8*)(ovp + lc * 8) = *(const bf16x8*)(sV2 + row * 128 + pc * 16);
+    }
+    return;
+  }
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     const int kj = wave * 64 + kb * 32 + l31;
