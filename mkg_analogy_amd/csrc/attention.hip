@@ -1210,26 +1210,30 @@ __global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd
     glds16_raw((const bf16*)p.q + rq * p.ldq + h * 64 + lc * 8, sQ + doff);
     glds16_raw((const bf16*)pb.dctx + rq * pb.lddctx + h * 64 + lc * 8, sG + doff);
   }
-  {                                                       // row statistics: two threads per query row (32 head dims each)
-    const int q = tid >> 1, half = tid & 1;
-    float l = 1.0e30f, dsum = 0.f;                        // rows past Sq: p = exp2(x - 1e30) = 0
-    const long long li = ((long long)b * p.nh + h) * p.Sq + q;
-    if (q < p.Sq) {
-      l = p.lse[li];
-      const bf16* op = (const bf16*)p.ctx + ((long long)b * p.Sq + q) * p.ldctx + h * 64 + half * 32;
-      const bf16* gp = (const bf16*)pb.dctx + ((long long)b * p.Sq + q) * pb.lddctx + h * 64 + half * 32;
+  {                                                       // row statistics: eight lanes per query row (whole 128-byte row segments per load instruction)
+    const int pc = tid & 7;
+    bf16x8 ov[4], gv[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const bf16x8 o = *(const bf16x8*)(op + c * 8), g = *(const bf16x8*)(gp + c * 8);
+    for (int i = 0; i < 4; ++i) {                         // rows past Sq: clamped, discarded below
+      const long long r = (long long)b * p.Sq + min(16 * i + rowh, p.Sq - 1);
+      ov[i] = *(const bf16x8*)((const bf16*)p.ctx + r * p.ldctx + h * 64 + pc * 8);
+      gv[i] = *(const bf16x8*)((const bf16*)pb.dctx + r * pb.lddctx + h * 64 + pc * 8);
+    }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += (float)o[e] * (float)g[e];
+    for (int i = 0; i < 4; ++i) {
+      const int q = 16 * i + rowh;
+      float dsum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += (float)ov[i][e] * (float)gv[i][e];
+      dsum += dpp_f32<0xB1>(dsum);
+      dsum += dpp_f32<0x4E>(dsum);
+      dsum += dpp_f32<0x141>(dsum);
+      if (pc == 0) {
+        sDel[q] = q < p.Sq ? dsum : 0.f;
+        if (q < p.Sq) pb.delta[((long long)b * p.nh + h) * p.Sq + q] = dsum;
       }
     }
-    dsum += __builtin_bit_cast(float, pair_swap(__builtin_bit_cast(uint32_t, dsum)));
-    if (half == 0) {
-      if (q < p.Sq) pb.delta[li] = dsum;
-      sLse[q] = l; sDel[q] = dsum;
-    }
+    if (tid < 64) sLse[tid] = tid < p.Sq ? p.lse[((long long)b * p.nh + h) * p.Sq + tid] : 1.0e30f;   // rows past Sq: p = exp2(x - 1e30) = 0
   }
   // own keys
   const int kj = wave * 32 + l31;

@@ -22,6 +22,18 @@ inline int row_grid(int M) {
   return g > 4096 ? 4096 : (g < 1 ? 1 : g);
 }
 
+// Dropout decisions of the four consecutive elements o .. o+3 (o % 4 == 0: H is a multiple of 256) as keep factors: TWO pair hashes and no
+// seed fold per element (common.h dropout_keep costs two mix32 per element; the text-stream LayerNorm kernels spent more VALU time on it than on
+// the normalisation).  Identical decisions: elements 2j, 2j+1 take the low / high 16 bits of rng_pair(s2, pair j); s2 folds the upper pair bits,
+// which are 0 for every tensor below 2^33 elements (s2_lo = rng_seedmix(seed, 0), computed once per kernel).
+__device__ __forceinline__ f32x4 dropout_scale4(uint64_t seed, uint32_t s2_lo, long long o, uint32_t thr, float inv_keep) {
+  const uint64_t pair = (uint64_t)o >> 1;
+  const uint32_t hi = (uint32_t)(pair >> 32);
+  const uint32_t s2 = hi == 0 ? s2_lo : rng_seedmix(seed, hi);
+  const uint32_t h0 = rng_pair(s2, (uint32_t)pair), h1 = rng_pair(s2, (uint32_t)pair + 1u);
+  return f32x4{(h0 & 0xffffu) >= thr ? inv_keep : 0.f, (h0 >> 16) >= thr ? inv_keep : 0.f, (h1 & 0xffffu) >= thr ? inv_keep : 0.f, (h1 >> 16) >= thr ? inv_keep : 0.f};
+}
+
 // ------------------------------------------------------------------ LayerNorm forward
 template <int VMAX>
 __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
@@ -30,6 +42,7 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
   const int nwaves = gridDim.x * WPB;
   const int nv = p.H / 256;                       // float4 per lane (H multiple of 256), nv <= VMAX
   const float inv_keep = 1.f / (1.f - p.p_drop);
+  const uint32_t s2_lo = rng_seedmix(p.seed, 0), thr16 = dropout_thr16(p.p_drop);
   const bf16* yb = (const bf16*)p.y_bf16;
   for (int m = wave_g; m < p.M; m += nwaves) {
     f32x4 x[VMAX];
@@ -44,16 +57,14 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
         if (yb) {
           f32x4 y = bf4_to_f4(ldx((const bf16x4*)(yb + o), (LN_NT & 1) != 0));
           if (p.p_drop > 0.f) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? y[e] * inv_keep : 0.f;
+            y = y * dropout_scale4(p.seed, s2_lo, o, thr16, inv_keep);
           }
           t += y;
         }
         if (p.y_f32) {
           f32x4 y = ldx((const f32x4*)(p.y_f32 + o), (LN_NT & 1) != 0);
           if (p.p_drop > 0.f) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? y[e] * inv_keep : 0.f;
+            y = y * dropout_scale4(p.seed, s2_lo, o, thr16, inv_keep);
           }
           t += y;
         }
@@ -151,6 +162,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
   const int nwaves = gridDim.x * WPB;
   const int nv = p.H / 256;
   const float inv_keep = 1.f / (1.f - p.p_drop);
+  const uint32_t s2_lo = rng_seedmix(p.seed, 0), thr16 = dropout_thr16(p.p_drop);
   const bf16* dyb = (const bf16*)p.dy_bf16;
   f32x4 dg[VMAX], db[VMAX], gam[VMAX];
 #pragma unroll
@@ -204,10 +216,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
         for (int e = 0; e < 4; ++e) ds[e] = rstd * (dy[v][e] * gam[v][e] - c1 - xh[v][e] * c2);
         if (p.ds_bf16 && !p.bf16_total) {
           f32x4 dd = ds;
-          if (p.p_drop > 0.f) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dd[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? dd[e] * inv_keep : 0.f;
-          }
+          if (p.p_drop > 0.f) dd = dd * dropout_scale4(p.seed, s2_lo, o, thr16, inv_keep);
           stx((bf16x4*)((bf16*)p.ds_bf16 + o), f4_to_bf4(dd), (LN_NT & 4) != 0);
         }
         if (p.add_f32) ds += r.add[v];
@@ -403,10 +412,8 @@ __global__ __launch_bounds__(TPB) void text_embed_k(mart_text_embed_desc p) {
         const long long o = (long long)m * p.H + c;
         f32x4 g = *(const f32x4*)(p.gamma + c), b = *(const f32x4*)(p.beta + c), y;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          y[e] = (x[v][e] - mean) * rstd * g[e] + b[e];
-          if (p.p_drop > 0.f) y[e] = dropout_keep(p.seed, (uint64_t)(o + e), p.p_drop) ? y[e] * inv_keep : 0.f;
-        }
+        for (int e = 0; e < 4; ++e) y[e] = (x[v][e] - mean) * rstd * g[e] + b[e];
+        if (p.p_drop > 0.f) y = y * dropout_scale4(p.seed, rng_seedmix(p.seed, 0), o, dropout_thr16(p.p_drop), inv_keep);
         if (p.out_f32) stx((f32x4*)(p.out_f32 + o), y, (LN_NT & 2) != 0);
         if (p.out_bf16) stx((bf16x4*)((bf16*)p.out_bf16 + o), f4_to_bf4(y), (LN_NT & 4) != 0);
       }
