@@ -1180,33 +1180,44 @@ int check_fwd(const mart_attn_fwd_desc* d) {
 //     d(w0) / d(w1)) exactly as in the two-pass kernels, dV += dO^T Pd, dK += Q^T dS; dS goes transposed-ready into a fourth tile [key][q]
 //   * after the second barrier wave w OWNS queries [32w, 32w + 32): dQ^T = K^T dS^T over all 64 keys, both operands by transposed LDS reads
 // No atomics, no cross-wave reduction: results are independent of scheduling.
-constexpr int T64_LDS = 3 * TILE_BYTES + 512;
+// NB = number of 32-row blocks (= waves): 2 covers the fine-tune shape (L = 64), 4 the pre-train shape (L = 96) up to 128 x 128.
+//   R = 32 NB rows per tile; dS is stored as R / 64 sub-tiles [R keys][64 queries] so that every tile keeps the 128-byte row of the fragment
+//   readers; the K tile lands over rows [0, R/2) of the Q and the dO tile once the first NB / 2 query blocks are through.
+template <int NB> struct T64 {
+  static constexpr int R = 32 * NB, NT = 64 * NB;
+  static constexpr int TILE = R * 128;                    // one [R][64] bf16 tile
+  static constexpr int DS = ((R + 63) / 64) * TILE;       // the dS sub-tiles
+  static constexpr int LDS = 2 * TILE + DS + 2 * R * 4;   // Q, dO, dS, lse / delta
+  static constexpr int TK = (R / 2 + 31) / 32 - 1;        // query block after which rows [0, R/2) of the Q / dO tiles are dead
+};
 // swap a value between lanes 2m and 2m + 1 (DPP quad_perm [1,0,3,2]: a full-rate VALU move, no LDS)
 __device__ __forceinline__ uint32_t pair_swap(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
-#ifndef T64_MINW
-#define T64_MINW 3
-#endif
-template <bool DROP>
-__global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd_desc pb) {
-  __shared__ __attribute__((aligned(16))) char smem[T64_LDS];
+template <bool DROP, int NB>
+__global__ __launch_bounds__(64 * NB, NB == 2 ? 3 : 2) void attn_bwd_text64_k(mart_attn_bwd_desc pb) {
+  using G = T64<NB>;
+  constexpr int R = G::R;
+  __shared__ __attribute__((aligned(16))) char smem[G::LDS];
   const mart_attn_fwd_desc& p = pb.f;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.x, b = blockIdx.y;
-  const int Stot = p.Sk;                                  // host: no prefix, Sq <= 64, Sk <= 64
+  const int Stot = p.Sk;                                  // host: no prefix, Sq <= R, Sk <= R
   const TextCtl ctl = make_ctl(p, b, p.Sk);
   const LaneOffs lo = make_offs(lane);
   char* sQ = smem;
-  char* sG = smem + TILE_BYTES;
-  char* sD = smem + 2 * TILE_BYTES;
-  float* sLse = (float*)(smem + 3 * TILE_BYTES);
-  float* sDel = sLse + 64;
+  char* sG = smem + G::TILE;
+  char* sD = smem + 2 * G::TILE;
+  float* sLse = (float*)(smem + 2 * G::TILE + G::DS);
+  float* sDel = sLse + R;
 
-  const int rowh = tid >> 3, lc = (tid & 7) ^ swz_key(rowh);             // staging: 16 rows per DMA instruction of the workgroup; the key repeats every 16 rows
+  // staging: one DMA instruction of the workgroup covers 8 NB rows (eight lanes per 128-byte row); the swizzle key repeats every 16 rows
+  constexpr int RPI = 8 * NB;
+  const int rowh = tid >> 3;
+  auto lc_of = [&](int i) { return (tid & 7) ^ swz_key(RPI * i + rowh); };   // logical chunk held by this lane's physical chunk (NB = 3: 24 rows per instruction)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {                           // Q, dO tiles (rows past the end: clamped copies)
-    const long long rq = (long long)b * p.Sq + min(16 * i + rowh, p.Sq - 1);
-    const int doff = (i * 128 + wave * 64) * 16;
+    const long long rq = (long long)b * p.Sq + min(RPI * i + rowh, p.Sq - 1);
+    const int doff = (i * G::NT + wave * 64) * 16, lc = lc_of(i);
     glds16_raw((const bf16*)p.q + rq * p.ldq + h * 64 + lc * 8, sQ + doff);
     glds16_raw((const bf16*)pb.dctx + rq * pb.lddctx + h * 64 + lc * 8, sG + doff);
   }
@@ -1215,13 +1226,13 @@ __global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd
     bf16x8 ov[4], gv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                         // rows past Sq: clamped, discarded below
-      const long long r = (long long)b * p.Sq + min(16 * i + rowh, p.Sq - 1);
+      const long long r = (long long)b * p.Sq + min(RPI * i + rowh, p.Sq - 1);
       ov[i] = *(const bf16x8*)((const bf16*)p.ctx + r * p.ldctx + h * 64 + pc * 8);
       gv[i] = *(const bf16x8*)((const bf16*)pb.dctx + r * pb.lddctx + h * 64 + pc * 8);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int q = 16 * i + rowh;
+      const int q = RPI * i + rowh;
       float dsum = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) dsum += (float)ov[i][e] * (float)gv[i][e];
@@ -1233,12 +1244,12 @@ __global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd
         if (q < p.Sq) pb.delta[((long long)b * p.nh + h) * p.Sq + q] = dsum;
       }
     }
-    if (tid < 64) sLse[tid] = tid < p.Sq ? p.lse[((long long)b * p.nh + h) * p.Sq + tid] : 1.0e30f;   // rows past Sq: p = exp2(x - 1e30) = 0
+    if (tid < R) sLse[tid] = tid < p.Sq ? p.lse[((long long)b * p.nh + h) * p.Sq + tid] : 1.0e30f;   // rows past Sq: p = exp2(x - 1e30) = 0
   }
   // own keys
   const int kj = wave * 32 + l31;
   const bool kvalid = kj < Stot;
-  // K / V fragments of the own keys: loaded for each query half (the second time from L1 / L2) instead of held across the softmax arithmetic --
+  // K / V fragments of the own keys: loaded for each query block (after the first time from L1 / L2) instead of held across the softmax arithmetic --
   // 32 VGPRs that decide between two and three waves per SIMD
   bf16x8 kf[4], vf[4];
   const bf16* kp = (const bf16*)p.k + ((long long)b * p.Sk + min(kj, p.Sk - 1)) * p.ldk + h * 64 + hh * 8;
@@ -1268,95 +1279,100 @@ __global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd
   const int dkey = swz_key(kj);
   char* drow = sD + kj * 128 + 8 * hh;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (t * 32 >= p.Sq) continue;                          // wave-uniform: no query in this half (its dS columns are never read)
-    f32x16 st, dp;
+  for (int t = 0; t < NB; ++t) {
+    if (t * 32 < p.Sq) {                                   // wave-uniform: a block without queries is skipped (its dS columns are never read)
+      f32x16 st, dp;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      st = mfma32(tile_frag(sQ, t, ks, lo), kf[ks], st);
-      dp = mfma32(tile_frag(sG, t, ks, lo), vf[ks], dp);
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      float pd8[8], ds8[8], l8[8], d8[8];
-      {
-        const f32x4 la = *(const f32x4*)(sLse + t * 32 + 16 * a + 4 * hh), lb = *(const f32x4*)(sLse + t * 32 + 16 * a + 8 + 4 * hh);
-        const f32x4 da = *(const f32x4*)(sDel + t * 32 + 16 * a + 4 * hh), db = *(const f32x4*)(sDel + t * 32 + 16 * a + 8 + 4 * hh);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { l8[e] = la[e]; l8[4 + e] = lb[e]; d8[e] = da[e]; d8[4 + e] = db[e]; }
+      for (int ks = 0; ks < 4; ++ks) {
+        st = mfma32(tile_frag(sQ, t, ks, lo), kf[ks], st);
+        dp = mfma32(tile_frag(sG, t, ks, lo), vf[ks], dp);
       }
-      float keep8[8];
-      if (DROP) {
-        const int g0 = t * 32 + 16 * a;                    // first query row of the group (rows g0 + 4hh + {0..3, 8..11})
-        uint32_t hv[8];
-        if (shared) {
-          uint32_t mine[4], other[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) mine[j] = rng_pair(ctl.s2, (ib_pair + (uint32_t)(g0 + j) * (uint32_t)Stot) >> 1);
+      for (int a = 0; a < 2; ++a) {
+        float pd8[8], ds8[8], l8[8], d8[8];
+        {
+          const f32x4 la = *(const f32x4*)(sLse + t * 32 + 16 * a + 4 * hh), lb = *(const f32x4*)(sLse + t * 32 + 16 * a + 8 + 4 * hh);
+          const f32x4 da = *(const f32x4*)(sDel + t * 32 + 16 * a + 4 * hh), db = *(const f32x4*)(sDel + t * 32 + 16 * a + 8 + 4 * hh);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) other[j] = pair_swap(mine[j]);
+          for (int e = 0; e < 4; ++e) { l8[e] = la[e]; l8[4 + e] = lb[e]; d8[e] = da[e]; d8[4 + e] = db[e]; }
+        }
+        float keep8[8];
+        if (DROP) {
+          const int g0 = t * 32 + 16 * a;                  // first query row of the group (rows g0 + 4hh + {0..3, 8..11})
+          uint32_t hv[8];
+          if (shared) {
+            uint32_t mine[4], other[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { hv[j] = odd ? other[j] : mine[j]; hv[4 + j] = odd ? mine[j] : other[j]; }
-        } else {
+            for (int j = 0; j < 4; ++j) mine[j] = rng_pair(ctl.s2, (ib_pair + (uint32_t)(g0 + j) * (uint32_t)Stot) >> 1);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) hv[i] = rng_pair(ctl.s2, (ib_own + (uint32_t)(g0 + (i & 3) + 8 * (i >> 2)) * (uint32_t)Stot) >> 1);
+            for (int j = 0; j < 4; ++j) other[j] = pair_swap(mine[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hv[j] = odd ? other[j] : mine[j]; hv[4 + j] = odd ? mine[j] : other[j]; }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hv[i] = rng_pair(ctl.s2, (ib_own + (uint32_t)(g0 + (i & 3) + 8 * (i >> 2)) * (uint32_t)Stot) >> 1);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const uint32_t idx_par = shared ? 0u : ((ib_own + (uint32_t)(g0 + (i & 3) + 8 * (i >> 2)) * (uint32_t)Stot) & 1u) * 16u;
+            const uint32_t u = (hv[i] >> (shared ? hsh : idx_par)) & 0xffffu;
+            keep8[i] = u >= ctl.thr ? ctl.inv_keep : 0.f;
+          }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const uint32_t idx_par = shared ? 0u : ((ib_own + (uint32_t)(g0 + (i & 3) + 8 * (i >> 2)) * (uint32_t)Stot) & 1u) * 16u;
-          const uint32_t u = (hv[i] >> (shared ? hsh : idx_par)) & 0xffffu;
-          keep8[i] = u >= ctl.thr ? ctl.inv_keep : 0.f;
+          const int r = 8 * a + i;
+          const int qi = t * 32 + mfma_row(r, hh);
+          const float spre = st[r] * p.scale;
+          const bool qhi = qi >= sep;
+          const bool qlo = !qhi && !(ctl.skip0 && qi == 0);
+          const float fq = qhi ? ctl.c1 : (qlo ? ctl.c0 : 1.f);
+          const float f = rw ? fq : 1.f;
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(spre * f, LOG2E, madd2 - l8[i]));
+          const float dpd = DROP ? dp[r] * keep8[i] : dp[r];
+          const float ds = pr * (dpd - d8[i]);             // d/d(post-reweight, pre-mask score)
+          const float tw = ds * (spre * rwf);
+          dc1 = __builtin_fmaf(tw, qhi ? 1.f : 0.f, dc1);
+          dc0 = __builtin_fmaf(tw, qlo ? 1.f : 0.f, dc0);
+          pd8[i] = DROP ? pr * keep8[i] : pr;
+          ds8[i] = ds * f;
+        }
+        const bf16x8 pf = pack8(pd8);
+        const bf16x8 df = pack8(ds8);
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        const u32x4_t dw4 = __builtin_bit_cast(u32x4_t, df);
+        // dS sub-tile t/2, [key][64 q]: elements 0-3 are queries 16a + 4hh + 0..3 of the block (16-byte chunk 4(t&1) + 2a), elements 4-7 the same
+        // rows of the next chunk
+        char* dsub = drow + (t >> 1) * G::TILE;
+        *(u32x2_t*)(dsub + (((4 * (t & 1) + 2 * a) ^ dkey) << 4)) = u32x2_t{dw4[0], dw4[1]};
+        *(u32x2_t*)(dsub + (((4 * (t & 1) + 2 * a + 1) ^ dkey) << 4)) = u32x2_t{dw4[2], dw4[3]};
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = mfma32(tile_frag_tr(sG, t * 32 + 16 * a, dt, lo), pf, dv[dt]);
+          dk[dt] = mfma32(tile_frag_tr(sQ, t * 32 + 16 * a, dt, lo), df, dk[dt]);
         }
       }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = 8 * a + i;
-        const int qi = t * 32 + mfma_row(r, hh);
-        const float spre = st[r] * p.scale;
-        const bool qhi = qi >= sep;
-        const bool qlo = !qhi && !(ctl.skip0 && qi == 0);
-        const float fq = qhi ? ctl.c1 : (qlo ? ctl.c0 : 1.f);
-        const float f = rw ? fq : 1.f;
-        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(spre * f, LOG2E, madd2 - l8[i]));
-        const float dpd = DROP ? dp[r] * keep8[i] : dp[r];
-        const float ds = pr * (dpd - d8[i]);               // d/d(post-reweight, pre-mask score)
-        const float tw = ds * (spre * rwf);
-        dc1 = __builtin_fmaf(tw, qhi ? 1.f : 0.f, dc1);
-        dc0 = __builtin_fmaf(tw, qlo ? 1.f : 0.f, dc0);
-        pd8[i] = DROP ? pr * keep8[i] : pr;
-        ds8[i] = ds * f;
-      }
-      const bf16x8 pf = pack8(pd8);
-      const bf16x8 df = pack8(ds8);
-      typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-      typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-      const u32x4_t dw4 = __builtin_bit_cast(u32x4_t, df);
-      // dS tile [key][q]: elements 0-3 are queries t*32 + 16a + 4hh + 0..3 (16-byte chunk 4t + 2a), elements 4-7 the same rows of chunk 4t + 2a + 1
-      *(u32x2_t*)(drow + (((4 * t + 2 * a) ^ dkey) << 4)) = u32x2_t{dw4[0], dw4[1]};
-      *(u32x2_t*)(drow + (((4 * t + 2 * a + 1) ^ dkey) << 4)) = u32x2_t{dw4[2], dw4[3]};
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        dv[dt] = mfma32(tile_frag_tr(sG, t * 32 + 16 * a, dt, lo), pf, dv[dt]);
-        dk[dt] = mfma32(tile_frag_tr(sQ, t * 32 + 16 * a, dt, lo), df, dk[dt]);
-      }
     }
-    if (t == 0) {
-      // rows 0..31 of the Q and dO tiles are dead once BOTH waves are through the first query half: the K tile of the dQ contraction lands there
-      // (keys 0..31 over Q, 32..63 over dO) while the second half computes -- three tiles of LDS instead of four: six workgroups per CU
+    if (t + 1 < NB) {                                      // K / V fragments for the next query block
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const volatile bf16x8*)(kp + ks * 16); vf[ks] = *(const volatile bf16x8*)(vp + ks * 16); }
+    }
+    if (t == G::TK) {
+      // rows [0, R/2) of the Q and dO tiles are dead once EVERY wave is through the first NB / 2 query blocks: the K tile of the dQ contraction lands
+      // there (keys [0, R/2) over Q, [R/2, R) over dO) while the other blocks compute -- no fourth tile in LDS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __syncthreads();
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const volatile bf16x8*)(kp + ks * 16); vf[ks] = *(const volatile bf16x8*)(vp + ks * 16); }
-#pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const long long rk = (long long)b * p.Sk + min(16 * i + rowh, p.Sk - 1);
-        glds16_raw((const bf16*)p.k + rk * p.ldk + h * 64 + lc * 8, (i < 2 ? sQ : sG) + ((i & 1) * 128 + wave * 64) * 16);
+        const long long rk = (long long)b * p.Sk + min(RPI * i + rowh, p.Sk - 1);        // K row R/2 + r sits in LDS row r of the dO tile: R/2 is a multiple of 16, same key
+        glds16_raw((const bf16*)p.k + rk * p.ldk + h * 64 + lc_of(i) * 8, (i < 2 ? sQ : sG) + ((i & 1) * G::NT + wave * 64) * 16);
       }
     }
   }
-  // ---- d(w0), d(w1): one private slot per wave (slots 2, 3 of the head are the idle waves of the two-pass layout: zero)
+  // ---- d(w0), d(w1): one private slot per wave (four slots per head as in the two-pass layout; with two waves slots 2, 3 are zero)
   if (pb.dw) {
     const bool on = ctl.sep >= 0;
     dc0 = wave_sum(dc0); dc1 = wave_sum(dc1);
@@ -1364,7 +1380,8 @@ __global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd
       if (pb.dw_ws) {
         const long long slot = ((long long)b * p.nh + h) * 4 + wave;
         pb.dw_ws[2 * slot] = on ? dc0 : 0.f; pb.dw_ws[2 * slot + 1] = on ? dc1 : 0.f;
-        pb.dw_ws[2 * (slot + 2)] = 0.f; pb.dw_ws[2 * (slot + 2) + 1] = 0.f;
+        if (NB == 2) { pb.dw_ws[2 * (slot + 2)] = 0.f; pb.dw_ws[2 * (slot + 2) + 1] = 0.f; }
+        if (NB == 3 && wave == 0) { pb.dw_ws[2 * (slot + 3)] = 0.f; pb.dw_ws[2 * (slot + 3) + 1] = 0.f; }
       } else if (on) {
         const float w0 = p.w0[0], w1 = p.w1[0];
         if (w0 >= 0.f && w0 <= 0.5f) atomicAdd(pb.dw + 0, dc0);     // clamp sub-gradient: passes inside and AT the bounds
@@ -1372,7 +1389,7 @@ __global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd
       }
     }
   }
-  tile_barrier();                                          // dS tile complete (LDS writes of both waves), K tile landed
+  tile_barrier();                                          // dS tiles complete (LDS writes of every wave), K tile landed
 
   // ---- dQ^T[d][q] = sum over keys K^T[d][key] dS^T[key][q] for the wave's 32 queries
   const bool qwave = wave * 32 < p.Sq;                     // wave-uniform
@@ -1380,22 +1397,23 @@ __global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd
   if (qwave) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
-    const int tq1 = wave ? lo.tr1[1] : lo.tr1[0], tq2 = wave ? lo.tr2[1] : lo.tr2[0];   // (a run-time index into the offset arrays would put them in scratch)
+    const int tq1 = (wave & 1) ? lo.tr1[1] : lo.tr1[0], tq2 = (wave & 1) ? lo.tr2[1] : lo.tr2[0];   // (a run-time index into the offset arrays would put them in scratch)
+    const char* dsub = sD + (wave >> 1) * G::TILE;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8 df = join_tr(lds_tr_read(sD + 16 * kk * 128 + tq1), lds_tr_read(sD + 16 * kk * 128 + tq2));
+    for (int kk = 0; kk < 2 * NB; ++kk) {
+      const bf16x8 df = join_tr(lds_tr_read(dsub + 16 * kk * 128 + tq1), lds_tr_read(dsub + 16 * kk * 128 + tq2));
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tile_frag_tr(kk < 2 ? sQ : sG, 16 * (kk & 1), dt, lo), df, dq[dt]);
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(tile_frag_tr(kk < NB ? sQ : sG, 16 * (kk % NB), dt, lo), df, dq[dt]);
     }
   }
   // ---- results leave through LDS.  A result tile has "lane = row, registers = 4 consecutive head dims": stored from registers a wave instruction
   // writes 8 bytes into each of 32 rows that lie 2 * ld bytes apart -- 32 partial cache lines per instruction, 24 such instructions per wave (the
   // stores were 21 of the kernel's 57 us).  Staged [row][64 dims] in the tiles that are dead by now, eight lanes write one 128-byte row segment.
-  //   dQ: bf16 tile over the dS tile;  dK, then dV: f32 tiles over the Q | dO tiles (f32 so that the optional accumulation into the destination
+  //   dQ: bf16 tile over the dS tiles;  dK, then dV: f32 tiles over the Q | dO tiles (f32 so that the optional accumulation into the destination
   //   rounds once, exactly as the two-pass kernels do)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();                                         // every LDS read of the dQ contraction is done
-  char* sF = smem;                                         // 64 rows x 256 bytes
+  char* sF = smem;                                         // R rows x 256 bytes
   const int fkey = (kj & 15);
   auto stage_f32 = [&](const f32x16* acc2, float mul) {
 #pragma unroll
@@ -1407,12 +1425,12 @@ __global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd
             f32x4{acc2[dt][4 * qd] * mul, acc2[dt][4 * qd + 1] * mul, acc2[dt][4 * qd + 2] * mul, acc2[dt][4 * qd + 3] * mul};
       }
   };
-  auto copy_f32 = [&](void* dst, int ld) {                 // thread: rows 16i + rowh, dims 8g .. 8g+7 (g = tid & 7)
+  auto copy_f32 = [&](void* dst, int ld) {                 // thread: rows RPI i + rowh, dims 8g .. 8g+7 (g = tid & 7)
     const int g = tid & 7;
     const bool acc = pb.accum_dkv != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = 16 * i + rowh;
+      const int row = RPI * i + rowh;
       if (row >= p.Sk) continue;
       f32x4 a = *(const f32x4*)(sF + row * 256 + (((2 * g) ^ (row & 15)) << 4));
       f32x4 c = *(const f32x4*)(sF + row * 256 + (((2 * g + 1) ^ (row & 15)) << 4));
@@ -1439,9 +1457,9 @@ __global__ __launch_bounds__(128, T64_MINW) void attn_bwd_text64_k(mart_attn_bwd
   stage_f32(dk, p.scale);
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {                            // dQ: physical chunk pc of row 16i + rowh holds the logical chunk lc (same map as the staging DMA)
-    const int row = 16 * i + rowh;
-    if (row < p.Sq) *(bf16x8*)((bf16*)pb.dq + ((long long)b * p.Sq + row) * pb.lddq + h * 64 + lc * 8) = *(const bf16x8*)(sD + row * 128 + (tid & 7) * 16);
+  for (int i = 0; i < 4; ++i) {                            // dQ: physical chunk pc of row RPI i + rowh holds the logical chunk lc (same map as the staging DMA)
+    const int row = RPI * i + rowh;
+    if (row < p.Sq) *(bf16x8*)((bf16*)pb.dq + ((long long)b * p.Sq + row) * pb.lddq + h * 64 + lc_of(i) * 8) = *(const bf16x8*)(sD + row * 128 + (tid & 7) * 16);
   }
   copy_f32(pb.dk, pb.lddk);
   __syncthreads();
@@ -1500,9 +1518,12 @@ extern "C" int mart_attn_bwd(const mart_attn_bwd_desc* d, void* stream) {
   }
   static const int text_fused = getenv("MART_ATTN_TEXT_FUSED") ? atoi(getenv("MART_ATTN_TEXT_FUSED")) : 1;
   const bool al16 = d->lddq % 8 == 0 && d->lddk % 8 == 0 && d->lddv % 8 == 0 && (((uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 15) == 0;
-  if (text && text_fused && al16 && f.Lp == 0 && f.Sq <= 64 && f.Sk <= 64) {            // one 64 x 64 score tile per head: one pass, one 2-wave workgroup per head
-    if (f.p_drop > 0.f) hipLaunchKernelGGL(attn_bwd_text64_k<true>, dim3(f.nh, f.B), dim3(128), 0, st, *d);
-    else hipLaunchKernelGGL(attn_bwd_text64_k<false>, dim3(f.nh, f.B), dim3(128), 0, st, *d);
+  if (text && text_fused && al16 && f.Lp == 0 && f.Sq <= 128 && f.Sk <= 128) {          // the whole score matrix of a head in one workgroup: one pass
+    const int mx = f.Sq > f.Sk ? f.Sq : f.Sk;                                             // 2 waves (64 x 64), 3 (96 x 96) or 4 (128 x 128)
+    const bool drop = f.p_drop > 0.f;
+    if (mx > 96) { if (drop) hipLaunchKernelGGL((attn_bwd_text64_k<true, 4>), dim3(f.nh, f.B), dim3(256), 0, st, *d); else hipLaunchKernelGGL((attn_bwd_text64_k<false, 4>), dim3(f.nh, f.B), dim3(256), 0, st, *d); }
+    else if (mx > 64) { if (drop) hipLaunchKernelGGL((attn_bwd_text64_k<true, 3>), dim3(f.nh, f.B), dim3(192), 0, st, *d); else hipLaunchKernelGGL((attn_bwd_text64_k<false, 3>), dim3(f.nh, f.B), dim3(192), 0, st, *d); }
+    else { if (drop) hipLaunchKernelGGL((attn_bwd_text64_k<true, 2>), dim3(f.nh, f.B), dim3(128), 0, st, *d); else hipLaunchKernelGGL((attn_bwd_text64_k<false, 2>), dim3(f.nh, f.B), dim3(128), 0, st, *d); }
     MART_LAUNCH_CHECK();
     if (d->dw && d->dw_ws && f.sep) {
       hipLaunchKernelGGL(attn_dw_reduce_k, dim3(1), dim3(1024), 0, st, d->dw_ws, (long long)f.B * f.nh * 4, f.w0, f.w1, d->dw);

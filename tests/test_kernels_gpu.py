@@ -399,7 +399,7 @@ def test_attention_rescale_branch(ops):
     close(dqkv[:, 2 * H:], vr.grad, 2e-2 * max(float(vr.grad.abs().max()), 1), 3e-2, "dv (spiked)")
 
 
-@pytest.mark.parametrize("B,nh,L,p", [(3, 12, 64, 0.0), (2, 12, 64, 0.1), (2, 4, 24, 0.0), (2, 2, 96, 0.1), (2, 4, 23, 0.1), (2, 3, 40, 0.1)])
+@pytest.mark.parametrize("B,nh,L,p", [(3, 12, 64, 0.0), (2, 12, 64, 0.1), (2, 4, 24, 0.0), (2, 2, 96, 0.1), (2, 4, 23, 0.1), (2, 3, 40, 0.1), (2, 2, 128, 0.1), (2, 3, 101, 0.1), (1, 2, 80, 0.0), (2, 2, 160, 0.1)])
 def test_attention_text(ops, B, nh, L, p):
     H = nh * 64
     seed = 99

@@ -5,7 +5,7 @@ import torch
 from mkg_analogy_amd import ops
 from tools.bench_kernels import timeit
 ops.require_gpu()
-B, L, nh, H = 256, 64, 12, 768
+B, L, nh, H = 256, int(os.environ.get("L", 64)), 12, 768
 BF = torch.bfloat16
 qkv = torch.randn(B * L, 3 * H, device="cuda").to(BF)
 dctx = torch.randn(B * L, H, device="cuda").to(BF)
@@ -13,7 +13,7 @@ ctx = torch.empty(B * L, H, device="cuda", dtype=BF)
 lse = torch.empty(B, nh, L, device="cuda")
 delta = torch.empty(B, nh, L, device="cuda")
 dqkv = torch.empty(B * L, 3 * H, device="cuda", dtype=BF)
-am = torch.ones(B, L, device="cuda", dtype=torch.int64); am[:, 50:] = 0
+am = torch.ones(B, L, device="cuda", dtype=torch.int64); am[:, L - 14:] = 0
 sep = torch.full((B, 6), 20, device="cuda", dtype=torch.int64)
 w0, w1 = torch.tensor([0.25], device="cuda"), torch.tensor([0.5], device="cuda")
 dw = torch.zeros(2, device="cuda")

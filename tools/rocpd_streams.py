@@ -44,3 +44,17 @@ for n, s, e, q in sel:
     if s < step_end and ("copyBuffer" in n or "fillBuffer" in n or "at6native" in n or "at_native" in n):
         print(f"    q{q} t={(s - lo) / 1e6:8.3f} +{(e - s) / 1e3:6.1f} us {n[:70]}   after {short(prev.get(q, ''))}")
     prev[q] = n
+# the GPU as a whole: union of the kernel intervals of all queues over the two-step window (time in which NO kernel runs = launch / dependency bubbles)
+iv = sorted((s, e) for n, s, e, q in sel)
+busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+idle = []
+for s, e in iv[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s
+        idle.append(((s - cur_e) / 1e3, (cur_e - lo) / 1e6))
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+print(f"--- all queues: some kernel running {busy / 1e6:.2f} ms of the {(hi - lo) / 1e6:.2f} ms window; {len(idle)} idle intervals, {sum(i[0] for i in idle) / 1e3:.2f} ms in total; "
+      f"longest: " + ", ".join(f"{i[0]:.0f} us at t={i[1]:.2f}" for i in sorted(idle, key=lambda i: -i[0])[:8]))
