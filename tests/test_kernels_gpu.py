@@ -327,7 +327,7 @@ def _heads(x, B, S, nh):          # [B*S, nh*64] -> [B,nh,S,64]
     return x.view(B, S, nh, 64).permute(0, 2, 1, 3)
 
 
-@pytest.mark.parametrize("B,nh,S,Lp", [(2, 12, 99, 0), (2, 12, 393, 64), (3, 4, 130, 24), (1, 2, 64, 0), (2, 3, 300, 0), (1, 2, 257, 64)])
+@pytest.mark.parametrize("B,nh,S,Lp", [(2, 12, 99, 0), (2, 12, 393, 64), (3, 4, 130, 24), (1, 2, 64, 0), (2, 3, 300, 0), (1, 2, 257, 64), (3, 12, 100, 0), (2, 2, 128, 0), (2, 2, 33, 0)])
 def test_attention_vision(ops, B, nh, S, Lp):
     H = nh * 64
     qkv = rnd(B * S, 3 * H, seed=1, scale=1.0)

@@ -10,7 +10,7 @@ ops.require_gpu()
 DEV, BF = "cuda", torch.bfloat16
 B = int(os.environ.get("B", 256))
 print("B =", B)
-for (S, Lp) in [(393, 0), (393, 64)]:
+for (S, Lp) in ([(int(os.environ["S"]), 0), (int(os.environ["S"]), 64)] if "S" in os.environ else [(393, 0), (393, 64)]):
     nh, H = 12, 768
     bufs = []
     for i in range(4):                                    # rotate operands: the step never re-reads a hot buffer
