@@ -930,11 +930,19 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
       dsum += dpp_f32<0x4E>(dsum);
       dsum += dpp_f32<0x141>(dsum);
       if (pc == 0) {
-        sDel[q] = q < p.Sq ? dsum : 0.f;
+#ifndef FUSED_CINIT
+#define FUSED_CINIT 1
+#endif
+        // FUSED_CINIT: the row statistics enter the score / dP products as the INITIAL accumulator of the MFMA chains (S - lse / c2, dP - delta):
+        // their LDS reads move in front of the MFMAs, out of the dependent chain MFMA -> read -> exp2, and one packed op per score pair goes away
+        sDel[q] = q < p.Sq ? (FUSED_CINIT ? -dsum : dsum) : 0.f;
         if (pb.delta && q < p.Sq) pb.delta[((long long)b * p.nh + h) * p.Sq + q] = dsum;
       }
     }
-    sLse[tid] = tid < p.Sq ? p.lse[((long long)b * p.nh + h) * p.Sq + tid] : 1.0e30f;   // rows past Sq: p = exp2(x - 1e30) = 0, they contribute nothing
+    {
+      const float l = tid < p.Sq ? p.lse[((long long)b * p.nh + h) * p.Sq + tid] : 1.0e30f;   // rows past Sq: p = exp2(x - 1e30) = 0, they contribute nothing
+      sLse[tid] = FUSED_CINIT ? -l / (p.scale * LOG2E) : l;
+    }
   }
   // own keys: V fragments in registers, validity
   bf16x8 vf[2][4];
@@ -1016,8 +1024,18 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
       const char* krow = sK + key * 128;
       const int kkey = swz_key(key);
       f32x16 st, dp;
+      if (FUSED_CINIT) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+        for (int qd = 0; qd < 4; ++qd) {             // accumulator rows 4qd .. 4qd+3 of this lane-half are query rows 8qd + 4hh + 0..3 of the tile
+          const f32x4 l4 = *(const f32x4*)(sLse + t * FQ + 8 * qd + 4 * hh);
+          const f32x4 d4 = *(const f32x4*)(sDel + t * FQ + 8 * qd + 4 * hh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { st[4 * qd + e] = l4[e]; dp[4 * qd + e] = d4[e]; }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+      }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = *(const bf16x8*)(krow + (((ks * 2 + hh) ^ kkey) << 4));
@@ -1036,16 +1054,19 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
 #pragma unroll
         for (int q2 = 0; q2 < 2; ++q2) {
           const int qd = 2 * a + q2;
-          const f32x4 l4 = *(const f32x4*)(sLse + t * FQ + 8 * qd + 4 * hh);
-          const f32x4 d4 = *(const f32x4*)(sDel + t * FQ + 8 * qd + 4 * hh);
+          f32x4 l4 = {0.f, 0.f, 0.f, 0.f}, d4 = l4;
+          if (!FUSED_CINIT) {
+            l4 = *(const f32x4*)(sLse + t * FQ + 8 * qd + 4 * hh);
+            d4 = *(const f32x4*)(sDel + t * FQ + 8 * qd + 4 * hh);
+          }
 #if ATTN_PK
           const f32x2 c22 = {c2, c2};
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
             const int r = 4 * qd + e;
-            const f32x2 x = f32x2{st[r], st[r + 1]} * c22 - f32x2{l4[e], l4[e + 1]};
+            const f32x2 x = FUSED_CINIT ? f32x2{st[r], st[r + 1]} * c22 : f32x2{st[r], st[r + 1]} * c22 - f32x2{l4[e], l4[e + 1]};
             const f32x2 pr = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-            const f32x2 ds = pr * (f32x2{dp[r], dp[r + 1]} - f32x2{d4[e], d4[e + 1]});
+            const f32x2 ds = FUSED_CINIT ? pr * f32x2{dp[r], dp[r + 1]} : pr * (f32x2{dp[r], dp[r + 1]} - f32x2{d4[e], d4[e + 1]});
             pd8[4 * q2 + e] = pr[0]; pd8[4 * q2 + e + 1] = pr[1];
             ds8[4 * q2 + e] = ds[0]; ds8[4 * q2 + e + 1] = ds[1];
           }
