@@ -216,6 +216,51 @@ def source_sha16(*names):
     return h.hexdigest()[:16]
 
 
+def reference_parity(model, lit, batch, cfg, dev, timed_weights: str):
+    """The timed code path (same engine, same precision configuration) against the UNMODIFIED reference: eval-mode logits of the [MASK] rows of
+    the first 32 examples of the rank-0 bench batch over the 2063 MARS analogy entities, compared with tests/golden/g7_bench_{cond,plain}.npz
+    (written by oracle/gen_goldens_full.py from /root/reference; same batch seed, weights regenerated from the goldens' numpy seed).  Runs LAST:
+    it overwrites the timed network's weights."""
+    import numpy as np
+    from mkg_analogy_amd import data_synth as D
+    keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
+    ids = torch.tensor(D.data_config(seed=1234)["analogy_entity_ids"], device=dev)
+    res = {"what": "eval-mode [MASK]-row logits of this code path vs the unmodified reference CPU path (goldens G7: first 32 examples of this batch x 2063 analogy "
+                   "entities, weights regenerated from the goldens' seed); north_star: 1e-2 (bf16) on well-conditioned weights",
+           "timed_mode": f"vision bf16, text_f16={int(model.engine.text_f16)}, head_split={int(model.engine.head_split)}, last_layer_rows={int(lit.last_layer_rows)}",
+           "timed_weights": timed_weights, "north_star_tol": 1e-2}
+    model.eval()
+    for tag, cond in (("g7_bench_cond", True), ("g7_bench_plain", False)):
+        path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+        if not os.path.exists(path):
+            res[tag] = "golden file missing"
+            continue
+        g = np.load(path, allow_pickle=False)
+        B0 = int(g["B"])
+        if batch["input_ids"].shape[0] < B0 or not np.array_equal(batch["input_ids"][:B0].cpu().numpy(), g["in::input_ids"]):
+            res[tag] = "bench batch differs from the golden's batch"
+            continue
+        D.load_seeded_weights(model, lit, seed=int(g["weight_seed"]), conditioned=cond)
+        with torch.no_grad():
+            pos = (batch["input_ids"][:B0] == D.MASK).int().argmax(1)
+            o, _ = model(**{k: batch[k][:B0] for k in keys}, return_dict=True, needed_rows=pos if lit.last_layer_rows else None)
+            lg = o.logits.mask_rows(batch["input_ids"][:B0], D.MASK)[:, ids].float().cpu().numpy()
+        ref, ctl = g["mask_logits"], g["ctl::mask_logits"]
+        lab = np.asarray(g["in::label"])
+        rk = lambda x: (x > x[np.arange(B0), lab][:, None]).sum(1) + 1
+        res[tag] = {"max_abs_dlogit": round(float(np.abs(lg - ref).max()), 5), "rms_dlogit": round(float(np.sqrt(((lg - ref) ** 2).mean())), 6),
+                    "logit_abs_max": round(float(np.abs(ref).max()), 3), "n_logits": int(ref.size),
+                    "ranks_identical_to_reference": f"{int((rk(lg) == rk(ref)).sum())}/{B0}",
+                    "reference_bf16_weight_control": {"max_abs_dlogit": round(float(np.abs(ctl - ref).max()), 5),
+                                                      "rms_dlogit": round(float(np.sqrt(((ctl - ref) ** 2).mean())), 6),
+                                                      "what": "the reference itself, fp32 math, with only its weight matrices rounded to bf16"}}
+    c = res.get("g7_bench_cond")
+    if isinstance(c, dict):
+        res["max_abs_dlogit"], res["rms_dlogit"] = c["max_abs_dlogit"], c["rms_dlogit"]          # headline: the well-conditioned golden
+        res["meets_north_star"] = bool(c["max_abs_dlogit"] < 1e-2)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +276,10 @@ def main():
                     help="fine-tune scoring head: 11292 = every MarKG entity (north_star's '~11k-entity head', the headline), 2063 = the MARS "
                          "analogy entities the reference's fine-tune branch scores (lit_models/transformer.py:95); the other one is timed "
                          "briefly as well and reported under 'alt_entity_head'")
+    ap.add_argument("--weights", default="plain", choices=["plain", "conditioned", "g7plain"],
+                    help="weights of the TIMED network: plain = torch-RNG N(0,0.02) (default; every round's headline), conditioned / g7plain = the seeded weight "
+                         "sets of the reference goldens tests/golden/g7_bench_{cond,plain}.npz.  Whatever is timed, the `parity` block of the line compares "
+                         "this code path with the UNMODIFIED reference's logits stored in those goldens (first 32 examples of this very batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-rate-only", type=int, default=0, help=argparse.SUPPRESS)      # child process of cpu_baseline(): threads
@@ -255,6 +304,9 @@ def main():
     pre = a.task == "pretrain"
     head = D.N_ENT if pre else a.entity_head
     model, lit, cfg = build(a.patch, seed=0, device=dev, backbone=a.model, entity_head=D.N_ANALOGY if pre else head)
+    if a.weights != "plain":
+        assert a.model == "mkgformer", "--weights conditioned / g7plain are MKGformer weight sets"
+        D.load_seeded_weights(model, lit, seed=0, conditioned=a.weights == "conditioned")
     if pre:
         lit.args.pretrain = 1
     batch = D.make_batch(a.batch, a.seq_len, seed=1234 + rank, device=dev, pretrain=pre, n_labels=head)
@@ -360,12 +412,8 @@ def main():
     evalb = None
     if world == 1 and not a.train_only and not a.no_kernel_timing:
         # Evaluation-path throughput (lit_models/transformer.py:115-166: forward + scoring + rank of the label), per precision mode
-        def time_eval(prec, split, n=3):
+        def time_eval(prec, n=3):
             lit.args.eval_precision = prec
-            eng_ = getattr(model, "engine", None)
-            old_split = getattr(eng_, "text_split_eval", False)
-            if eng_ is not None and hasattr(eng_, "text_split_eval"):
-                eng_.text_split_eval = split          # the switch evaluation passes obey (engine.text_split_eval; default on)
             try:
                 m = tr.validate(lit, [batch])
                 barrier()
@@ -376,55 +424,17 @@ def main():
                 return {"examples_per_s": round(a.batch * n / (time.perf_counter() - t1), 1), "hits1": m.get("Eval_entity/hits1"),
                         "mean_rank": m.get("Eval_entity/mean_rank")}
             finally:
-                if eng_ is not None and hasattr(eng_, "text_split_eval"):
-                    eng_.text_split_eval = old_split
                 lit.args.eval_precision = None
-        split_default = bool(getattr(getattr(model, "engine", None), "text_split_eval", False)) and a.model == "mkgformer"
-        default_mode = "bf16_text_split" if split_default else "bf16"
         evalb = {"what": "validation pass over the timed batch: forward, scoring head, device-side rank of the label",
-                 "bf16": time_eval("bf16", False)}                      # the training configuration of the text stream
-        if a.model == "mkgformer":
-            evalb["bf16_text_split"] = time_eval("bf16", True)        # evaluation default: split-precision text stream (engine.text_split_eval)
-        evalb["fp32"] = time_eval("fp32", split_default)
-        evalb["eval_examples_per_s"] = evalb[default_mode]["examples_per_s"]
-        evalb["eval_precision"] = default_mode
-    parity = None
-    if world == 1 and a.model == "mkgformer" and not pre and not a.no_kernel_timing and not a.train_only:
-        # the bf16 training path against the fp32-accurate evaluation path (engine_precise: held to the reference at 1e-3 on logits
-        # in tests/test_parity_full_gpu.py) on THIS batch and THESE weights: mask-row logits over the scored entity ids, eval mode
-        model.eval()
-        ids = torch.tensor(cfg["analogy_entity_ids"], device=dev)
-        keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
-        lg = {}
-        split0, spliteval0 = model.engine.text_split, model.engine.text_split_eval
-        model.engine.text_split_eval = False                    # the modes are selected explicitly below
-        with torch.no_grad():
-            for prec in ("bf16", "bf16_text_split", "fp32"):
-                model.set_precision("fp32" if prec == "fp32" else "bf16")
-                model.engine.text_split = prec == "bf16_text_split"
-                o, _ = model(**{k: batch[k] for k in keys}, return_dict=True)
-                lg[prec] = o.logits.mask_rows(batch["input_ids"], D.MASK)[:, ids].float()
-            model.set_precision("bf16")
-            model.engine.text_split, model.engine.text_split_eval = split0, spliteval0
-        lab = batch["label"]
-        rk = {k: ((v > v.gather(1, lab[:, None])).sum(1) + 1) for k, v in lg.items()}
-
-        def cmp(k):
-            dl = lg[k] - lg["fp32"]
-            return {"max_abs_dlogit": round(float(dl.abs().max()), 5), "rms_dlogit": round(float(dl.pow(2).mean().sqrt()), 6),
-                    "ranks_identical_frac": round(float((rk[k] == rk["fp32"]).float().mean()), 4),
-                    "median_abs_rank_diff": float((rk[k] - rk["fp32"]).abs().float().median())}
-        parity = {"what": "bf16 training path vs fp32-accurate path (held to the reference at 1e-3 in tests/test_parity_full_gpu.py), mask-row logits of the timed batch and weights (eval mode)",
-                  **cmp("bf16"), "logit_abs_max": round(float(lg["fp32"].abs().max()), 3), "entity_head": head,
-                  "text_split": {"what": "the same with the text stream's forward products on two-term operand splits (MART_TEXT_SPLIT=1)", **cmp("bf16_text_split")},
-                  "timed_mode": "bf16_text_split" if split0 else "bf16",
-                  "note": "plain N(0,0.02) weights: the unscaled fusion softmax of layers 8-11 makes the map chaotic (DESIGN section 5): the reference itself with only its weight "
-                          "matrices rounded to bf16 moves its logits by 0.50 max / 2.8e-2 rms on this batch (tests/golden/g7_bench_plain.npz ctl::)"}
+                 "bf16": time_eval("bf16"),                              # the training configuration (text stream on fp16 operands, split-precision head)
+                 "fp32": time_eval("fp32")}
+        evalb["eval_examples_per_s"] = evalb["bf16"]["examples_per_s"]
+        evalb["eval_precision"] = "bf16"
     tsplit = None
     if world == 1 and a.model == "mkgformer" and not a.no_kernel_timing and not a.train_only:
-        # the training step with the text stream in the other precision mode, timed briefly on the same network
+        # the training step with the text stream in the other precision mode (plain bf16 operands), timed briefly on the same network
         eng_ = model.engine
-        eng_.text_split = not eng_.text_split
+        eng_.text_f16 = not eng_.text_f16
         for i in range(2):
             tr.train_step(lit, batch, a.warmup + a.steps + 20 + i)
         barrier()
@@ -433,8 +443,8 @@ def main():
             tr.train_step(lit, batch, a.warmup + a.steps + 22 + i)
         barrier()
         d3 = time.perf_counter() - t1
-        tsplit = {"text_split": eng_.text_split, "steps": 5, "ms_per_step": round(1000.0 * d3 / 5, 3), "value": round(a.batch * 5 / d3, 2)}
-        eng_.text_split = not eng_.text_split
+        tsplit = {"text_f16": eng_.text_f16, "steps": 5, "ms_per_step": round(1000.0 * d3 / 5, 3), "value": round(a.batch * 5 / d3, 2)}
+        eng_.text_f16 = not eng_.text_f16
     alt = None
     if world == 1 and a.model == "mkgformer" and not pre and not a.no_kernel_timing and not a.train_only:
         # the other scoring head, timed briefly on the same network (the head is 0.03 % of the step's FLOPs either way)
@@ -452,6 +462,9 @@ def main():
         barrier()
         d2 = time.perf_counter() - t1
         alt = {"entity_head": other, "steps": 5, "ms_per_step": round(1000.0 * d2 / 5, 3), "value": round(a.batch * 5 / d2, 2)}
+    parity = None
+    if world == 1 and a.model == "mkgformer" and not pre and a.patch == 16 and a.seq_len == 64 and not a.no_kernel_timing and not a.train_only:
+        parity = reference_parity(model, lit, batch, cfg, dev, a.weights)
     spread = None
     if world > 1:
         # data-parallel self-check: every replica must hold the same weights after the same all-reduced updates
@@ -468,7 +481,9 @@ def main():
                "config": {"workload": (f"MKGformer (BERT-base + ViT-B/{a.patch} patches)" if a.model == "mkgformer" else "FLAVA-base (12+12+6 layers)") +
                           (" fine-tune step, MARS-shaped batch" if not pre else " MarKG pre-train step (full entity / relation heads)"), "batch_per_gpu": a.batch,
                           "global_batch": a.batch * world, "seq_len": a.seq_len, "patches_per_image": P, "vision_tokens": 1 + 2 * P,
-                          "entity_head": head, "relation_head": D.N_REL if pre else None, "vocab": D.VOCAB, "parallelism": f"dp{world}", "weights": "random-init N(0,0.02)"},
+                          "entity_head": head, "relation_head": D.N_REL if pre else None, "vocab": D.VOCAB, "parallelism": f"dp{world}",
+                          "weights": {"plain": "random-init N(0,0.02) (torch RNG)", "g7plain": "random-init N(0,0.02), the seeded set of golden G7 (plain)",
+                                      "conditioned": "random-init N(0,0.02), the seeded, well-conditioned set of golden G7 (text value projections of layers 8-11 x 0.05)"}[a.weights]},
                "loss": round(float(loss), 4), "hits1": metrics.get("Eval_entity/hits1"),
                "train_gflop_per_example": round(train_gflop, 1)}
         if spread is not None:
@@ -489,7 +504,7 @@ def main():
             out["comm"] = comm
             out["comm_exposed_ms"] = comm["comm_exposed_ms"]
             out["rccl_world"] = comm["rccl_world"]
-        out["metric_detail"] = f"entity_head={head}, text_split={int(getattr(getattr(model, 'engine', None), 'text_split', False))}"
+        out["metric_detail"] = f"entity_head={head}, text_f16={int(getattr(getattr(model, 'engine', None), 'text_f16', False))}, weights={a.weights}"
         if not a.no_cpu_baseline and world == 1 and a.model == "mkgformer" and not pre:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.patch, a.seq_len)

@@ -64,6 +64,9 @@ typedef struct {
   int a_src_rows, b_src_rows;                                     /* with a_rows / b_rows: number of rows of the table the indices point into (the kernel forms 32-bit
                                                                      element offsets row * ld, so src_rows * ld must stay below 2^32; checked when stated, 0 = the caller
                                                                      vouches for it).  Without a gather the same check uses M * lda / N * ldb. */
+  int in_f16, c_f16;                                              /* in_f16: A, B (A2, B2) hold IEEE fp16 instead of bf16 (v_mfma_f32_32x32x16_f16, same rate, 11-bit
+                                                                     significands): the forward linear layers of the text stream.  c_f16 (needs in_f16, 16-bit C): C is
+                                                                     written as fp16 and C2, when given, is its bf16 copy (what the backward pass reads).  preact stays bf16. */
 } mart_gemm_nt_desc;
 int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream);
 
@@ -100,7 +103,10 @@ typedef struct {
   float* s_out;                                                   /* optional: the pre-LN sum (saved for bwd) */
   float* out_f32; void* out_bf16;                                 /* either may be NULL */
   float* mean; float* rstd;                                       /* [M] */
-  const float* y_f32;                                             /* optional: the dropped-out branch in f32 instead of y_bf16 (text layers in split precision) */
+  const float* y_f32;                                             /* optional: the dropped-out branch in f32 instead of y_bf16 (the text layers' dense outputs) */
+  void* out_f16;                                                  /* optional: the normalised output as IEEE fp16 (A operand of the text stream's fp16 forward products) */
+  const int32_t* x_rows;                                          /* optional row gather of the residual input: row m reads x_f32[x_rows[m]] (last text layer, computed
+                                                                     only on the rows the loss reads); y_*, s_out, outputs, mean / rstd and the dropout index stay compact */
 } mart_ln_fwd_desc;
 int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream);
 
@@ -148,6 +154,7 @@ typedef struct {
   int B, L, H;
   float* s_out; float* mean; float* rstd;
   float* out_f32; void* out_bf16;
+  void* out_f16;                                                   /* optional fp16 copy of the output (engine.text_f16) */
 } mart_text_embed_desc;
 int mart_text_embed_fwd(const mart_text_embed_desc* d, void* stream);
 /* dy*dropmask/(1-p) -> dyd (f32) : first half of the text-embedding backward (LN bwd follows) */
@@ -179,6 +186,7 @@ typedef struct {
   void* ctx; int ldctx;                                             /* bf16 out [B*Sq, nh*64] */
   float* lse;                                                       /* [B,nh,Sq] softmax statistic, LOG2 domain: log2(sum_j 2^(s_ij*log2e)) */
   int rw_skip_row0;                                                 /* FLAVA reweight variant: query row 0 ([CLS]) is not scaled (modeling_flava.py:494) */
+  void* ctx_f16;                                                    /* optional: the context also as fp16 (rounded once from f32; ld = ldctx): A operand of the fp16 output projection */
 } mart_attn_fwd_desc;
 int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream);
 
@@ -205,6 +213,7 @@ typedef struct {
   void* out; int ldo;                                               /* fusion_output bf16 [B*Lq, H] */
   void* probs; int ldp;                                             /* bf16 [B*Lq, ldp], ldp a multiple of 8 in [Nv, 64*ceil(Nv/64)] */
   int B, Lq, Nv, H;
+  void* out_f16;                                                    /* optional fp16 copy of fusion_output (ld = ldo) */
 } mart_fusion_fwd_desc;
 int mart_fusion_supported(int Lq, int Nv, int H);
 int mart_fusion_fwd(const mart_fusion_fwd_desc* d, void* stream);
@@ -249,6 +258,8 @@ int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, const int64_t* 
 int mart_find_token(const int64_t* ids, int B, int L, int64_t token, int32_t* pos_out, int32_t* row_out, void* stream);
 int mart_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
 int mart_cast_bf16_f32(const void* src, float* dst, long long n, void* stream);
+int mart_cast_f32_f16(const float* src, void* dst_f16, long long n, void* stream);   /* fp16 shadow of the text-stream weights */
+int mart_cast_bf16_f16(const void* src_bf16, void* dst_f16, long long n, void* stream);   /* exact for |x| in [2^-14, 65504] */
 /* dst[r, 0:C] = bf16(src[r, 0:C]), dst[r, C:ldd] = 0 */
 int mart_cast_pad_f32_bf16(const float* src, int lds_, void* dst, int ldd, int R, int C, void* stream);
 /* dst[r,:] = src[rows[r],:] for 2-byte (bf16) elements; H multiple of 8 */
@@ -257,6 +268,16 @@ int mart_gather_rows_bf16(const void* src, int ld, const int32_t* rows, void* ds
 int mart_act_bwd(const void* dy_bf16, const void* z_bf16, int act, void* out_bf16, long long n, void* stream);
 int mart_gather_rows_f32(const float* src, int ld, const int32_t* rows, float* dst, int R, int H, void* stream);
 int mart_scatter_add_rows_f32(const float* src, const int32_t* rows, float* dst, int ld, int R, int H, void* stream);
+/* ---- row subsets of the last text layer (lit_models/transformer.py:94-95,103-107 read <= 5 rows per example of trans_hidden_states; nothing reads
+ * text layer 11's other rows: modeling_unimo.py:616 exports K/V of layers idx-1 <= 10 only).  rows[R] are flat row ids, `group` consecutive entries
+ * belong to one example.
+ * mart_gather_rows_first_f32: dst[r] = src[rows[r]], or 0 when an EARLIER slot of the same group names the same row (the gradient of a row that was
+ * requested twice is taken once).
+ * mart_scatter_rows: slots of a group applied in order by one workgroup (deterministic); src f32, dst f32 or bf16 (dst_bf16 != 0: sums are formed
+ * in f32 and rounded once).  accumulate = 1: dst[rows[r]] += src[r] (gradient rows; a row named twice receives both); accumulate = 0:
+ * dst[rows[r]] = src[r] and the FIRST slot naming a row wins (forward values). */
+int mart_gather_rows_first_f32(const float* src, int ld, const int32_t* rows, int group, float* dst, int R, int H, void* stream);
+int mart_scatter_rows(const float* src, const int32_t* rows, int group, void* dst, int ld, int dst_bf16, int accumulate, int R, int H, void* stream);
 /* out = a (+ b) with mixed dtypes; used to merge gradient contributions */
 int mart_add_f32_bf16(const float* a, const void* b_bf16, float* out_f32, void* out_bf16, long long n, void* stream);
 /* debug/test hook: the dropout keep-mask the kernels derive from (seed, index) */
@@ -264,11 +285,13 @@ int mart_dropout_mask(uint8_t* out, long long n, float p, uint64_t seed, void* s
 
 /* ---------------------------------------------------------------- optimizer (lit_models/transformer.py:224-241)
  * Multi-tensor AdamW over the flat parameter buffer; also refreshes the bf16 shadow the GEMMs read.
- * chunks: int32 triples (start, length, decay_flag), start/length in elements. */
+ * chunks: int32 triples (start, length, flags), start/length in elements; flags bit 0 = weight decay applies, bit 1 = the chunk also
+ * refreshes the fp16 shadow (forward weights of the text stream, engine.text_f16). */
 typedef struct {
   float* master; const float* grad; float* m; float* v; void* shadow_bf16;
   const int32_t* chunks; int n_chunks;
   float lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale;
+  void* shadow_f16;                                                 /* optional fp16 shadow, same layout as master (written for chunks with flag bit 1) */
 } mart_adamw_desc;
 int mart_adamw(const mart_adamw_desc* d, void* stream);
 /* batched bf16 transposes described by int64 quadruples (src_off, dst_off, rows, cols) into the W^T shadow */

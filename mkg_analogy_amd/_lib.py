@@ -24,7 +24,8 @@ class GemmNT(C.Structure):
                 ("batch", i32), ("stride_a", i64), ("stride_b", i64), ("stride_c", i64), ("stride_aux", i64),
                 ("bias", vp), ("bias2", vp), ("bias_by_brow", i32), ("act", i32), ("preact", vp),
                 ("mulz", vp), ("mul_act", i32), ("res_f32", vp), ("res_bf16", vp), ("ldres", i32),
-                ("alpha", f32), ("C", vp), ("ldc", i32), ("c_f32", i32), ("C2", vp), ("ldc2", i32), ("tile_cfg", i32), ("preact_grad", i32), ("b_blocked", i32), ("a_src_rows", i32), ("b_src_rows", i32)]
+                ("alpha", f32), ("C", vp), ("ldc", i32), ("c_f32", i32), ("C2", vp), ("ldc2", i32), ("tile_cfg", i32), ("preact_grad", i32), ("b_blocked", i32), ("a_src_rows", i32), ("b_src_rows", i32),
+                ("in_f16", i32), ("c_f16", i32)]
 
 
 class GemmTN(C.Structure):
@@ -36,7 +37,8 @@ class GemmTN(C.Structure):
 
 class LnFwd(C.Structure):
     _fields_ = [("x_f32", vp), ("y_bf16", vp), ("p_drop", f32), ("seed", u64), ("gamma", vp), ("beta", vp), ("eps", f32),
-                ("M", i32), ("H", i32), ("s_out", vp), ("out_f32", vp), ("out_bf16", vp), ("mean", vp), ("rstd", vp), ("y_f32", vp)]
+                ("M", i32), ("H", i32), ("s_out", vp), ("out_f32", vp), ("out_bf16", vp), ("mean", vp), ("rstd", vp), ("y_f32", vp),
+                ("out_f16", vp), ("x_rows", vp)]
 
 
 class LnBwd(C.Structure):
@@ -48,7 +50,7 @@ class LnBwd(C.Structure):
 class TextEmbed(C.Structure):
     _fields_ = [("ids", vp), ("tt", vp), ("word", vp), ("pos", vp), ("type", vp), ("gamma", vp), ("beta", vp), ("eps", f32),
                 ("p_drop", f32), ("seed", u64), ("B", i32), ("L", i32), ("H", i32), ("s_out", vp), ("mean", vp), ("rstd", vp),
-                ("out_f32", vp), ("out_bf16", vp)]
+                ("out_f32", vp), ("out_bf16", vp), ("out_f16", vp)]
 
 
 class AttnFwd(C.Structure):
@@ -56,7 +58,7 @@ class AttnFwd(C.Structure):
                 ("pk", vp), ("pv", vp), ("ldp", i32), ("Lp", i32),
                 ("B", i32), ("nh", i32), ("Sq", i32), ("Sk", i32), ("scale", f32),
                 ("attn_mask", vp), ("sep", vp), ("sep_stride", i32), ("w0", vp), ("w1", vp),
-                ("p_drop", f32), ("seed", u64), ("ctx", vp), ("ldctx", i32), ("lse", vp), ("rw_skip_row0", i32)]
+                ("p_drop", f32), ("seed", u64), ("ctx", vp), ("ldctx", i32), ("lse", vp), ("rw_skip_row0", i32), ("ctx_f16", vp)]
 
 
 class AttnF32(C.Structure):
@@ -80,7 +82,7 @@ class AttnBwd(C.Structure):
 
 class FusionFwd(C.Structure):
     _fields_ = [("q", vp), ("ldq", i32), ("v", vp), ("ldv", i32), ("out", vp), ("ldo", i32), ("probs", vp), ("ldp", i32),
-                ("B", i32), ("Lq", i32), ("Nv", i32), ("H", i32)]
+                ("B", i32), ("Lq", i32), ("Nv", i32), ("H", i32), ("out_f16", vp)]
 
 
 class FusionBwd(C.Structure):
@@ -92,7 +94,7 @@ class FusionBwd(C.Structure):
 class AdamW(C.Structure):
     _fields_ = [("master", vp), ("grad", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("chunks", vp), ("n_chunks", i32),
                 ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bc1", f32), ("bc2", f32),
-                ("grad_scale", f32)]
+                ("grad_scale", f32), ("shadow_f16", vp)]
 
 
 _SIGS = {
@@ -130,6 +132,10 @@ _SIGS = {
     "mart_find_token": (i32, [vp, i32, i32, i64, vp, vp, vp]),
     "mart_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "mart_cast_bf16_f32": (i32, [vp, vp, i64, vp]),
+    "mart_cast_f32_f16": (i32, [vp, vp, i64, vp]),
+    "mart_cast_bf16_f16": (i32, [vp, vp, i64, vp]),
+    "mart_gather_rows_first_f32": (i32, [vp, i32, vp, i32, vp, i32, i32, vp]),
+    "mart_scatter_rows": (i32, [vp, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "mart_cast_pad_f32_bf16": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "mart_gather_rows_bf16": (i32, [vp, i32, vp, vp, i32, i32, vp]),
     "mart_act_bwd": (i32, [vp, vp, i32, vp, i64, vp]),
@@ -153,6 +159,7 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
+EXPECTED_ABI = 4            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
 _lib = None
 
 
@@ -168,6 +175,10 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        abi = int(l.mart_abi_version())
+        if abi != EXPECTED_ABI:
+            raise MartError(f"{LIB_PATH} has ABI {abi}, this package binds ABI {EXPECTED_ABI}: rebuild it "
+                            "(`python -c 'import __graft_entry__ as g; g.build()'`)")
         _lib = l
     return _lib
 

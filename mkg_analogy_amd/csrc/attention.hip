@@ -450,7 +450,7 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
 #ifndef FWD_LDS_EPI
 #define FWD_LDS_EPI 1
 #endif
-  if (FWD_LDS_EPI && TPW == 1 && !TEXT && (((uintptr_t)p.ctx & 15) == 0) && p.ldctx % 8 == 0) {   // (text shape, two active waves: 1.6 us SLOWER)
+  if (FWD_LDS_EPI && TPW == 1 && !TEXT && !p.ctx_f16 && (((uintptr_t)p.ctx & 15) == 0) && p.ldctx % 8 == 0) {   // (text shape, two active waves: 1.6 us SLOWER)
     // The output tile has "lane = query, registers = 4 consecutive head dims": stored from registers, an instruction writes 8 bytes into each of 32
     // rows that lie 2 * ld bytes apart (32 partial cache lines).  Each wave stages its 32 rows in its own 4 KB of the (now dead) K / V ring and
     // stores them as 16-byte chunks, eight lanes per 128-byte row segment.
@@ -489,6 +489,7 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
         for (int qd = 0; qd < 4; ++qd) {
           f32x4 v = {ot[u][dt][4 * qd] * inv, ot[u][dt][4 * qd + 1] * inv, ot[u][dt][4 * qd + 2] * inv, ot[u][dt][4 * qd + 3] * inv};
           *(bf16x4*)(op + dt * 32 + 8 * qd + 4 * hh) = f4_to_bf4(v);
+          if (p.ctx_f16) *(bf16x4*)((bf16*)p.ctx_f16 + (op - (bf16*)p.ctx) + dt * 32 + 8 * qd + 4 * hh) = f4_to_h4raw(v);   // fp16 twin, rounded once from f32
         }
       if (hh == 0 && p.lse) p.lse[((long long)b * p.nh + h) * p.Sq + qi[u]] = m_run[u] + __builtin_amdgcn_logf(l_run[u]);   // log2-domain LSE
     }
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_bwd_dkv_k(mart_attn_bwd_desc pb) 
     kf[ks] = *(const bf16x8*)(kp + ks * 16 + hh * 8);
     vf[ks] = *(const bf16x8*)(vp + ks * 16 + hh * 8);
   }
-  const float maskadd = (ctl.mask_row && kvalid) ? (1.0f - (float)ctl.mask_row[kj]) * -10000.0f : 0.f;
+  const float maskadd = (ctl.mask_row && kvalid) ? (ctl.mask_row[kj] != 0 ? 0.f : -10000.0f) : 0.f;   // any non-zero mask value = attended, as mask_bits() in the forward pass
   const float c2 = p.scale * LOG2E;
 
   f32x16 dk[2], dv[2];
@@ -1278,7 +1279,7 @@ __global__ __launch_bounds__(64 * NB, NB == 2 ? 3 : 2) void attn_bwd_text64_k(ma
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const bf16x8*)(kp + ks * 16); vf[ks] = *(const bf16x8*)(vp + ks * 16); }
   // lane constants of the key: additive mask in the log2 domain (keys past the end: p = 0), membership in the reweighted block
-  const float madd2 = !kvalid ? -1.0e30f : (ctl.mask_row ? (1.0f - (float)ctl.mask_row[kj]) * (-10000.0f * LOG2E) : 0.f);
+  const float madd2 = !kvalid ? -1.0e30f : (ctl.mask_row ? (ctl.mask_row[kj] != 0 ? 0.f : -10000.0f * LOG2E) : 0.f);   // same convention as mask_bits(): non-zero = attended
   const int sep = ctl.sep < 0 ? 0x7fffffff : ctl.sep;
   const bool rw = kj >= sep;                               // this lane's key is in the reweighted block
   const float rwf = rw ? 1.f : 0.f;

@@ -9,6 +9,12 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+// fp16: the FORWARD operands of the text stream (engine.text_f16).  Post-LayerNorm activations, GELU outputs and N(0, 0.02)-scale weights sit
+// well inside fp16's range, and its 11-bit significand rounds 8x finer than bf16 at the same MFMA rate; gradients stay bf16 (range).
+typedef _Float16 h16;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -46,6 +52,10 @@ struct MartAttrOnce {
 // Result layout: lane l, reg r holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// the same product on fp16 operands (raw 16-bit lanes travel through LDS as bf16x8; only the matrix instruction differs)
+__device__ __forceinline__ f32x16 mfma32h(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
 // row index inside a 32x32 MFMA result tile held by (lane-half h, reg r)
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -90,6 +100,9 @@ __device__ __forceinline__ bf16x4 f2x2_to_bf4(f32x2 lo, f32x2 hi) {
   const u32x2_t w = {__builtin_bit_cast(unsigned, l), __builtin_bit_cast(unsigned, h)};
   return __builtin_bit_cast(bf16x4, w);
 }
+// f32 -> fp16 with the 16-bit lanes typed as bf16x4 (the staging / store code moves raw 16-bit lanes)
+__device__ __forceinline__ bf16x4 f4_to_h4raw(f32x4 v) { return __builtin_bit_cast(bf16x4, __builtin_convertvector(v, h16x4)); }
+__device__ __forceinline__ bf16x4 f2x2_to_h4raw(f32x2 lo, f32x2 hi) { return f4_to_h4raw(f32x4{lo[0], lo[1], hi[0], hi[1]}); }
 __device__ __forceinline__ f32x4 bf4_to_f4(bf16x4 v) {
   f32x4 o = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   return o;

@@ -199,7 +199,7 @@ __device__ __forceinline__ void apply_V(const bf16* Vb, int ldv, int Nv, const G
     if (nbuf == 1) { __syncthreads(); if (kc + 1 < g.KT32) stage(kc + 1, vb0); }
   }
 }
-template <int DT>
+template <int DT, bool F16 = false>
 __device__ __forceinline__ void store_rows(bf16* out, int ldo, const Geo& g, int Lq, int wave, int l31, int hh, const f32x16 (&acc)[DT][2]) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -210,7 +210,10 @@ __device__ __forceinline__ void store_rows(bf16* out, int ldo, const Geo& g, int
     for (int i = 0; i < DT; ++i)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        *(bf16x4*)(row + (wave * DT + i) * 32 + 8 * c + 4 * hh) = f4_to_bf4(f32x4{acc[i][u][4 * c], acc[i][u][4 * c + 1], acc[i][u][4 * c + 2], acc[i][u][4 * c + 3]});
+      {
+        const f32x4 v = {acc[i][u][4 * c], acc[i][u][4 * c + 1], acc[i][u][4 * c + 2], acc[i][u][4 * c + 3]};
+        *(bf16x4*)(row + (wave * DT + i) * 32 + 8 * c + 4 * hh) = F16 ? f4_to_h4raw(v) : f4_to_bf4(v);
+      }
   }
 }
 
@@ -274,6 +277,7 @@ __global__ __launch_bounds__(FT, 1) void fusion_fwd_k(mart_fusion_fwd_desc p, in
   f32x16 ov[DT][2];
   apply_V<DT>(Vb, p.ldv, p.Nv, g, pimg, smem + g.PB, nbuf, tid, wave, o, l31, hh, ov);
   store_rows<DT>((bf16*)p.out, p.ldo, g, p.Lq, wave, l31, hh, ov);
+  if (p.out_f16) store_rows<DT, true>((bf16*)p.out_f16, p.ldo, g, p.Lq, wave, l31, hh, ov);
 }
 
 

@@ -76,7 +76,24 @@ enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32, F
 
 // PERSIST: one workgroup per CU slot walks over its tiles; the first K-tile of the NEXT tile is put in flight before the
 // epilogue of the current one, so the ~2-3 us of launch + first-DMA latency per tile hide behind the epilogue.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0, bool PERSIST = false>   // ACTK: activation kind of the fast masks (literal: no erf code in the quick-GELU kernels)
+// DT: operand / output element type.  0 = bf16 operands, C bf16 | f32 (every product of the vision stream and of the backward pass);
+// 1 = fp16 operands (v_mfma_f32_32x32x16_f16: same rate, 11-bit significands), C bf16 | f32; 2 = fp16 operands AND C in fp16 (the GELU output that
+// is the next product's A operand), with C2 as its bf16 copy for the backward pass.  The 16-bit lanes move through LDS untyped.
+template <int DT> __device__ __forceinline__ f32x16 mm(bf16x8 a, bf16x8 b, f32x16 c) {
+  if constexpr (DT == 0) return mfma32(a, b, c); else return mfma32h(a, b, c);
+}
+template <int DT> __device__ __forceinline__ bf16x4 cvt_c(f32x4 v) {            // primary 16-bit output
+  if constexpr (DT == 2) return f4_to_h4raw(v); else return f4_to_bf4(v);
+}
+template <int DT> __device__ __forceinline__ bf16x4 cvt_c2(f32x2 lo, f32x2 hi) {
+  if constexpr (DT == 2) return f2x2_to_h4raw(lo, hi); else return f2x2_to_bf4(lo, hi);
+}
+constexpr bool epi_packed(int EPI, int DT) {     // 16-bit outputs only, no streamed operands: staged through LDS as packed 16-bit rows
+  return EPI >= 0 && (EPI & (1 | 2 | 16)) == 0 && (DT == 2 || (EPI & 32) == 0);
+}
+constexpr int epi_outputs(int EPI) { return 1 + ((EPI & 4) != 0 ? 1 : 0) + ((EPI & 32) != 0 ? 1 : 0); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0, bool PERSIST = false, int DT = 0>   // ACTK: activation kind of the fast masks (literal: no erf code in the quick-GELU kernels)
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int BK = 64;
@@ -243,7 +260,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[u][j], af[u][i], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = mm<DT>(bfr[u][j], af[u][i], acc[i][j]);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // all fragment reads of this slot retired before the next barrier
     }
   } else if constexpr (PIPE == 2) {
@@ -313,14 +330,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       constexpr int ih = decltype(IH)::value, j = decltype(J)::value;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii) acc[2 * ih + ii][j] = mfma32(bfr[j][0], af[ii][0], acc[2 * ih + ii][j]);
+      for (int ii = 0; ii < 2; ++ii) acc[2 * ih + ii][j] = mm<DT>(bfr[j][0], af[ii][0], acc[2 * ih + ii][j]);
       __builtin_amdgcn_sched_barrier(0);
       dma();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 1; ks < 4; ++ks)
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) acc[2 * ih + ii][j] = mfma32(bfr[j][ks], af[ii][ks], acc[2 * ih + ii][j]);
+        for (int ii = 0; ii < 2; ++ii) acc[2 * ih + ii][j] = mm<DT>(bfr[j][ks], af[ii][ks], acc[2 * ih + ii][j]);
       __builtin_amdgcn_s_setprio(0);
     };
     auto bar = [&]() {
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[u][j], af[u][i], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = mm<DT>(bfr[u][j], af[u][i], acc[i][j]);
       __builtin_amdgcn_s_setprio(0);
     };
     auto phase_end = [&]() {
@@ -462,7 +479,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(bfr[j], af[i], acc[i][j]);   // D[n][m]: lane = row m
+        for (int j = 0; j < TN; ++j) acc[i][j] = mm<DT>(bfr[j], af[i], acc[i][j]);   // D[n][m]: lane = row m
     }
   }
   }
@@ -498,13 +515,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     __builtin_amdgcn_wave_barrier();
   };
 
-  static_assert(EPI < 0 || (EPI & F_PGRAD) == 0 || (EPI & (F_PREACT | F_ACT | F_RES | F_MULZ | F_CF32 | F_C2)) == (F_PREACT | F_ACT),
-                "act'(z) output is a fast-lane option of the bf16 pre-activation + activation epilogue only");
-  if constexpr (EPI >= 0 && (EPI & (F_RES | F_MULZ | F_CF32 | F_C2)) == 0) {
+  static_assert(EPI < 0 || (EPI & F_PGRAD) == 0 || (EPI & (F_PREACT | F_ACT | F_RES | F_MULZ | F_CF32)) == (F_PREACT | F_ACT),
+                "act'(z) output is a fast-lane option of the 16-bit pre-activation + activation epilogue only");
+  static_assert(EPI < 0 || (EPI & F_C2) == 0 || DT == 2 || (EPI & F_CF32) != 0, "C2 is the bf16 copy of an f32 C, or of an fp16 C (DT 2)");
+  if constexpr (epi_packed(EPI, DT)) {
     // ---- bf16-only outputs without streamed operands (plain / bias, and fc1's pre-activation + activation): bias and
     // activation are applied in MFMA layout, the results go through LDS as packed bf16 (half the staging traffic of the
     // f32 round trip) and leave as 16-byte stores, 8 lanes per 128-byte row segment.
-    constexpr int NO = ((EPI & F_PREACT) != 0) ? 2 : 1;          // outputs
+    constexpr int NO = epi_outputs(EPI);                          // outputs: C, [preact], [C2 = bf16 copy of an fp16 C]
+    constexpr int S2 = ((EPI & F_PREACT) != 0) ? 2 : 1;           // staging slot of C2
     constexpr int RS = WN * 2 + 16;                               // staging row stride in bytes (16-byte aligned rows)
     static_assert(WN == 64, "bf16 staging is laid out for 64-column wave tiles");
     char* epb = smem + (PERSIST ? STAGE : 0) + wave * (NO * 32 * RS);
@@ -526,7 +545,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     const long long ub = cb + (long long)(em0 + wm0) * p.ldc + en0 + wn0;
     char* const cbase = (char*)p.C + ub * 2;
     char* const pbase = (char*)p.preact + ub * 2;
+    char* const c2base = (char*)p.C2 + (cb + (long long)(em0 + wm0) * p.ldc2 + en0 + wn0) * 2;
     const unsigned loff = ((unsigned)rr * (unsigned)p.ldc + (unsigned)rc) * 2u;
+    const unsigned loff2 = ((unsigned)rr * (unsigned)p.ldc2 + (unsigned)rc) * 2u;
     const int mrem = p.M - (em0 + wm0);                            // rows of this sub-tile inside the matrix (wave-uniform)
     auto run = [&](auto guard) {                                  // two straight-line arms, one wave-uniform row-guard test per sub-tile
     constexpr bool GUARD = decltype(guard)::value;
@@ -546,7 +567,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
             act_fwd_grad2(f32x2{v[2], v[3]}, ACTK, a1, g1);
 #endif
             *(bf16x4*)(dst + 32 * RS) = f2x2_to_bf4(g0, g1);
-            *(bf16x4*)dst = f2x2_to_bf4(a0, a1);
+            *(bf16x4*)dst = cvt_c2<DT>(a0, a1);
+            if constexpr ((EPI & F_C2) != 0) *(bf16x4*)(dst + S2 * 32 * RS) = f2x2_to_bf4(a0, a1);
             continue;
           } else {
             if constexpr ((EPI & F_PREACT) != 0) *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(v);
@@ -559,7 +581,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
               v = f32x4{a0[0], a0[1], a1[0], a1[1]};
             }
           }
-          *(bf16x4*)dst = f4_to_bf4(v);
+          *(bf16x4*)dst = cvt_c<DT>(v);
+          if constexpr ((EPI & F_C2) != 0) *(bf16x4*)(dst + S2 * 32 * RS) = f4_to_bf4(v);
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
@@ -575,6 +598,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #endif
           st_stream((bf16x8*)(cbase + uo + loff), o);
           if constexpr ((EPI & F_PREACT) != 0) st_stream((bf16x8*)(pbase + uo + loff), *(const bf16x8*)(epb + 32 * RS + row * RS + rc * 2));
+          if constexpr ((EPI & F_C2) != 0)
+            st_stream((bf16x8*)(c2base + (long long)(ro(i) + it * 8) * p.ldc2 * 2 + loff2), *(const bf16x8*)(epb + S2 * 32 * RS + row * RS + rc * 2));
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -665,7 +690,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
           if constexpr ((EPI & F_RES) != 0) v += pr[i % NPRE][it];
           if (ok) {
             if constexpr ((EPI & F_CF32) != 0) st_stream((f32x4*)adr(cbase, g, p.ldc, 4, lo_c), v);
-            else st_stream((bf16x4*)adr(cbase, g, p.ldc, 2, lo_c), f4_to_bf4(v));
+            else st_stream((bf16x4*)adr(cbase, g, p.ldc, 2, lo_c), cvt_c<DT>(v));
             if constexpr ((EPI & F_C2) != 0) st_stream((bf16x4*)adr(c2base, g, p.ldc2, 2, lo_2), f4_to_bf4(v));
           }
         }
@@ -766,10 +791,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
         for (int e = 0; e < 4; ++e) if (e < nv) Cf[oc + e] = v[e];
       }
     } else {
-      if (full) st_stream((bf16x4*)(Cb + oc), f4_to_bf4(f32x4{v[0], v[1], v[2], v[3]}));
+      if (full) st_stream((bf16x4*)(Cb + oc), cvt_c<DT>(f32x4{v[0], v[1], v[2], v[3]}));
       else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) Cb[oc + e] = f2bf(v[e]);
+        for (int e = 0; e < 4; ++e) if (e < nv) {
+          if constexpr (DT == 2) ((h16*)Cb)[oc + e] = (h16)v[e]; else Cb[oc + e] = f2bf(v[e]);
+        }
       }
     }
     if (C2) {
@@ -803,19 +830,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
   }   // tile loop
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0, bool PERSIST = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0, bool PERSIST = false, int DT = 0>
 int launch(const Args& a, int batch, hipStream_t st) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2;
   // epilogue staging per wave: packed bf16 rows (one or two outputs) in the bf16-only lane, one f32 block otherwise
-  constexpr bool PACKED = EPI >= 0 && (EPI & (F_RES | F_MULZ | F_CF32 | F_C2)) == 0;
-  constexpr int EPI_WAVE = PACKED ? (((EPI & F_PREACT) != 0) ? 2 : 1) * 32 * (BN / WAVES_N * 2 + 16) : 32 * (BN / WAVES_N + 4) * 4;
+  constexpr bool PACKED = epi_packed(EPI, DT);
+  constexpr int EPI_WAVE = PACKED ? epi_outputs(EPI) * 32 * (BN / WAVES_N * 2 + 16) : 32 * (BN / WAVES_N + 4) * 4;
   constexpr int LDS_EPI = WAVES_M * WAVES_N * EPI_WAVE + (PERSIST ? (BM + BN) * 64 * 2 : 0);   // persistent: staging above buffer 0
   static_assert(LDS_EPI <= 160 * 1024, "epilogue staging does not fit next to the first K-tile buffer");
   constexpr int LDS = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
   static MartAttrOnce once;
   bool* attr_set = once.slot();
-  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, EPI, ACTK, PERSIST>;
+  auto kern = gemm_nt_kernel<BM, BN, WAVES_M, WAVES_N, PIPE, EPI, ACTK, PERSIST, DT>;
   if (!*attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       mart_set_error("gemm_nt: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -847,6 +874,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   MART_CHECK(d->act >= ACT_NONE && d->act <= ACT_QGELU, "gemm_nt: act must be NONE, GELU or QGELU");
   MART_CHECK(!d->preact_grad || (d->preact && d->act != ACT_NONE), "gemm_nt: preact_grad needs preact and an activation");
   MART_CHECK(d->mul_act >= ACT_NONE && d->mul_act <= ACT_STORED && (d->mul_act == ACT_NONE || d->mulz), "gemm_nt: bad mul_act");
+  MART_CHECK(!d->c_f16 || (d->in_f16 && !d->c_f32), "gemm_nt: c_f16 needs in_f16 and a 16-bit C");
+  MART_CHECK(!d->in_f16 || (!d->mulz && !d->res_bf16), "gemm_nt: fp16 operands are a forward-pass option (no mulz / bf16 residual)");
   MART_CHECK(!d->b_blocked || (d->N % 256 == 0 && !d->b_rows && (d->batch <= 1 || d->stride_b == 0)), "gemm_nt: b_blocked needs N % 256 == 0, no b_rows, shared B");
   MART_CHECK((long long)(d->a_rows ? d->a_src_rows : d->M) * d->lda < (1LL << 32) && (long long)(d->b_rows ? d->b_src_rows : d->N) * d->ldb < (1LL << 32),
              "gemm_nt: operand (or the table a row gather indexes: a_src_rows / b_src_rows) too large for 32-bit element offsets");
@@ -898,6 +927,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
                        ((uintptr_t)d->C % 16 == 0) && ((uintptr_t)d->res_f32 % 16 == 0) && ((uintptr_t)d->mulz % 8 == 0) &&
                        ((uintptr_t)d->preact % 8 == 0) && ((uintptr_t)d->C2 % 8 == 0) && ((uintptr_t)d->bias % 16 == 0) &&
                        ((uintptr_t)d->bias2 % 16 == 0) && (d->stride_c % 4 == 0) && (d->stride_aux % 4 == 0);
+  const int dt = d->in_f16 ? (d->c_f16 ? 2 : 1) : 0;
   const bool two_acts = d->mulz && d->act != ACT_NONE;               // not a fast combination
   const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->preact_grad ? F_PGRAD : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
                    (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
@@ -912,13 +942,13 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
     const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;
 #ifdef MART_EXPERIMENTS
 #define MART_FAST(M_, K_)                                                                   \
-    if (mask == (M_) && kind == (K_)) {                                                       \
+    if (dt == 0 && mask == (M_) && kind == (K_)) {                                                       \
       if (tile == 256 && !old_loop) return persist ? launch<256, 256, 2, 4, 2, (M_), (K_), true>(a, batch, st) : launch<256, 256, 2, 4, 2, (M_), (K_)>(a, batch, st); \
       if (persist) return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_), true>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_), true>(a, batch, st); \
       return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_)>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st); }
 #else
 #define MART_FAST(M_, K_)                                                                   \
-    if (mask == (M_) && kind == (K_)) {                                                       \
+    if (dt == 0 && mask == (M_) && kind == (K_)) {                                                       \
       if (tile == 256) return persist ? launch<256, 256, 2, 4, 2, (M_), (K_), true>(a, batch, st) : launch<256, 256, 2, 4, 2, (M_), (K_)>(a, batch, st); \
       return persist ? launch<128, 128, 2, 2, 0, (M_), (K_), true>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st); }
 #endif
@@ -937,7 +967,20 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
     MART_FAST(F_CF32 | F_ACT, ACT_GELU)           // head transform / precise-path GELU (f32 out)
     MART_FAST(F_CF32 | F_ACT, ACT_QGELU)
 #undef MART_FAST
+    // fp16 operands: the forward linear layers of the text stream (engine.text_f16)
+#define MART_FAST_H(M_, K_, DT_, P_)                                                           \
+    if (dt == (DT_) && mask == (M_) && kind == (K_)) {                                         \
+      if (tile == 256) return launch<256, 256, 2, 4, 2, (M_), (K_), (P_), (DT_)>(a, batch, st); \
+      return launch<128, 128, 2, 2, 0, (M_), (K_), (P_), (DT_)>(a, batch, st); }
+    MART_FAST_H(0, ACT_NONE, 1, true)                                 // Q/K/V (bf16 out, the attention kernels' operand type)
+    MART_FAST_H(F_CF32, ACT_NONE, 1, false)                           // attention.output.dense / output.dense: f32 into the LayerNorm
+    MART_FAST_H(F_CF32 | F_ACT, ACT_GELU, 1, false)                   // head transform
+    MART_FAST_H(F_PREACT | F_ACT | F_PGRAD | F_C2, ACT_GELU, 2, false)   // intermediate: fp16 GELU output + its bf16 copy + act'(z)
+    MART_FAST_H(F_ACT, ACT_GELU, 2, false)                            // ... under no_grad
+#undef MART_FAST_H
   }
+  if (dt == 1) return (cfg == 256 || cfg == 2561) ? launch<256, 256, 2, 4, 2, -1, 0, false, 1>(a, batch, st) : launch<128, 128, 2, 2, 0, -1, 0, false, 1>(a, batch, st);
+  if (dt == 2) return (cfg == 256 || cfg == 2561) ? launch<256, 256, 2, 4, 2, -1, 0, false, 2>(a, batch, st) : launch<128, 128, 2, 2, 0, -1, 0, false, 2>(a, batch, st);
   if ((cfg == 256 || cfg == 2561) && !old_loop) return launch<256, 256, 2, 4, 2>(a, batch, st);
 #ifdef MART_EXPERIMENTS
   if (cfg == 256 || cfg == 2561) return launch<256, 256, 2, 4>(a, batch, st);

@@ -134,11 +134,13 @@ __global__ __launch_bounds__(TPB) void adamw_k(mart_adamw_desc p) {
   for (int wi = blockIdx.x; wi < p.n_chunks * parts; wi += gridDim.x) {
     const int ci = wi / parts, part = wi % parts;
     const int start = p.chunks[3 * ci], len = p.chunks[3 * ci + 1];
-    const float wd = p.chunks[3 * ci + 2] ? p.weight_decay : 0.f;
+    const int flags = p.chunks[3 * ci + 2];
+    const float wd = (flags & 1) ? p.weight_decay : 0.f;
     const float decay = 1.f - p.lr * wd;
     const float step_size = p.lr / p.bc1;
     const float inv_sqrt_bc2 = rsqrtf(p.bc2);
     bf16* sh = (bf16*)p.shadow_bf16;
+    h16* sh16 = (flags & 2) ? (h16*)p.shadow_f16 : nullptr;       // fp16 forward shadow of the text-stream weights
     for (int base = part * ADAMW_PART; base < len; base += parts * ADAMW_PART)        // longer chunks (the ABI sets no limit): round-robin
     for (int i = base + threadIdx.x * 4, pend = min(len, base + ADAMW_PART); i < pend; i += TPB * 4) {
       const long long o = (long long)start + i;
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(TPB) void adamw_k(mart_adamw_desc p) {
         }
         *(f32x4*)(p.master + o) = w; *(f32x4*)(p.m + o) = m; *(f32x4*)(p.v + o) = v;
         if (sh) *(bf16x4*)(sh + o) = f4_to_bf4(w);
+        if (sh16) *(bf16x4*)(sh16 + o) = f4_to_h4raw(w);
       } else {
         for (int e = 0; e < len - i; ++e) {
           const float ge = p.grad[o + e] * p.grad_scale;
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(TPB) void adamw_k(mart_adamw_desc p) {
           w -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + p.eps);
           p.master[o + e] = w; p.m[o + e] = m; p.v[o + e] = v;
           if (sh) sh[o + e] = f2bf(w);
+          if (sh16) sh16[o + e] = (h16)w;
         }
       }
     }

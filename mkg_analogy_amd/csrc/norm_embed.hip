@@ -53,7 +53,7 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
         const int c = (v * 64 + lane) * 4;
         const long long o = (long long)m * p.H + c;
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (p.x_f32) t = ldx((const f32x4*)(p.x_f32 + o), (LN_NT & 1) != 0);
+        if (p.x_f32) t = ldx((const f32x4*)(p.x_f32 + (p.x_rows ? (long long)p.x_rows[m] * p.H + c : o)), (LN_NT & 1) != 0);
         if (yb) {
           f32x4 y = bf4_to_f4(ldx((const bf16x4*)(yb + o), (LN_NT & 1) != 0));
           if (p.p_drop > 0.f) {
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
         for (int e = 0; e < 4; ++e) y[e] = (x[v][e] - mean) * rstd * g[e] + b[e];
         if (p.out_f32) stx((f32x4*)(p.out_f32 + o), y, (LN_NT & 2) != 0);
         if (p.out_bf16) stx((bf16x4*)((bf16*)p.out_bf16 + o), f4_to_bf4(y), (LN_NT & 4) != 0);
+        if (p.out_f16) stx((bf16x4*)((bf16*)p.out_f16 + o), f4_to_h4raw(y), (LN_NT & 4) != 0);
       }
   }
 }
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(TPB) void text_embed_k(mart_text_embed_desc p) {
         if (p.p_drop > 0.f) y = y * dropout_scale4(p.seed, rng_seedmix(p.seed, 0), o, dropout_thr16(p.p_drop), inv_keep);
         if (p.out_f32) stx((f32x4*)(p.out_f32 + o), y, (LN_NT & 2) != 0);
         if (p.out_bf16) stx((bf16x4*)((bf16*)p.out_bf16 + o), f4_to_bf4(y), (LN_NT & 4) != 0);
+        if (p.out_f16) stx((bf16x4*)((bf16*)p.out_f16 + o), f4_to_h4raw(y), (LN_NT & 4) != 0);
       }
   }
 }
@@ -769,11 +771,12 @@ extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
   MART_CHECK(d && (d->x_f32 || d->y_bf16 || d->y_f32), "ln_fwd: need x_f32, y_bf16 or y_f32");
   MART_CHECK(!(d->y_bf16 && d->y_f32), "ln_fwd: y_bf16 and y_f32 are alternatives");
   MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_fwd: H must be a multiple of 256 and <= 1024");
-  MART_CHECK(d->gamma && d->beta && d->mean && d->rstd && (d->out_f32 || d->out_bf16), "ln_fwd: null pointer");
+  MART_CHECK(d->gamma && d->beta && d->mean && d->rstd && (d->out_f32 || d->out_bf16 || d->out_f16), "ln_fwd: null pointer");
+  MART_CHECK(!d->x_rows || d->x_f32, "ln_fwd: x_rows gathers x_f32");
   MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "ln_fwd: bad dropout p");
   static const int fast = getenv("MART_LN_FAST") ? atoi(getenv("MART_LN_FAST")) : 1;
   static const int fcap = getenv("MART_LN_FWD_GRID") ? atoi(getenv("MART_LN_FWD_GRID")) : 512;   // 6.15 TB/s (768 / 1024 / 2048: 5.8-5.95)
-  if (fast && d->x_f32 && !d->y_bf16 && !d->y_f32 && !d->s_out && !d->out_f32 && d->out_bf16 && d->p_drop == 0.f && (d->H == 768 || d->H == 1024) && d->M >= 4096) {
+  if (fast && d->x_f32 && !d->x_rows && !d->out_f16 && !d->y_bf16 && !d->y_f32 && !d->s_out && !d->out_f32 && d->out_bf16 && d->p_drop == 0.f && (d->H == 768 || d->H == 1024) && d->M >= 4096) {
     int g = (d->M + WPB - 1) / WPB;
     if (g > fcap) g = fcap;
     const int gmin = (d->M + WPB * 64 - 1) / (WPB * 64);          // at most 64 rows per wave (their statistics live in one register across the lanes)
@@ -817,7 +820,7 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
 extern "C" int mart_text_embed_fwd(const mart_text_embed_desc* d, void* stream) {
   MART_CHECK(d && d->ids && d->tt && d->word && d->pos && d->type && d->gamma && d->beta, "text_embed: null pointer");
   MART_CHECK(d->B > 0 && d->L > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "text_embed: bad shape");
-  MART_CHECK(d->mean && d->rstd && (d->out_f32 || d->out_bf16), "text_embed: null output");
+  MART_CHECK(d->mean && d->rstd && (d->out_f32 || d->out_bf16 || d->out_f16), "text_embed: null output");
   hipLaunchKernelGGL(text_embed_k, dim3(row_grid(d->B * d->L)), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
   return 0;

@@ -9,7 +9,7 @@ extern "C" void mart_set_error(const char* msg) {
   g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* mart_last_error(void) { return g_err; }
-extern "C" int mart_abi_version(void) { return 3; }   // round 3: mart_ln_fwd_desc.y_f32, mart_split_bf16x3*(terms), fp32 backward entry points
+extern "C" int mart_abi_version(void) { return 4; }   // round 4: fp16 forward operands (gemm_nt in_f16 / c_f16, *_f16 outputs, adamw shadow_f16), row-subset helpers
 extern "C" int mart_check_device(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { mart_set_error("no HIP device"); return -2; }
@@ -40,6 +40,51 @@ __global__ void cast_bf16_f32_k(const bf16* __restrict__ s, float* __restrict__ 
   long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4, stride = (long long)gridDim.x * TPB * 4;
   for (; i + 3 < n; i += stride) *(f32x4*)(d + i) = bf4_to_f4(*(const bf16x4*)(s + i));
   if (i < n && i + 3 >= n) for (long long j = i; j < n; ++j) d[j] = bf2f(s[j]);
+}
+__global__ void cast_f32_f16_k(const float* __restrict__ s, h16* __restrict__ d, long long n) {
+  long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4, stride = (long long)gridDim.x * TPB * 4;
+  for (; i + 3 < n; i += stride) *(bf16x4*)(d + i) = f4_to_h4raw(*(const f32x4*)(s + i));
+  if (i < n && i + 3 >= n) for (long long j = i; j < n; ++j) d[j] = (h16)s[j];
+}
+__global__ void cast_bf16_f16_k(const bf16* __restrict__ s, h16* __restrict__ d, long long n) {
+  long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4, stride = (long long)gridDim.x * TPB * 4;
+  for (; i + 3 < n; i += stride) *(bf16x4*)(d + i) = f4_to_h4raw(bf4_to_f4(*(const bf16x4*)(s + i)));
+  if (i < n && i + 3 >= n) for (long long j = i; j < n; ++j) d[j] = (h16)bf2f(s[j]);
+}
+// dst[r] = src[rows[r]] unless an earlier slot of the same group names the same row (then 0)
+__global__ void gather_rows_first_k(const float* __restrict__ src, int ld, const int32_t* __restrict__ rows, int group, float* __restrict__ dst, int R, int H) {
+  const int r = blockIdx.x, g0 = (r / group) * group, me = rows[r];
+  bool dup = false;
+  for (int i = g0; i < r; ++i) dup |= rows[i] == me;
+  const float* s = src + (long long)me * ld;
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4)
+    *(f32x4*)(dst + (long long)r * H + c) = dup ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(s + c);
+}
+// one workgroup per group, its slots applied in order.  ACC: dst[rows[r]] += src[r] (gradient rows; a row named twice receives both
+// contributions).  !ACC: dst[rows[r]] = src[r], the FIRST slot that names a row wins (forward values: the later slots of a repeated row
+// were computed under other dropout masks, and their gradient is dropped by gather_rows_first_k as well).
+template <bool DBF, bool ACC>
+__global__ void scatter_rows_k(const float* __restrict__ src, const int32_t* __restrict__ rows, int group, void* __restrict__ dst_, int ld, int R, int H) {
+  const int g0 = blockIdx.x * group;
+  for (int j = 0; j < group && g0 + j < R; ++j) {
+    const long long drow = (long long)rows[g0 + j] * ld;
+    bool seen = false;
+    if (!ACC) for (int i = 0; i < j; ++i) seen |= rows[g0 + i] == rows[g0 + j];
+    if (ACC || !seen)
+      for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+        f32x4 v = *(const f32x4*)(src + (long long)(g0 + j) * H + c);
+        if (DBF) {
+          bf16* d = (bf16*)dst_ + drow + c;
+          if (ACC) v += bf4_to_f4(*(const bf16x4*)d);
+          *(bf16x4*)d = f4_to_bf4(v);
+        } else {
+          float* d = (float*)dst_ + drow + c;
+          if (ACC) v += *(const f32x4*)d;
+          *(f32x4*)d = v;
+        }
+      }
+    __syncthreads();                                    // the next slot may name the same row: this slot's stores first
+  }
 }
 __global__ void cast_pad_k(const float* __restrict__ s, int lds_, bf16* __restrict__ d, int ldd, int R, int C) {
   const int r = blockIdx.x;
@@ -118,6 +163,40 @@ extern "C" int mart_cast_bf16_f32(const void* src, float* dst, long long n, void
   MART_CHECK(src && dst && n >= 0, "cast_bf16_f32: bad args");
   if (n == 0) return 0;
   hipLaunchKernelGGL(cast_bf16_f32_k, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)src, dst, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_cast_f32_f16(const float* src, void* dst, long long n, void* stream) {
+  MART_CHECK(src && dst && n >= 0, "cast_f32_f16: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_f32_f16_k, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, src, (h16*)dst, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_cast_bf16_f16(const void* src, void* dst, long long n, void* stream) {
+  MART_CHECK(src && dst && n >= 0, "cast_bf16_f16: bad args");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(cast_bf16_f16_k, dim3(grid_for(n, 4)), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)src, (h16*)dst, n);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_gather_rows_first_f32(const float* src, int ld, const int32_t* rows, int group, float* dst, int R, int H, void* stream) {
+  MART_CHECK(src && rows && dst && R > 0 && H > 0 && H % 4 == 0 && ld % 4 == 0 && group > 0 && group <= 64, "gather_rows_first_f32: bad args");
+  hipLaunchKernelGGL(gather_rows_first_k, dim3(R), dim3(192), 0, (hipStream_t)stream, src, ld, rows, group, dst, R, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_scatter_rows(const float* src, const int32_t* rows, int group, void* dst, int ld, int dst_bf16, int accumulate, int R, int H, void* stream) {
+  MART_CHECK(src && rows && dst && R > 0 && H > 0 && H % 4 == 0 && ld % 4 == 0 && group > 0 && group <= 64, "scatter_rows: bad args");
+  const dim3 g((R + group - 1) / group), b(192);
+  hipStream_t st = (hipStream_t)stream;
+  if (dst_bf16) {
+    if (accumulate) hipLaunchKernelGGL((scatter_rows_k<true, true>), g, b, 0, st, src, rows, group, dst, ld, R, H);
+    else hipLaunchKernelGGL((scatter_rows_k<true, false>), g, b, 0, st, src, rows, group, dst, ld, R, H);
+  } else {
+    if (accumulate) hipLaunchKernelGGL((scatter_rows_k<false, true>), g, b, 0, st, src, rows, group, dst, ld, R, H);
+    else hipLaunchKernelGGL((scatter_rows_k<false, false>), g, b, 0, st, src, rows, group, dst, ld, R, H);
+  }
   MART_LAUNCH_CHECK();
   return 0;
 }

@@ -130,3 +130,49 @@ def synthetic_wordpiece_vocab(texts, size: int = 30522):
     while len(vocab) < size:
         vocab.append(f"[unused{i}]"); i += 1
     return vocab
+
+
+def seeded_weights(named_shapes, seed: int = 0, conditioned: bool = False) -> Dict[str, torch.Tensor]:
+    """The seeded random-init weight set of the reference goldens G7 / G8: numpy PCG64 draws in ``named_parameters()`` order --
+    N(0, 0.02) matrices / embeddings / biases, LayerNorm weights 1 + 0.05 N(0,1), adaptive_weight = (0.25, 0.5).  ``conditioned``: the text value
+    projections of layers 8-11 scaled by 0.05, which takes the UNSCALED fusion softmax of those layers (modeling_unimo.py:405-410) out of its
+    one-hot, chaotic regime.  Every side (golden generator, CPU oracle, this package) regenerates the same tensors from the seed;
+    tests/test_host_logic_cpu.py holds this function to the oracle's bit for bit."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in named_shapes:
+        shape = tuple(shape)
+        if name.endswith("adaptive_weight.0"):
+            v = np.full(shape, 0.25, np.float32)
+        elif name.endswith("adaptive_weight.1"):
+            v = np.full(shape, 0.5, np.float32)
+        elif any(t in name for t in ("LayerNorm.weight", "layer_norm1.weight", "layer_norm2.weight", "layrnorm.weight", "layernorm.weight")):
+            v = (1.0 + 0.05 * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            v = (0.02 * rng.standard_normal(shape)).astype(np.float32)
+        out[name] = torch.from_numpy(v)
+    if conditioned:
+        for l in range(8, 12):
+            for k in ("weight", "bias"):
+                n = f"unimo.encoder.text_layer.{l}.attention.self.value.{k}"
+                out[n] = out[n] * 0.05
+    return out
+
+
+def load_seeded_weights(model, lit, seed: int = 0, conditioned: bool = False) -> None:
+    """Put ``seeded_weights`` into a finalized MKGformer model whose vocabulary already carries the [R] row (bench.py): the set is drawn for the
+    vocabulary WITHOUT [R] (as the goldens' generator loads it before ``_init_relation_word``); the [R] row is then rebuilt from the analogy
+    relation rows (lit_models/transformer.py:41-54) and its decoder-bias entry is zero (the zero-padded resize, modeling_unimo.py:915-930)."""
+    named = [(n, p.shape) for n, p in model.named_parameters()]
+    v0 = VOCAB - 1
+    shapes = [(n, ((v0,) + tuple(s[1:]) if n in ("unimo.text_embeddings.word_embeddings.weight", "cls.predictions.bias") else tuple(s))) for n, s in named]
+    sd = seeded_weights(shapes, seed, conditioned)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            src = sd[n].to(p.device)
+            if src.shape[0] != p.shape[0]:
+                p[:src.shape[0]].copy_(src)
+                p[src.shape[0]:].zero_()
+            else:
+                p.copy_(src)
+    lit._init_relation_word()                       # rebuilds the [R] row and refreshes the bf16 / fp16 / transposed shadows

@@ -21,7 +21,7 @@ import torch
 from . import ops
 from .params import FlatStore
 
-BF, F32 = torch.bfloat16, torch.float32
+BF, F32, HF = torch.bfloat16, torch.float32, torch.float16
 
 
 def _e(shape, dtype, dev):
@@ -74,16 +74,14 @@ class UnimoEngine:
         # two-term bf16 operand splits of the f32 text stream / f32 master weights (K' = 3K: hi*hi + lo*hi + hi*lo, csrc/precise.hip);
         # the backward pass is unchanged (bf16 operands).
         self.head_split = os.environ.get("MART_HEAD_SPLIT", "1") == "1"
-        # text_split: the linear layers of the TEXT stream (16 k of the 117 k rows of a step, 14 % of its FLOPs, but 58 % of the logit error
-        # variance on well-conditioned weights and ~80 % on plain N(0,0.02) weights, where layers 8-11 amplify whatever layers 0-7 rounded)
-        # run their FORWARD products on two-term splits: f32 layer inputs as [hi|lo|hi] x weights [hi|hi|lo] (K' = 3K), bf16-exact inputs
-        # (attention context, GELU output) against [hi] + [lo] weights as a dual-K product; their outputs reach the LayerNorms in f32.
-        # Backward pass unchanged (bf16 operands = the hi parts, read in place).  Costs 2.5x the text-stream forward GEMM FLOPs.
-        self.text_split = os.environ.get("MART_TEXT_SPLIT", "0") == "1"
-        # ... and by default for EVALUATION passes (eval mode under no_grad: validation / test ranking, lit_models/transformer.py:115-166):
-        # +14 % evaluation time (8486 -> 7444 examples/s) for logits 2x closer to the reference's (max 6.4e-3 vs 1.25e-2 on the conditioned
-        # golden); the training step keeps the plain bf16 text stream unless text_split is set.
-        self.text_split_eval = os.environ.get("MART_TEXT_SPLIT_EVAL", "1") == "1"
+        # text_f16: the FORWARD linear layers of the text stream (16 k of the 117 k rows of a step, 14 % of its FLOPs, but 58 % of the bf16 logit
+        # error variance on well-conditioned weights: tools/error_budget.py) multiply fp16 operands instead of bf16 ones -- the same MFMA rate
+        # (v_mfma_f32_32x32x16_f16), 11-bit instead of 8-bit significands, and post-LayerNorm activations / GELU outputs / N(0, 0.02)-scale
+        # weights sit well inside fp16's range.  The LayerNorms, the attention kernel, the fusion op and the GELU epilogue write fp16 twins
+        # of their outputs, AdamW keeps an fp16 shadow of the text weights, the dense outputs reach the LayerNorms in f32.  The backward
+        # pass is unchanged (bf16 operands: gradients need the range).  Replaces round 3's split-precision text stream (2.5x the text
+        # forward FLOPs for the same logit error).  MART_TEXT_F16=0: plain bf16 text stream (A/B).
+        self.text_f16 = os.environ.get("MART_TEXT_F16", "1") == "1"
         self._w3cache: Dict[str, tuple] = {}
 
     # ------------------------------------------------------------------ helpers
@@ -190,7 +188,12 @@ class UnimoEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train: bool, seed: int,
-                image_table=None, image_index=None):
+                image_table=None, image_index=None, rows=None):
+        """``rows`` (int32 [B, nr], flat row ids b * L + position): the caller promises to read only these rows of
+        ``trans_hidden_states`` (lit_models/transformer.py:94-95,103-107: the [MASK] row and four more per example).  Nothing else reads
+        the last text layer's other rows (modeling_unimo.py:616 exports the K/V of layers idx - 1 <= 10 only), so everything behind its
+        attention / fusion -- output projection, FFN, both LayerNorms, the head transform, and their backward -- runs on B * nr rows
+        instead of B * L.  Exact: the computed rows are what the dense pass computes; the returned tensor is zero elsewhere."""
         self._pass_begin()
         st, H, nh, I = self.st, self.H, self.nh, self.I
         dev = input_ids.device
@@ -205,6 +208,13 @@ class UnimoEngine:
         p_h = self.p_hidden if train else 0.0
         keep = bool(getattr(self, "save_for_backward", True))      # False under torch.no_grad(): backward-only outputs are skipped
         p_a = self.p_attn if train else 0.0
+        f16 = self.text_f16
+        R = nr = None
+        if rows is not None:
+            assert rows.dtype == torch.int32 and rows.dim() == 2 and rows.shape[0] == B and rows.is_contiguous()
+            R, nr = rows.view(-1), int(rows.shape[1])
+            sv["rows"] = (R, nr)
+        Mr = B * nr if nr else 0
         self._text_begin()                            # text stream starts behind whatever produced the inputs
 
         # ---- vision embeddings: patchify -> GEMM -> assemble(+cls,+pos) -> pre-LN    (modeling_unimo.py:119-132,711)
@@ -233,10 +243,11 @@ class UnimoEngine:
         with self._text_ctx():
             u = "unimo.text_embeddings."
             s_t, tmean, trstd = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
-            xt, xtb = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+            xt, xtb = _e((Mt, H), F32, dev), (_e((Mt, H), BF, dev) if keep or not f16 else None)
+            xth = _e((Mt, H), HF, dev) if f16 else None
             ops.text_embed_fwd(ids=input_ids, tt=token_type_ids, word=st.m(u + "word_embeddings.weight"), pos=st.m(u + "position_embeddings.weight"),
                                type_=st.m(u + "token_type_embeddings.weight"), gamma=st.m(u + "LayerNorm.weight"), beta=st.m(u + "LayerNorm.bias"),
-                               eps=self.eps_t, p_drop=p_h, seed=seed + 1, B=B, Lq=Lq, H=H, s_out=s_t, mean=tmean, rstd=trstd, out_f32=xt, out_bf16=xtb)
+                               eps=self.eps_t, p_drop=p_h, seed=seed + 1, B=B, Lq=Lq, H=H, s_out=s_t, mean=tmean, rstd=trstd, out_f32=xt, out_bf16=xtb, out_f16=xth)
             sv["temb"] = (s_t, tmean, trstd)
         if self.taps is not None:
             self.taps["vis_emb"] = xv.view(B, Nv, H).clone()
@@ -247,7 +258,7 @@ class UnimoEngine:
                 xv = self.inject["vis_emb"].reshape(Mv, H).to(device=dev, dtype=F32).contiguous()
             if "txt_emb" in self.inject:
                 xt = self.inject["txt_emb"].reshape(Mt, H).to(device=dev, dtype=F32).contiguous()
-                xtb = xt.to(BF)
+                xtb, xth = xt.to(BF), (xt.to(HF) if f16 else None)
 
         t_qkv_prev = None
         ev_tqkv = ev_vis = None
@@ -290,19 +301,18 @@ class UnimoEngine:
             # ================= text layer l (BertLayer.forward, modeling_unimo.py:540-577)
             with self._text_ctx():
                 t = f"unimo.encoder.text_layer.{l}."
-                split = self.text_split or (self.text_split_eval and not train and not keep)
+                sub = R is not None and l == self.n_layers - 1           # last layer: post-attention part on the requested rows only
                 tqkv = _e((Mt, 3 * H), BF, dev)
                 names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
                 qbias = st.fused([n + ".bias" for n in names], st.master)
-                if split:
-                    x3 = ops.split_bf16x3(xt, 0)                          # [hi|lo|hi]; the hi block doubles as the bf16 copy the backward pass reads
-                    xtb = x3[:, :H]
-                    ops.gemm_nt(x3, self._w3(*[n + ".weight" for n in names]), tqkv, bias=qbias)
+                if f16:
+                    ops.gemm_nt(xth, st.h(*[n + ".weight" for n in names]), tqkv, bias=qbias)
                 else:
                     ops.gemm_nt(xtb, st.fused([n + ".weight" for n in names]), tqkv, bias=qbias)
                 if l >= self.export_from:
                     ev_tqkv = self._text_record()
                 tctx, tlse = _e((Mt, H), BF, dev), _e((B, nh, Lq), F32, dev)
+                tctx_h = _e((Mt, H), HF, dev) if f16 else None
                 w0 = st.m(t + "attention.self.adaptive_weight.0")
                 w1 = st.m(t + "attention.self.adaptive_weight.1")
                 tkw = dict(q=tqkv[:, :H], k=tqkv[:, H:2 * H], v=tqkv[:, 2 * H:], ctx=tctx, lse=tlse, B=B, nh=nh, Sq=Lq, Sk=Lq, scale=0.125,
@@ -310,100 +320,111 @@ class UnimoEngine:
                            sep_stride=sep_idx.shape[1] if sep_idx is not None else 0,
                            w0=w0 if sep_idx is not None else None, w1=w1 if sep_idx is not None else None,
                            p_drop=p_a, seed=seed + 10 + 4 * l)
-                ops.attn_fwd(**tkw)
-                fus = probs = visT = None
+                ops.attn_fwd(ctx_f16=tctx_h, **tkw)
+                fus = fus_h = probs = visT = None
                 if l >= self.fuse_from:                                   # BertFusion.forward, modeling_unimo.py:400-414
                     self._text_wait(ev_vis)
                     probs, visT = _e((Mt, Nvp), BF, dev), None
-                    f3 = _e((Mt, 3 * H), BF, dev) if split else None      # [fus|fus|-]: bf16-exact operand of the dual-K product below
-                    fus = f3[:, :H] if split else _e((Mt, H), BF, dev)
+                    fus, fus_h = _e((Mt, H), BF, dev), (_e((Mt, H), HF, dev) if f16 else None)
                     if self.fused_fusion and ops.fusion_supported(Lq, Nv, H):
-                        ops.fusion_fwd(tctx, x2b, fus, probs, B, Lq, Nv, H)        # scores / softmax / probs @ visual in one kernel
+                        ops.fusion_fwd(tctx, x2b, fus, probs, B, Lq, Nv, H, out_f16=fus_h)   # scores / softmax / probs @ visual in one kernel
                     else:
                         scores = _e((Mt, Nvp), F32, dev)
                         ops.gemm_nt(tctx, x2b, scores, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
                         ops.softmax_fwd(scores, probs, Mt, Nv)
                         visT = _e((B * H, Nvp), BF, dev)
                         ops.transpose_bf16(x2b, visT, Nv, H, Nvp, batch=B, stride_i=Nv * H, stride_o=H * Nvp)
-                        fusc = _e((Mt, H), BF, dev) if split else fus
-                        ops.gemm_nt(probs, visT, fusc, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
-                        if split:
-                            fus.copy_(fusc)
-                    if split:
-                        f3[:, H:2 * H].copy_(fus)
+                        ops.gemm_nt(probs, visT, fus, M=Lq, N=H, batch=B, stride_a=Lq * Nvp, stride_b=H * Nvp, stride_c=Lq * H)
+                        if f16:
+                            ops.cast_bf16_f16(fus, fus_h)
+                # ---- from here on: Ms rows (all B * L, or the B * nr requested ones of the last layer, gathered by the GEMM / LayerNorm reads)
+                Ms, xr = (Mr, R) if sub else (Mt, None)
                 w, b = self._lin(t + "attention.output.dense")
-                s1, am1, ar1 = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
-                a, ab = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-                if split:
-                    w3 = self._w3(t + "attention.output.dense.weight")    # bf16-exact context: ctx x W_hi + ctx x W_lo as one dual-K product
-                    so = _e((Mt, H), F32, dev)
-                    ops.gemm_nt(tctx, w3[:, :H], so, A2=tctx, B2=w3[:, 2 * H:], bias=b)
-                    ops.ln_fwd(x_f32=xt, y_f32=so, p_drop=p_h, seed=seed + 11 + 4 * l, gamma=st.m(t + "attention.output.LayerNorm.weight"),
-                               beta=st.m(t + "attention.output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=am1, rstd=ar1, s_out=s1, out_f32=a)
-                    a3 = ops.split_bf16x3(a, 0)
-                    ab = a3[:, :H]
+                s1, am1, ar1 = _e((Ms, H), F32, dev), _e((Ms,), F32, dev), _e((Ms,), F32, dev)
+                a = _e((Ms, H), F32, dev)
+                ab = _e((Ms, H), BF, dev) if keep or not f16 else None     # bf16 copies: what the backward pass multiplies
+                ah = _e((Ms, H), HF, dev) if f16 else None
+                lnkw = dict(gamma=st.m(t + "attention.output.LayerNorm.weight"), beta=st.m(t + "attention.output.LayerNorm.bias"), eps=self.eps_t,
+                            M=Ms, H=H, mean=am1, rstd=ar1, s_out=s1, out_f32=a, out_bf16=ab, out_f16=ah, p_drop=p_h, seed=seed + 11 + 4 * l)
+                if f16:                                                   # dense outputs reach the LayerNorm in f32
+                    so = _e((Ms, H), F32, dev)
+                    ops.gemm_nt(tctx_h, st.h(t + "attention.output.dense.weight"), so, bias=b, a_rows=xr)
+                    ops.ln_fwd(x_f32=xt, x_rows=xr, y_f32=so, **lnkw)
                 else:
-                    so = _e((Mt, H), BF, dev)
-                    ops.gemm_nt(tctx, w, so, bias=b)
-                    ops.ln_fwd(x_f32=xt, y_bf16=so, p_drop=p_h, seed=seed + 11 + 4 * l, gamma=st.m(t + "attention.output.LayerNorm.weight"),
-                               beta=st.m(t + "attention.output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=am1, rstd=ar1, s_out=s1, out_f32=a, out_bf16=ab)
-                zt, ht = (_e((Mt, I), BF, dev) if keep else None), _e((Mt, I), BF, dev)
+                    so = _e((Ms, H), BF, dev)
+                    ops.gemm_nt(tctx, w, so, bias=b, a_rows=xr)
+                    ops.ln_fwd(x_f32=xt, x_rows=xr, y_bf16=so, **lnkw)
+                fus_s, fus_sh = fus, fus_h
+                if sub and fus is not None:                               # the fusion rows of the requested positions, compact
+                    if keep or not f16:
+                        fus_s = _e((Ms, H), BF, dev)
+                        ops.gather_rows_bf16(fus, R, fus_s)
+                    if f16:
+                        fus_sh = _e((Ms, H), HF, dev)
+                        ops.gather_rows_bf16(fus_h, R, fus_sh)            # (a 2-byte row copy: the element type does not matter)
+                zt = _e((Ms, I), BF, dev) if keep else None
                 w, b = self._lin(t + "intermediate.dense")
-                if split:
-                    wi3 = self._w3(t + "intermediate.dense.weight")
+                bf_ = st.m(t + "intermediate.fusion_dense.bias") if fus is not None else None
+                s2, om, orr = _e((Ms, H), F32, dev), _e((Ms,), F32, dev), _e((Ms,), F32, dev)
+                xo = _e((Ms, H), F32, dev)
+                xob = _e((Ms, H), BF, dev) if keep or not f16 or not self.head_split else None
+                xoh = _e((Ms, H), HF, dev) if f16 and l < self.n_layers - 1 else None    # (the head transform reads the f32 stream)
+                lnkw = dict(gamma=st.m(t + "output.LayerNorm.weight"), beta=st.m(t + "output.LayerNorm.bias"), eps=self.eps_t,
+                            M=Ms, H=H, mean=om, rstd=orr, s_out=s2, out_f32=xo, out_bf16=xob, out_f16=xoh, p_drop=p_h, seed=seed + 12 + 4 * l)
+                if f16:
+                    hth, ht = _e((Ms, I), HF, dev), (_e((Ms, I), BF, dev) if keep else None)   # GELU output: fp16 for the next product, bf16 for the backward pass
+                    ops.gemm_nt(ah, st.h(t + "intermediate.dense.weight"), hth, A2=fus_sh,
+                                B2=st.h(t + "intermediate.fusion_dense.weight") if fus is not None else None,
+                                bias=b, bias2=bf_, act=ops.ACT_GELU, preact=zt, preact_grad=keep, C2=ht)
+                    oo = _e((Ms, H), F32, dev)
+                    ops.gemm_nt(hth, st.h(t + "output.dense.weight"), oo, bias=st.m(t + "output.dense.bias"))
+                    ops.ln_fwd(x_f32=a, y_f32=oo, **lnkw)
+                else:
+                    ht = _e((Ms, I), BF, dev)
                     if fus is not None:
-                        wf3 = self._w3(t + "intermediate.fusion_dense.weight")
-                        bf_ = st.m(t + "intermediate.fusion_dense.bias")
-                        ops.gemm_nt(a3, wi3, ht, A2=f3[:, :2 * H], B2=wf3[:, H:], bias=b, bias2=bf_, act=ops.ACT_GELU, preact=zt, preact_grad=keep)
+                        wf, _ = self._lin(t + "intermediate.fusion_dense")
+                        ops.gemm_nt(ab, w, ht, A2=fus_s, B2=wf, bias=b, bias2=bf_, act=ops.ACT_GELU, preact=zt, preact_grad=keep)
                     else:
-                        ops.gemm_nt(a3, wi3, ht, bias=b, act=ops.ACT_GELU, preact=zt, preact_grad=keep)
-                elif fus is not None:
-                    wf, bf_ = self._lin(t + "intermediate.fusion_dense")
-                    ops.gemm_nt(ab, w, ht, A2=fus, B2=wf, bias=b, bias2=bf_, act=ops.ACT_GELU, preact=zt, preact_grad=keep)
-                else:
-                    ops.gemm_nt(ab, w, ht, bias=b, act=ops.ACT_GELU, preact=zt, preact_grad=keep)
-                w, b = self._lin(t + "output.dense")
-                s2, om, orr = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
-                xo, xob = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-                if split:
-                    w3 = self._w3(t + "output.dense.weight")
-                    oo = _e((Mt, H), F32, dev)
-                    ops.gemm_nt(ht, w3[:, :I], oo, A2=ht, B2=w3[:, 2 * I:], bias=b)
-                    ops.ln_fwd(x_f32=a, y_f32=oo, p_drop=p_h, seed=seed + 12 + 4 * l, gamma=st.m(t + "output.LayerNorm.weight"),
-                               beta=st.m(t + "output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=om, rstd=orr, s_out=s2, out_f32=xo, out_bf16=xob)
-                else:
-                    oo = _e((Mt, H), BF, dev)
+                        ops.gemm_nt(ab, w, ht, bias=b, act=ops.ACT_GELU, preact=zt, preact_grad=keep)
+                    w, b = self._lin(t + "output.dense")
+                    oo = _e((Ms, H), BF, dev)
                     ops.gemm_nt(ht, w, oo, bias=b)
-                    ops.ln_fwd(x_f32=a, y_bf16=oo, p_drop=p_h, seed=seed + 12 + 4 * l, gamma=st.m(t + "output.LayerNorm.weight"),
-                               beta=st.m(t + "output.LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=om, rstd=orr, s_out=s2, out_f32=xo, out_bf16=xob)
-                sv[f"t{l}"] = dict(xb=xtb, qkv=tqkv, ctx=tctx, lse=tlse, tkw=tkw, fus=fus, probs=probs, visT=visT, visb=x2b,
-                                   s1=s1, m1=am1, r1=ar1, ab=ab, zt=zt, ht=ht, s2=s2, m2=om, r2=orr)
-                xt, xtb = xo, xob
+                    ops.ln_fwd(x_f32=a, y_bf16=oo, **lnkw)
+                sv[f"t{l}"] = dict(xb=xtb, qkv=tqkv, ctx=tctx, lse=tlse, tkw=tkw, fus=fus_s if fus is not None else None, probs=probs, visT=visT, visb=x2b,
+                                   s1=s1, m1=am1, r1=ar1, ab=ab, zt=zt, ht=ht, s2=s2, m2=om, r2=orr, sub=sub)
+                xt, xtb, xth = xo, xob, xoh
             t_qkv_prev = tqkv if l >= self.export_from else None
             if self.taps is not None:
                 self.taps[f"vis{l}"] = xv.view(B, Nv, H).clone()
-                self.taps[f"txt{l}"] = xt.view(B, Lq, H).clone()
+                if xt.shape[0] == Mt:
+                    self.taps[f"txt{l}"] = xt.view(B, Lq, H).clone()
             if self.inject is not None:
                 if f"vis{l}" in self.inject:
                     xv = self.inject[f"vis{l}"].reshape(Mv, H).to(device=dev, dtype=F32).contiguous()
                 if f"txt{l}" in self.inject:
                     xt = self.inject[f"txt{l}"].reshape(Mt, H).to(device=dev, dtype=F32).contiguous()
-                    xtb = xt.to(BF)
+                    xtb, xth = xt.to(BF), (xt.to(HF) if f16 else None)
 
         # ---- MLM head transform (BertPredictionHeadTransform.forward, modeling_unimo.py:972-975)
         with self._text_ctx():
             hp = "cls.predictions.transform."
-            y, zh = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
+            Mh = xt.shape[0]                                # B * L, or the B * nr requested rows
+            y, zh = _e((Mh, H), F32, dev), _e((Mh, H), BF, dev)
             w, b = self._lin(hp + "dense")
             if self.head_split:
                 ops.gemm_nt(ops.split_bf16x3(xt, 0), self._w3(hp + "dense.weight"), y, bias=b, act=ops.ACT_GELU, preact=zh)
             else:
                 ops.gemm_nt(xtb, w, y, bias=b, act=ops.ACT_GELU, preact=zh)
-            trans, transb = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-            hm, hr = _e((Mt,), F32, dev), _e((Mt,), F32, dev)
-            ops.ln_fwd(x_f32=y, gamma=st.m(hp + "LayerNorm.weight"), beta=st.m(hp + "LayerNorm.bias"), eps=self.eps_t, M=Mt, H=H, mean=hm, rstd=hr,
-                       out_f32=trans, out_bf16=transb)
+            trans, transb = _e((Mh, H), F32, dev), _e((Mh, H), BF, dev)
+            hm, hr = _e((Mh,), F32, dev), _e((Mh,), F32, dev)
+            ops.ln_fwd(x_f32=y, gamma=st.m(hp + "LayerNorm.weight"), beta=st.m(hp + "LayerNorm.bias"), eps=self.eps_t, M=Mh, H=H, mean=hm, rstd=hr,
+                       out_f32=trans, out_bf16=transb if Mh == Mt else None)
             sv["head"] = (xtb, y, zh, hm, hr)
+            if Mh != Mt:                                    # the reference's [B, L, H] tensor with the requested rows filled in
+                tc = trans
+                trans, transb = torch.zeros((Mt, H), device=dev, dtype=F32), torch.zeros((Mt, H), device=dev, dtype=BF)
+                ops.scatter_rows(tc, R, nr, trans)
+                ops.scatter_rows(tc, R, nr, transb)
         self._text_done()
         if self._tstream is not None:                  # allocated on the text stream, consumed by the caller on the main stream
             trans.record_stream(torch.cuda.current_stream())
@@ -436,16 +457,22 @@ class UnimoEngine:
         self._text_begin()                                            # text stream starts behind the main stream (dtrans is ready)
         dtrans = dtrans.contiguous()
         self._text_uses(dtrans)
+        R, nr = sv.get("rows", (None, None))
         with self._text_ctx():
             xtb, y, zh, hm, hr = sv["head"]
             hp = "cls.predictions.transform."
-            dyb = _e((Mt, H), BF, dev)
-            ops.ln_bwd(dy_f32=dtrans.contiguous().view(Mt, H), s=y, mean=hm, rstd=hr, gamma=st.m(hp + "LayerNorm.weight"), M=Mt, H=H, ds_bf16=dyb,
+            Mh = y.shape[0]                                               # B * L, or the B * nr rows the forward pass was asked for
+            dtr = dtrans.view(Mt, H)
+            if Mh != Mt:                                                  # gradient of the requested rows (a row requested twice: taken once)
+                dtr = _e((Mh, H), F32, dev)
+                ops.gather_rows_first_f32(dtrans.view(Mt, H), R, nr, dtr)
+            dyb = _e((Mh, H), BF, dev)
+            ops.ln_bwd(dy_f32=dtr, s=y, mean=hm, rstd=hr, gamma=st.m(hp + "LayerNorm.weight"), M=Mh, H=H, ds_bf16=dyb,
                        dgamma=st.g(hp + "LayerNorm.weight"), dbeta=st.g(hp + "LayerNorm.bias"))
-            dzh = _e((Mt, H), BF, dev)
+            dzh = _e((Mh, H), BF, dev)
             ops.act_bwd(dyb, zh, ops.ACT_GELU, dzh)
             self._wgrad(dzh, xtb, hp + "dense.weight", hp + "dense.bias")
-            d_f32 = _e((Mt, H), F32, dev)                                 # gradient w.r.t. the text stream, f32 part
+            d_f32 = _e((Mh, H), F32, dev)                                 # gradient w.r.t. the text stream, f32 part
             ops.gemm_nt(dzh, st.wt("head"), d_f32)
             d_b16 = None                                                  # ... plus an optional bf16 part
         if self.grad_ready is not None:
@@ -459,7 +486,7 @@ class UnimoEngine:
         for l in reversed(range(self.n_layers)):
             # ================= text layer l
             dxvb_fresh = False
-            if self.taps is not None:
+            if self.taps is not None and d_f32.shape[0] == Mt:
                 self.taps[f"dtxt{l}"] = (d_f32 + d_b16.float() if d_b16 is not None else d_f32.clone()).view(B, Lq, H)
             if self.inject_grad is not None and f"txt{l}" in self.inject_grad:
                 d_f32, d_b16 = self.inject_grad[f"txt{l}"].reshape(Mt, H).to(device=dev, dtype=F32).contiguous(), None
@@ -467,21 +494,29 @@ class UnimoEngine:
                 t = f"unimo.encoder.text_layer.{l}."
                 s = sv[f"t{l}"]
                 fused = s["fus"] is not None
-                ds2, doo = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-                ops.ln_bwd(dy_f32=d_f32, dy_bf16=d_b16, s=s["s2"], mean=s["m2"], rstd=s["r2"], gamma=st.m(t + "output.LayerNorm.weight"), M=Mt, H=H,
+                sub = bool(s["sub"])                                      # the post-attention part of this layer ran on the requested rows only
+                Ms = d_f32.shape[0] if sub else Mt
+                ds2, doo = _e((Ms, H), F32, dev), _e((Ms, H), BF, dev)
+                ops.ln_bwd(dy_f32=d_f32, dy_bf16=d_b16, s=s["s2"], mean=s["m2"], rstd=s["r2"], gamma=st.m(t + "output.LayerNorm.weight"), M=Ms, H=H,
                            ds_f32=ds2, ds_bf16=doo, p_drop=p_h, seed=seed + 12 + 4 * l,
                            dgamma=st.g(t + "output.LayerNorm.weight"), dbeta=st.g(t + "output.LayerNorm.bias"))
                 self._wgrad(doo, s["ht"], t + "output.dense.weight", t + "output.dense.bias")
-                dzt = _e((Mt, I), BF, dev)
+                dzt = _e((Ms, I), BF, dev)
                 ops.gemm_nt(doo, st.wt(f"t{l}.out"), dzt, mulz=s["zt"], mul_act=ops.ACT_STORED)
                 self._wgrad(dzt, s["ab"], t + "intermediate.dense.weight", t + "intermediate.dense.bias")
-                da2 = _e((Mt, H), BF, dev)
+                da2 = _e((Ms, H), BF, dev)
                 ops.gemm_nt(dzt, st.wt(f"t{l}.int"), da2)
                 dctx_fus = None
                 if fused:
                     self._wgrad(dzt, s["fus"], t + "intermediate.fusion_dense.weight", t + "intermediate.fusion_dense.bias")
-                    dfus = _e((Mt, H), BF, dev)
-                    ops.gemm_nt(dzt, st.wt(f"t{l}.fus"), dfus)
+                    if sub:                                                        # d(fusion_output) of the requested rows, zero elsewhere
+                        dfr = _e((Ms, H), F32, dev)
+                        ops.gemm_nt(dzt, st.wt(f"t{l}.fus"), dfr)
+                        dfus = torch.zeros((Mt, H), device=dev, dtype=BF)
+                        ops.scatter_rows(dfr, R, nr, dfus, accumulate=True)
+                    else:
+                        dfus = _e((Mt, H), BF, dev)
+                        ops.gemm_nt(dzt, st.wt(f"t{l}.fus"), dfus)
                     if s["visT"] is None:                                          # fused kernel ran forward: its backward twin
                         dctx_fus = _e((Mt, H), BF, dev)
                         self._text_wait(ev_vdone)                                  # dxv holds the gradient left by vision layer l+1
@@ -514,13 +549,22 @@ class UnimoEngine:
                             ops.gemm_tn(dsc, s["ctx"], dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
                             ops.gemm_tn(s["probs"], dfus, dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
                     ev_tfus = self._text_record()
-                ds1, dso = _e((Mt, H), F32, dev), _e((Mt, H), BF, dev)
-                ops.ln_bwd(dy_f32=ds2, dy_bf16=da2, s=s["s1"], mean=s["m1"], rstd=s["r1"], gamma=st.m(t + "attention.output.LayerNorm.weight"), M=Mt, H=H,
+                ds1, dso = _e((Ms, H), F32, dev), _e((Ms, H), BF, dev)
+                ops.ln_bwd(dy_f32=ds2, dy_bf16=da2, s=s["s1"], mean=s["m1"], rstd=s["r1"], gamma=st.m(t + "attention.output.LayerNorm.weight"), M=Ms, H=H,
                            ds_f32=ds1, ds_bf16=dso, p_drop=p_h, seed=seed + 11 + 4 * l,
                            dgamma=st.g(t + "attention.output.LayerNorm.weight"), dbeta=st.g(t + "attention.output.LayerNorm.bias"))
-                self._wgrad(dso, s["ctx"], t + "attention.output.dense.weight", t + "attention.output.dense.bias")
-                dctx = _e((Mt, H), BF, dev)
-                ops.gemm_nt(dso, st.wt(f"t{l}.ao"), dctx, res_bf16=dctx_fus)
+                if sub:
+                    ctx_r = _e((Ms, H), BF, dev)
+                    ops.gather_rows_bf16(s["ctx"], R, ctx_r)
+                    self._wgrad(dso, ctx_r, t + "attention.output.dense.weight", t + "attention.output.dense.bias")
+                    dcr = _e((Ms, H), F32, dev)
+                    ops.gemm_nt(dso, st.wt(f"t{l}.ao"), dcr)
+                    dctx = dctx_fus if dctx_fus is not None else torch.zeros((Mt, H), device=dev, dtype=BF)
+                    ops.scatter_rows(dcr, R, nr, dctx, accumulate=True)    # bf16(f32 product + bf16 fusion part): the dense path's one rounding
+                else:
+                    self._wgrad(dso, s["ctx"], t + "attention.output.dense.weight", t + "attention.output.dense.bias")
+                    dctx = _e((Mt, H), BF, dev)
+                    ops.gemm_nt(dso, st.wt(f"t{l}.ao"), dctx, res_bf16=dctx_fus)
                 # attention backward; for layers whose (K,V) fed a vision layer the k/v blocks already hold the prefix grads
                 has_prefix_grad = self.export_from <= l < self.n_layers - 1
                 dqkv = s.get("dqkv")
@@ -537,7 +581,12 @@ class UnimoEngine:
                 self._tn(dqkv, s["xb"], gw, colsum=st.fused([n + ".bias" for n in names], st.grad))
                 dtb = _e((Mt, H), BF, dev)
                 ops.gemm_nt(dqkv, st.wt(f"t{l}.qkv"), dtb)
-                d_f32, d_b16 = ds1, dtb
+                if sub:                                                    # residual-path gradient of the requested rows into the [B * L, H] stream
+                    d_f32 = torch.zeros((Mt, H), device=dev, dtype=F32)
+                    ops.scatter_rows(ds1, R, nr, d_f32, accumulate=True)
+                    d_b16 = dtb
+                else:
+                    d_f32, d_b16 = ds1, dtb
 
             # ================= vision layer l
             if l >= self.fuse_from:

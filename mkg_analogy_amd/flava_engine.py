@@ -93,6 +93,7 @@ class FlavaEngine:
         self.eps = float(tc.layer_norm_eps)
         self.grad_ready: Optional[Callable[[int], None]] = None
         self.taps: Optional[dict] = None
+        self.head_split = os.environ.get("MART_HEAD_SPLIT", "1") == "1"   # head transform + scoring GEMM on two-term operand splits (engine.UnimoEngine.head_split)
 
     # ------------------------------------------------------------------ one pre-LN block
     def _layer_fwd(self, p: str, x, M: int, attn_kw: dict, want_bf16: bool):
@@ -215,7 +216,7 @@ class FlavaEngine:
             xm, _, sv[f"m{l}"] = self._layer_fwd(f"flava.multimodal_model.encoder.layer.{l}.", xm, Mm, mkw, False)
         # ---- final multimodal layernorm, text positions, MLM head transform (:1209, :2187-2188, :1676-1680)
         mm_b, mmean, mrstd = _e((Mm, H), BF, dev), _e((Mm,), F32, dev), _e((Mm,), F32, dev)
-        split = os.environ.get("MART_HEAD_SPLIT", "1") == "1"        # head transform on two-term operand splits (engine.UnimoEngine.head_split)
+        split = self.head_split
         mm_f = _e((Mm, H), F32, dev) if split else None
         ops.ln_fwd(x_f32=xm, gamma=st.m("flava.multimodal_model.layernorm.weight"), beta=st.m("flava.multimodal_model.layernorm.bias"),
                    eps=self.eps, M=Mm, H=H, mean=mmean, rstd=mrstd, out_bf16=mm_b, out_f32=mm_f)

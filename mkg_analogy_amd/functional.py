@@ -6,7 +6,7 @@ into ``FlatStore.grad`` (which ``p.grad`` views), the way fused wgrad accumulati
 """
 from __future__ import annotations
 
-import os
+import weakref
 from typing import Optional
 
 import torch
@@ -15,7 +15,6 @@ from . import ops
 
 BF, F32 = torch.bfloat16, torch.float32
 WORD, BIAS = "unimo.text_embeddings.word_embeddings.weight", "cls.predictions.bias"
-HEAD_SPLIT = os.environ.get("MART_HEAD_SPLIT", "1") == "1"       # see engine.UnimoEngine.head_split
 
 
 class _MKGformerFn(torch.autograd.Function):
@@ -23,9 +22,10 @@ class _MKGformerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
-                image_table=None, image_index=None):
+                image_table=None, image_index=None, rows=None):
+        kw = {} if rows is None else dict(rows=rows)          # last-layer row subset (engine.UnimoEngine.forward)
         trans, transb, sv = engine.forward(input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed,
-                                           image_table=image_table, image_index=image_index)
+                                           image_table=image_table, image_index=image_index, **kw)
         ctx.engine, ctx.sv = engine, sv
         holder["trans_bf16"] = transb
         return trans
@@ -36,22 +36,28 @@ class _MKGformerFn(torch.autograd.Function):
         if sv is None:
             raise RuntimeError("MKGformer backward called twice (activations are freed after the first pass)")
         ctx.engine.backward(sv, dtrans)
-        return (None,) * 12
+        return (None,) * 13
 
 
-_UNIQUE_OK: dict = {}
+_UNIQUE_OK: dict = {}      # id(tensor) -> (weak reference to that tensor object, the _version it was checked at)
 
 
 def _require_unique(ids: torch.Tensor) -> None:
     """The deterministic weight-gradient reduction adds each scored vocabulary row with a plain read-modify-write
-    (mart_gemm_tn with a workspace: out_rows must not repeat); checked once per id tensor (one device sync)."""
-    key = (ids.data_ptr(), ids.numel(), ids._version)
-    if key not in _UNIQUE_OK:
-        if int(torch.unique(ids).numel()) != ids.numel():
-            raise ValueError("scored vocabulary ids must be unique (the tied-embedding gradient rows are scattered without atomics)")
-        if len(_UNIQUE_OK) > 64:
-            _UNIQUE_OK.clear()
-        _UNIQUE_OK[key] = True
+    (mart_gemm_tn with a workspace: out_rows must not repeat).  Ranges built by LazyRows from a slice are unique by construction
+    (``_mart_unique``); any other id tensor is checked (one device sync) once per tensor OBJECT and in-place version -- never per
+    address: the caching allocator hands the address of a freed id tensor to the next one."""
+    if getattr(ids, "_mart_unique", False):
+        return
+    hit = _UNIQUE_OK.get(id(ids))
+    if hit is not None and hit[0]() is ids and hit[1] == ids._version:
+        return
+    if int(torch.unique(ids).numel()) != ids.numel():
+        raise ValueError("scored vocabulary ids must be unique (the tied-embedding gradient rows are scattered without atomics)")
+    if len(_UNIQUE_OK) > 64:
+        for k in [k for k, (r, _) in _UNIQUE_OK.items() if r() is None]:
+            del _UNIQUE_OK[k]
+    _UNIQUE_OK[id(ids)] = (weakref.ref(ids), ids._version)
 
 
 class _ScoreFn(torch.autograd.Function):
@@ -59,12 +65,12 @@ class _ScoreFn(torch.autograd.Function):
     (modeling_unimo.py:958 restricted to what lit_models/transformer.py:75-95,131-160 actually read)."""
 
     @staticmethod
-    def forward(ctx, trans, transb, rows, ids, store, word_name=WORD, bias_name=BIAS):
+    def forward(ctx, trans, transb, rows, ids, store, word_name=WORD, bias_name=BIAS, head_split=True):
         R, A = rows.numel(), ids.numel()
         if trans.requires_grad:
             _require_unique(ids)
         out = torch.empty((R, A), device=trans.device, dtype=F32)
-        if HEAD_SPLIT:
+        if head_split:
             # two-term bf16 splits of the f32 rows on both sides (K' = 3K, csrc/precise.hip): the scoring GEMM is ~0.01 % of the
             # step's FLOPs and was 16 % of the bf16 logit error variance (tools/error_budget.py)
             H = trans.shape[-1]
@@ -99,7 +105,7 @@ class _ScoreFn(torch.autograd.Function):
         trows = torch.empty((R, H), device=dev, dtype=BF)
         ops.gather_rows_bf16(transb, rows, trows)
         ops.gemm_tn(dl, trows, store.g(word_name), NX=A, out_rows=ids, colsum=store.g(bias_name), colsum_by_row=True)
-        return dtrans, None, None, None, None, None, None
+        return dtrans, None, None, None, None, None, None, None
 
 
 class _LSCEFn(torch.autograd.Function):
@@ -152,6 +158,14 @@ def relaxation_loss(trans: torch.Tensor, rel_idx: torch.Tensor, q_head_idx: torc
                             a_head_idx.to(torch.int64).contiguous())
 
 
+def token_positions(input_ids: torch.Tensor, token_id: int) -> torch.Tensor:
+    """First position of ``token_id`` in every row, int32 [B] on the device (-1: absent) -- ``(input_ids == id).nonzero()`` of
+    lit_models/transformer.py:94 without the host sync."""
+    pos = torch.empty(input_ids.shape[0], device=input_ids.device, dtype=torch.int32)
+    ops.find_token(input_ids.contiguous(), token_id, pos, None)
+    return pos
+
+
 def entity_ranks(logits: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
     """1 + #(logit > logit[label]); equals argsort(argsort(-logits))[label]+1 of lit_models/transformer.py:162-164
     whenever the label's logit is not tied."""
@@ -175,7 +189,9 @@ class LazyRows:
         dev = self.rows.device
         if isinstance(sel, slice):
             st, ed, step = sel.indices(self.owner.vocab)
-            return torch.arange(st, ed, step, device=dev, dtype=torch.int32)
+            ids = torch.arange(st, ed, step, device=dev, dtype=torch.int32)
+            ids._mart_unique = True                  # a range: no uniqueness check (and no device sync) needed
+            return ids
         if isinstance(sel, (list, tuple)):
             return torch.tensor(list(sel), device=dev, dtype=torch.int32)
         return sel.to(device=dev, dtype=torch.int32).contiguous()
@@ -190,15 +206,17 @@ class LazyRows:
             if o.trans.requires_grad and hasattr(o.precise, "score_train"):
                 return o.precise.score_train(o.trans, rows, self._ids(csel), o.word_name, o.bias_name)
             return o.precise.score(o.trans, rows, self._ids(csel), o.word_name, o.bias_name)
-        return _ScoreFn.apply(o.trans, o.trans_bf16, rows, self._ids(csel), o.store, o.word_name, o.bias_name)
+        return _ScoreFn.apply(o.trans, o.trans_bf16, rows, self._ids(csel), o.store, o.word_name, o.bias_name, o.head_split)
 
 
 class LazyLogits:
     """Stand-in for ``MaskedLMOutput.logits`` [B,L,V] (2.75 GB fp32 at B=256 in the reference, modeling_unimo.py:958).
     Indexing patterns used by the trainer surface are scored on demand; ``materialize()`` builds the full tensor."""
 
-    def __init__(self, trans: torch.Tensor, trans_bf16: torch.Tensor, store, word_name: str = WORD, bias_name: str = BIAS, precise=None):
+    def __init__(self, trans: torch.Tensor, trans_bf16: torch.Tensor, store, word_name: str = WORD, bias_name: str = BIAS, precise=None,
+                 head_split: bool = True):
         self.trans, self.trans_bf16, self.store = trans, trans_bf16, store
+        self.head_split = head_split                # the ENGINE's switch (one source of truth for the transform and the scoring GEMM)
         self.word_name, self.bias_name = word_name, bias_name
         self.precise = precise                      # engine_precise.PreciseUnimoForward: fp32-accurate scoring (eval only)
         self.vocab = store.slots[word_name].shape[0]
@@ -228,4 +246,5 @@ class LazyLogits:
         ids = torch.arange(self.vocab, device=self.trans.device, dtype=torch.int32)
         if self.precise is not None:
             return self.precise.score(self.trans, rows, ids, self.word_name, self.bias_name).view(B, L, self.vocab)
-        return _ScoreFn.apply(self.trans, self.trans_bf16, rows, ids, self.store, self.word_name, self.bias_name).view(B, L, self.vocab)
+        ids._mart_unique = True
+        return _ScoreFn.apply(self.trans, self.trans_bf16, rows, ids, self.store, self.word_name, self.bias_name, self.head_split).view(B, L, self.vocab)

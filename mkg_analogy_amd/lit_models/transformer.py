@@ -37,6 +37,10 @@ class TransformerLitModel(BaseLitModel):
         self.model.resize_token_embeddings(len(self.tokenizer))
         self.alpha = args.alpha
         self._ids_cache = {}
+        # tell the model which rows of trans_hidden_states this step reads ([MASK] + the four relaxation-loss rows): the last text layer and the
+        # head transform then run on those rows only (UnimoForMaskedLM.forward: needed_rows).  MART_LAST_ROWS=0: every row, as the reference.
+        import os
+        self.last_layer_rows = os.environ.get("MART_LAST_ROWS", "1") == "1"
 
     # -- lit_models/transformer.py:41-54
     def _init_relation_word(self):
@@ -62,6 +66,17 @@ class TransformerLitModel(BaseLitModel):
             self._ids_cache[key] = c
         return c
 
+    def _needed(self, input_ids, extra):
+        """kwargs for the model call: the token positions whose trans_hidden_states rows this step reads."""
+        if not self.last_layer_rows or not getattr(self.model, "accepts_needed_rows", False) or getattr(self.model, "precision", "bf16") != "bf16":
+            return {}
+        dev = self.model.store.device
+        cols = [Fn.token_positions(input_ids.to(dev, torch.int64), int(self.tokenizer.mask_token_id)).to(torch.int64)]
+        if extra is not None:
+            rel_idx, q_head_idx, a_head_idx = (t.to(dev, torch.int64) for t in extra)
+            cols += [rel_idx[:, 0], rel_idx[:, 1], q_head_idx, a_head_idx]
+        return dict(needed_rows=torch.stack(cols, 1))
+
     def _mask_rows(self, logits, input_ids):
         return logits.mask_rows(input_ids, int(self.tokenizer.mask_token_id))
 
@@ -74,7 +89,7 @@ class TransformerLitModel(BaseLitModel):
         q_head_idx = batch.pop("q_head_idx", None)
         a_head_idx = batch.pop("a_head_idx", None)
         input_ids = batch["input_ids"]
-        model_output = self.model(**batch, return_dict=True)
+        model_output = self.model(**batch, return_dict=True, **self._needed(input_ids, None if self.args.pretrain else (rel_idx, q_head_idx, a_head_idx)))
         logits = model_output[0].logits
         dev = logits.trans.device
         label = label.to(dev)
@@ -105,7 +120,7 @@ class TransformerLitModel(BaseLitModel):
         for k in ("rel_idx", "rel_label", "q_head_idx", "a_head_idx"):
             batch.pop(k, None)
         input_ids = batch["input_ids"]
-        model_output = self.model(**batch, return_dict=True)
+        model_output = self.model(**batch, return_dict=True, **self._needed(input_ids, None))
         logits = model_output[0].logits
         dev = logits.trans.device
         label = label.to(dev)

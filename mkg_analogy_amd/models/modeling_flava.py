@@ -219,8 +219,9 @@ class FlavaForMaskedLM(nn.Module):
         self.tie_weights()
         self._engine = FlavaEngine(self._store, c)
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
-        self._step = 0
-        self.base_seed = 0x5EED          # dropout stream; distributed.GradSync hashes the rank into it
+        if not hasattr(self, "base_seed"):       # a re-finalize (resize_token_embeddings) keeps the rank-hashed seed and the step counter
+            self._step = 0
+            self.base_seed = 0x5EED      # dropout stream; distributed.GradSync hashes the rank into it
         if not hasattr(self, "precision"):
             self.precision = "bf16"
         return self._store
@@ -282,7 +283,7 @@ class FlavaForMaskedLM(nn.Module):
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx,
                                       bool(self.training), (self.base_seed * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFF, holder)
         logits = Fn.LazyLogits(trans, holder["trans_bf16"], st, word_name="flava.text_model.embeddings.word_embeddings.weight",
-                               bias_name="cls.bias")
+                               bias_name="cls.bias", head_split=self._engine.head_split)
         loss = None
         if labels is not None:
             full = logits.materialize()

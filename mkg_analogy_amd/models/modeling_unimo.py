@@ -177,6 +177,8 @@ class MaskedLMOutput(SimpleNamespace):
 
 
 class UnimoForMaskedLM(nn.Module):
+    accepts_needed_rows = True                      # forward(needed_rows=...): last-layer row subset
+
     def __init__(self, vision_config, text_config):
         super().__init__()
         self.unimo = UnimoModel(vision_config, text_config)
@@ -288,7 +290,12 @@ class UnimoForMaskedLM(nn.Module):
 
     # ------------------------------------------------------------------ forward (modeling_unimo.py:848-893)
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None, head_mask=None, sep_idx=None,
-                pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None, labels=None, image_index=None):
+                pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None, labels=None, image_index=None,
+                needed_rows=None):
+        """``needed_rows`` (optional, int [B] or [B, n] token positions): a promise that only these rows of ``trans_hidden_states`` / ``logits`` will
+        be read (the trainer surface reads the [MASK] row and four more, lit_models/transformer.py:94-95,103-107).  The last text layer's
+        post-attention part and the head transform then run on those rows only; the returned ``trans_hidden_states`` is zero elsewhere.
+        Exact for the rows named; omit it to get every row as the reference does."""
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention maps / per-layer hidden states are not materialised by the fused HIP path")
         if position_ids is not None or head_mask is not None:
@@ -336,9 +343,13 @@ class UnimoForMaskedLM(nn.Module):
         seed = (self.base_seed * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFF
         holder: Dict[str, torch.Tensor] = {}
         self._engine.save_for_backward = torch.is_grad_enabled()
+        rows = None
+        if needed_rows is not None and labels is None:
+            nr_ = needed_rows.to(dev).reshape(B, -1).to(torch.int64).clamp_(0, L - 1)
+            rows = (torch.arange(B, device=dev, dtype=torch.int64)[:, None] * L + nr_).to(torch.int32).contiguous()
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
-                                      image_table, image_index)
-        logits = Fn.LazyLogits(trans, holder["trans_bf16"], st)
+                                      image_table, image_index, rows)
+        logits = Fn.LazyLogits(trans, holder["trans_bf16"], st, head_split=self._engine.head_split)
         loss = None
         if labels is not None:                      # CrossEntropyLoss over the full vocabulary (:880-882); not used by MarT
             full = logits.materialize()

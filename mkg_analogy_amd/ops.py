@@ -14,7 +14,7 @@ import torch
 from . import _lib as L
 
 ACT_NONE, ACT_GELU, ACT_QGELU, ACT_STORED = 0, 1, 2, 3      # ACT_STORED: mul_act only (mulz holds act'(z))
-BF16, F32 = torch.bfloat16, torch.float32
+BF16, F32, F16 = torch.bfloat16, torch.float32, torch.float16
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -41,9 +41,14 @@ def gemm_nt(A, B, out, *, A2=None, B2=None, a_rows=None, b_rows=None, M=None, N=
             bias_by_brow=False, act=ACT_NONE, preact=None, mulz=None, mul_act=ACT_NONE, res_f32=None, res_bf16=None,
             C2=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_aux=0, tile_cfg=0, b_blocked=False,
             preact_grad=False):
-    """out[M,N] = epi(A[M,K] @ B[N,K]^T (+ A2 @ B2^T)).  A/B are 2-D (row stride = ld) bf16; out bf16 or f32."""
+    """out[M,N] = epi(A[M,K] @ B[N,K]^T (+ A2 @ B2^T)).  A/B are 2-D (row stride = ld) bf16 -- or fp16, all of them (the forward
+    products of the text stream); out bf16 or f32, or fp16 with fp16 operands (C2 is then its bf16 copy)."""
     d = L.GemmNT()
     K = A.shape[-1]
+    d.in_f16 = int(A.dtype == F16)
+    assert B.dtype == A.dtype and (A2 is None or (A2.dtype == A.dtype and B2.dtype == A.dtype)), "gemm_nt operands must share one 16-bit type"
+    d.c_f16 = int(out.dtype == F16)
+    assert not d.c_f16 or d.in_f16, "an fp16 output needs fp16 operands"
     d.A, d.B, d.A2, d.B2 = _p(A), _p(B), _p(A2), _p(B2)
     d.lda, d.ldb = _rows2d(A), _rows2d(B)
     d.M = M if M is not None else (a_rows.numel() if a_rows is not None else A.shape[-2])
@@ -98,8 +103,9 @@ def gemm_tn(X, Y, out, *, M=None, NX=None, NY=None, out_rows=None, colsum=None, 
 
 
 def ln_fwd(*, x_f32=None, y_bf16=None, y_f32=None, gamma, beta, eps, M, H, mean, rstd, s_out=None, out_f32=None, out_bf16=None,
-           p_drop=0.0, seed=0):
+           p_drop=0.0, seed=0, out_f16=None, x_rows=None):
     d = L.LnFwd()
+    d.out_f16, d.x_rows = _p(out_f16), _p(x_rows)
     d.x_f32, d.y_bf16, d.p_drop, d.seed = _p(x_f32), _p(y_bf16), p_drop, seed
     d.y_f32 = _p(y_f32)
     d.gamma, d.beta, d.eps, d.M, d.H = _p(gamma), _p(beta), eps, M, H
@@ -146,8 +152,9 @@ def vision_assemble_bwd(ds, dpatch, dcls, dpos, B, P, H, tail_shift=0):
     L.check(L.lib().mart_vision_assemble_bwd(_p(ds), _p(dpatch), _p(dcls), _p(dpos), B, P, H, tail_shift, _stream()), "mart_vision_assemble_bwd")
 
 
-def text_embed_fwd(*, ids, tt, word, pos, type_, gamma, beta, eps, p_drop, seed, B, Lq, H, s_out, mean, rstd, out_f32, out_bf16):
+def text_embed_fwd(*, ids, tt, word, pos, type_, gamma, beta, eps, p_drop, seed, B, Lq, H, s_out, mean, rstd, out_f32, out_bf16, out_f16=None):
     d = L.TextEmbed()
+    d.out_f16 = _p(out_f16)
     d.ids, d.tt, d.word, d.pos, d.type = _p(ids), _p(tt), _p(word), _p(pos), _p(type_)
     d.gamma, d.beta, d.eps, d.p_drop, d.seed = _p(gamma), _p(beta), eps, p_drop, seed
     d.B, d.L, d.H = B, Lq, H
@@ -173,8 +180,10 @@ def text_embed_scatter(ds, ids, tt, dword, dpos, dtype, B, Lq, H):
 
 
 def _attn_desc(d, *, q, k, v, ctx, lse, B, nh, Sq, Sk, scale, pk=None, pv=None, Lp=0, attn_mask=None, sep=None,
-               sep_stride=0, w0=None, w1=None, p_drop=0.0, seed=0, rw_skip_row0=False):
+               sep_stride=0, w0=None, w1=None, p_drop=0.0, seed=0, rw_skip_row0=False, ctx_f16=None):
     d.q, d.k, d.v = _p(q), _p(k), _p(v)
+    d.ctx_f16 = _p(ctx_f16)
+    assert ctx_f16 is None or (_rows2d(ctx_f16) == _rows2d(ctx) and ctx_f16.dtype == F16)
     d.ldq, d.ldk, d.ldv = _rows2d(q), _rows2d(k), _rows2d(v)
     d.pk, d.pv, d.ldp, d.Lp = _p(pk), _p(pv), (_rows2d(pk) if pk is not None else 0), Lp
     d.B, d.nh, d.Sq, d.Sk, d.scale = B, nh, Sq, Sk, scale
@@ -293,9 +302,11 @@ def fusion_supported(Lq, Nv, H) -> bool:
     return bool(L.lib().mart_fusion_supported(int(Lq), int(Nv), int(H)))
 
 
-def fusion_fwd(q, v, out, probs, B, Lq, Nv, H):
+def fusion_fwd(q, v, out, probs, B, Lq, Nv, H, out_f16=None):
     """BertFusion forward in one kernel (modeling_unimo.py:400-414): out = softmax(q v^T) v, probs saved for the backward pass."""
     d = L.FusionFwd()
+    d.out_f16 = _p(out_f16)
+    assert out_f16 is None or (_rows2d(out_f16) == _rows2d(out) and out_f16.dtype == F16)
     d.q, d.ldq, d.v, d.ldv, d.out, d.ldo, d.probs, d.ldp = _p(q), _rows2d(q), _p(v), _rows2d(v), _p(out), _rows2d(out), _p(probs), _rows2d(probs)
     d.B, d.Lq, d.Nv, d.H = B, Lq, Nv, H
     L.check(L.lib().mart_fusion_fwd(C.byref(d), _stream()), "mart_fusion_fwd")
@@ -365,6 +376,28 @@ def cast_bf16_f32(src, dst):
     L.check(L.lib().mart_cast_bf16_f32(_p(src), _p(dst), src.numel(), _stream()), "mart_cast_bf16_f32")
 
 
+def cast_f32_f16(src, dst):
+    L.check(L.lib().mart_cast_f32_f16(_p(src), _p(dst), src.numel(), _stream()), "mart_cast_f32_f16")
+
+
+def cast_bf16_f16(src, dst):
+    L.check(L.lib().mart_cast_bf16_f16(_p(src), _p(dst), src.numel(), _stream()), "mart_cast_bf16_f16")
+
+
+def gather_rows_first_f32(src, rows, group, dst):
+    """dst[r] = src[rows[r]], or 0 where an earlier slot of the same group (``group`` consecutive entries = one example) names the same row."""
+    R, H = dst.shape
+    L.check(L.lib().mart_gather_rows_first_f32(_p(src), _rows2d(src), _p(rows), group, _p(dst), R, H, _stream()), "mart_gather_rows_first_f32")
+
+
+def scatter_rows(src, rows, group, dst, accumulate=False):
+    """dst[rows[r]] (+)= src[r] (src f32 [R,H]; dst f32 or bf16), the slots of a group applied in order by one workgroup (repeats allowed)."""
+    R, H = src.shape
+    assert src.dtype == F32 and dst.dtype in (F32, BF16)
+    L.check(L.lib().mart_scatter_rows(_p(src), _p(rows), group, _p(dst), _rows2d(dst), int(dst.dtype == BF16), int(accumulate), R, H, _stream()),
+            "mart_scatter_rows")
+
+
 def cast_pad_f32_bf16(src, dst, R, Cc):
     L.check(L.lib().mart_cast_pad_f32_bf16(_p(src), _rows2d(src), _p(dst), _rows2d(dst), R, Cc, _stream()), "mart_cast_pad_f32_bf16")
 
@@ -396,8 +429,9 @@ def dropout_mask(out_u8, p, seed):
     L.check(L.lib().mart_dropout_mask(_p(out_u8), out_u8.numel(), p, seed, _stream()), "mart_dropout_mask")
 
 
-def adamw(*, master, grad, m, v, shadow, chunks, n_chunks, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale=1.0):
+def adamw(*, master, grad, m, v, shadow, chunks, n_chunks, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale=1.0, shadow_f16=None):
     d = L.AdamW()
+    d.shadow_f16 = _p(shadow_f16)
     d.master, d.grad, d.m, d.v, d.shadow_bf16 = _p(master), _p(grad), _p(m), _p(v), _p(shadow)
     d.chunks, d.n_chunks = _p(chunks), n_chunks
     d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.bc1, d.bc2, d.grad_scale = lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale

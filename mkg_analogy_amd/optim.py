@@ -61,7 +61,8 @@ class FusedAdamW(torch.optim.Optimizer):
     def _launch(self, upto_chunk: int) -> None:
         store = self.model.store
         if upto_chunk > self._cursor:
-            ops.adamw(master=store.master, grad=store.grad, m=self.m, v=self.v, shadow=store.shadow, chunks=store.chunks[self._cursor:upto_chunk],
+            ops.adamw(master=store.master, grad=store.grad, m=self.m, v=self.v, shadow=store.shadow, shadow_f16=store.shadow_h,
+                      chunks=store.chunks[self._cursor:upto_chunk],
                       n_chunks=upto_chunk - self._cursor, **self._hp)
             self._cursor = upto_chunk
 

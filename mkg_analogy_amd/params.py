@@ -62,6 +62,13 @@ def layout_order(n_layers: int) -> List[str]:
 
 
 DEAD = ("unimo.vision_post_layernorm.", "unimo.text_pooler.")
+
+
+def text_f16_weight(name: str) -> bool:
+    """GEMM weights of the MKGformer text layers: the tensors that get an fp16 forward shadow (engine.text_f16)."""
+    return name.startswith("unimo.encoder.text_layer.") and name.endswith(".weight") and "LayerNorm" not in name
+
+
 PACK_WITH_PREV = ("adaptive_weight.1",)           # shares the 256-element slot of adaptive_weight.0 (contiguous [2])
 
 
@@ -86,8 +93,8 @@ def gemm_weight_names(n_layers: int) -> List[Tuple[str, Tuple[str, ...]]]:
 
 class FlatStore:
     def __init__(self, named_params: Dict[str, torch.nn.Parameter], n_layers: int, device: torch.device,
-                 order: Optional[List[str]] = None, gemm_groups=None, dead: Sequence[str] = DEAD):
-        """``order`` / ``gemm_groups`` / ``dead`` default to the MKGformer layout; other backbones (FLAVA) pass their own."""
+                 order: Optional[List[str]] = None, gemm_groups=None, dead: Sequence[str] = DEAD, f16_weight=text_f16_weight):
+        """``order`` / ``gemm_groups`` / ``dead`` / ``f16_weight`` default to the MKGformer layout; other backbones (FLAVA) pass their own."""
         order = layout_order(n_layers) if order is None else order
         gemm_groups = gemm_weight_names(n_layers) if gemm_groups is None else gemm_groups
         self.dead = tuple(dead)
@@ -110,6 +117,10 @@ class FlatStore:
         self.master = torch.zeros(off, device=device, dtype=torch.float32)
         self.grad = torch.zeros(off, device=device, dtype=torch.float32)
         self.shadow = torch.zeros(off, device=device, dtype=torch.bfloat16)
+        # fp16 shadow of the same layout, maintained for the tensors ``f16_weight`` selects (forward weights of the text stream: fp16 rounds 8x
+        # finer than bf16 at the same MFMA rate, and N(0, 0.02)-scale weights sit inside its range); the other positions are never read
+        self.f16_weight = f16_weight
+        self.shadow_h = torch.zeros(off, device=device, dtype=torch.float16)
         with torch.no_grad():
             for name, s in self.slots.items():
                 p = named_params[name]
@@ -157,6 +168,8 @@ class FlatStore:
             s = self.slots[name]
             n = s.numel + (1 if name.endswith("adaptive_weight.0") else 0)
             decay = 0 if any(nd in name for nd in NO_DECAY) else 1
+            if self.f16_weight is not None and self.f16_weight(name):
+                decay |= 2                                     # flag bit 1: AdamW refreshes the fp16 shadow of this chunk too
             for c0 in range(0, n, CH):
                 chunks.append([s.offset + c0, min(CH, n - c0), decay])
         self.chunks = torch.tensor(chunks, dtype=torch.int32, device=device)
@@ -175,6 +188,11 @@ class FlatStore:
         """bf16 shadow of a (2-D) tensor."""
         s = self.slots[name]
         return self.shadow[s.offset:s.offset + s.numel].view(s.shape)
+
+    def h(self, *names: str) -> torch.Tensor:
+        """fp16 shadow of one (or several adjacent) 2-D weights selected by ``f16_weight``."""
+        assert all(self.f16_weight(n) for n in names), names
+        return self.fused(list(names), self.shadow_h)
 
     def fused(self, names: Sequence[str], buf: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Adjacent tensors as one [sum(rows), ...] view of ``buf`` (default: bf16 shadow)."""
@@ -206,6 +224,7 @@ class FlatStore:
         from . import ops
         self.version += 1
         ops.cast_f32_bf16(self.master, self.shadow)
+        ops.cast_f32_f16(self.master, self.shadow_h)
         ops.transpose_table(self.shadow, self.shadow_t, self.ttable, self.ttable.shape[0])
 
     def refresh_transposed(self) -> None:

@@ -282,3 +282,17 @@ def test_rank_seed_is_a_hash_of_base_seed_and_rank():
                 v = (s * 1000003 + step * 7919) & 0x7FFFFFFFFFFF
                 assert (v + off) not in used
                 used.add(v + off)
+
+
+@pytest.mark.parametrize("cond", [False, True])
+def test_seeded_weights_equal_the_golden_generators_recipe(model, cond):
+    """bench.py regenerates the goldens' weight sets with data_synth.seeded_weights (the product never imports the oracle): same tensors, bit for
+    bit, as oracle.init_params (+ condition_weights), which is what oracle/gen_goldens_full.py loaded into the unmodified reference."""
+    from mkg_analogy_amd import data_synth as D
+    ref = O.init_params(O.VisionCfg(patch_size=32), O.TextCfg(vocab_size=100, max_position_embeddings=32), seed=3)
+    if cond:
+        ref = O.condition_weights(ref)
+    got = D.seeded_weights([(n, p.shape) for n, p in model.named_parameters()], seed=3, conditioned=cond)
+    assert list(got) == list(ref)
+    for n in ref:
+        assert torch.equal(got[n], ref[n]), n

@@ -8,9 +8,11 @@
   +   teacher-forced per-layer parity on PLAIN weights: every layer is fed the oracle's inputs and upstream gradients, so the
       reported error is that layer's own bf16 rounding and not the chaos of the unscaled fusion softmax downstream.
 
-Tolerances are ABSOLUTE on logits (north_star: 1e-3 fp32 / 1e-2 bf16).  What the bf16 training path actually meets is asserted
-and printed: rms <= 5e-3 and max <= 2.5e-2 on logits of magnitude ~2 (24 layers of bf16 rounding: the max over 66 016 logits
-sits at 4-5 sigma); the fp32-accurate evaluation path meets 1e-3 absolute on the same batch, plain weights included.
+Tolerances are ABSOLUTE on logits (north_star: 1e-3 fp32 / 1e-2 bf16) wherever the network is well conditioned: the DEFAULT
+training / evaluation configuration (vision stream bf16, text stream's forward products on fp16 operands, split-precision head) is
+held to max|dlogit| < 1e-2 against the reference on every conditioned golden (G7, G8, G8b) and on all 256 examples of the bench batch;
+the fp32-accurate path to 1e-3, plain weights included.  Plain N(0,0.02) weights are chaotic in the unscaled fusion softmax: bf16
+bounds there are multiples of the reference's own bf16-weight control, and the per-layer teacher-forced test carries the parity claim.
 """
 import argparse
 import math
@@ -52,9 +54,6 @@ def _product(g, pretrain=False):
     assert not unexpected and all(("position_ids" in m or "decoder" in m) for m in missing), (missing, unexpected)
     model.cuda()
     lit._init_relation_word()
-    # these tests measure the TRAINING configuration of the text stream (plain bf16) in their eval-mode forward passes too; the split-precision
-    # text stream that evaluation passes use by default (engine.text_split_eval) is switched on explicitly where it is the subject
-    model.engine.text_split_eval = False
     return model, lit, cfg
 
 
@@ -203,15 +202,15 @@ def test_finetune_step_vs_reference_at_bench_shape(tag):
     amb = ((ref_logits - lab[:, None]).abs() < 2 * e_l).sum(1).numpy() - 1
     assert np.all(np.abs(ev["entity_ranks"] - ref_ranks) <= amb), (ev["entity_ranks"], ref_ranks, amb)
     if cond:
-        # The bf16 floor at these weights is a NUMBER (round 3): the reference itself, fp32 math, with nothing but its weight matrices
-        # rounded to bf16 moves its logits by ctl (max 1.02e-2, rms 2.2e-3 -- already past north_star's 1e-2 in max norm).  The bf16
-        # training path (bf16 activations as well) is held to 1.5 x that control in both norms; tools/error_budget.py splits the
-        # distance by component, and test_text_split_mode_vs_reference below asserts north_star's absolute 1e-2 for the split-precision
-        # text stream.
+        # north_star's number, absolute: the default configuration (this is what bench.py times) within 1e-2 of the reference CPU path on
+        # every one of the 66 016 logits.  For scale: the reference itself, fp32 math, with nothing but its weight matrices rounded to bf16
+        # (the golden's control) moves them by max 1.02e-2 / rms 2.2e-3 -- the text stream's fp16 operands and the split-precision head put
+        # this path BELOW that control (tools/error_budget.py: text stream 58 % + head 36 % of the plain-bf16 error variance).
         c_l = float(np.abs(g["ctl::mask_logits"] - ref_logits.numpy()).max())
         c_rms = float(np.sqrt(((g["ctl::mask_logits"] - ref_logits.numpy()) ** 2).mean()))
         print(f"   control (reference, bf16-rounded weight matrices): max|dlogit| {c_l:.3e} rms {c_rms:.3e}  ->  bf16 path = {e_l / c_l:.2f} x / {rms / c_rms:.2f} x")
-        assert e_l <= 1.5 * c_l and rms <= 1.5 * c_rms, (e_l, c_l, rms, c_rms)
+        assert e_l < 1e-2, f"north_star: bf16 logits within 1e-2 of the reference CPU path (got {e_l:.3e})"
+        assert rms < c_rms, (rms, c_rms)
         assert r_t < 1.5e-2 and dl < 5e-3
         _grad_report(st, g, tol_rel=0.12, tol_cos=0.99, tol_norm=0.08)
     else:
@@ -287,13 +286,14 @@ def test_fp32_training_step_vs_reference(tag):
         assert worst < 1e-3 and rels[0][0] < 1e-3 and r_aw < 1e-3, (worst, worst_n, rels[:3], r_aw)
 
 
-def test_evaluation_default_is_the_split_precision_text_stream():
-    """Evaluation passes (eval mode under no_grad: validation / test ranking) run the text stream on operand splits by default
-    (engine.text_split_eval): identical to text_split=True, closer to the reference than the training-path forward; a forward that
-    saves activations for a backward pass (the training step) stays on the plain bf16 text stream."""
+def test_text_fp16_forward_vs_plain_bf16_text_stream():
+    """engine.text_f16 (default): the text stream's forward products on fp16 operands.  Against MART_TEXT_F16=0 (plain bf16 text stream) on the
+    conditioned G7 golden: closer to the reference, below north_star's 1e-2; the evaluation pass (no_grad) and a forward that saves
+    activations for a backward pass compute the same logits bit for bit (one configuration for training and evaluation)."""
     g = _load("g7_bench_cond")
     model, lit, cfg = _product(g)
     eng = model.engine
+    assert eng.text_f16 is True, "default: fp16 forward operands in the text stream"
     batch = _batch(g)
     B = int(g["B"])
     gb = {k: v.cuda() for k, v in batch.items()}
@@ -309,23 +309,21 @@ def test_evaluation_default_is_the_split_precision_text_stream():
             out, _ = model(**{k: gb[k] for k in keys}, return_dict=True)
             return out.logits[ar, rows[:, 0]][:, ids].detach().float().cpu()
 
-    plain = logits(False)                                 # _product switched the evaluation default off
-    eng.text_split_eval = True
     ev, tr = logits(False), logits(True)
-    eng.text_split, eng.text_split_eval = True, False
-    sp = logits(False)
-    eng.text_split = False
-    assert torch.equal(ev, sp), "evaluation default == text_split"
-    assert torch.equal(tr, plain), "a forward with saved activations keeps the training configuration"
-    e_ev, e_pl = float((ev - ref).abs().max()), float((plain - ref).abs().max())
-    print(f"\nevaluation default: max|dlogit| {e_ev:.3e} (plain bf16 text stream {e_pl:.3e})")
-    assert e_ev < 1e-2 and e_ev < e_pl
+    eng.text_f16 = False
+    plain = logits(False)
+    eng.text_f16 = True
+    assert torch.equal(ev, tr), "evaluation and training forward passes are one configuration"
+    stat = lambda x: (float((x - ref).abs().max()), float((x - ref).pow(2).mean().sqrt()))
+    (e_h, r_h), (e_p, r_p) = stat(ev), stat(plain)
+    print(f"\ntext stream fp16 operands: max|dlogit| {e_h:.3e} rms {r_h:.3e};  plain bf16 text stream: {e_p:.3e} / {r_p:.3e}")
+    assert e_h < 1e-2 and r_h < 0.75 * r_p, (e_h, r_h, r_p)
 
 
-def test_text_split_training_step_with_dropout_matches_the_plain_step():
-    """Train mode (dropout on): the split-precision text stream draws the SAME dropout masks as the plain bf16 text stream (the f32 branch of
-    mart_ln_fwd hashes the same element indices), so with equal seeds the two steps agree to bf16 rounding: loss within 2e-2, gradients
-    of the sampled tensors within 10 %, everything finite."""
+def test_text_fp16_training_step_with_dropout_matches_the_plain_step():
+    """Train mode (dropout on): the fp16 text stream draws the SAME dropout masks as the plain bf16 text stream (same seeds, same element
+    indices), so with equal seeds the two steps agree to bf16 rounding: loss within 2e-2, gradients of the sampled tensors within 10 %,
+    everything finite."""
     g = _load("g7_bench_cond")
     model, lit, cfg = _product(g)
     batch = _batch(g)
@@ -333,8 +331,8 @@ def test_text_split_training_step_with_dropout_matches_the_plain_step():
     st = model.store
     model.train()
     res = []
-    for split in (False, True):
-        model.engine.text_split = split
+    for f16 in (False, True):
+        model.engine.text_f16 = f16
         model._step = 100                                  # same dropout stream for both passes
         st.zero_grad()
         loss = lit.training_step(dict(gb), 1)
@@ -342,7 +340,6 @@ def test_text_split_training_step_with_dropout_matches_the_plain_step():
         torch.cuda.synchronize()
         assert bool(torch.isfinite(st.grad).all()) and bool(torch.isfinite(loss.detach()))
         res.append((float(loss.detach()), st.grad.clone()))
-    model.engine.text_split = False
     (l0, g0), (l1, g1) = res
     names = ["unimo.encoder.text_layer.0.attention.self.query.weight", "unimo.encoder.text_layer.11.output.dense.weight",
              "unimo.encoder.vision_layers.5.mlp.fc1.weight", "cls.predictions.transform.dense.weight", "unimo.text_embeddings.word_embeddings.weight"]
@@ -351,53 +348,57 @@ def test_text_split_training_step_with_dropout_matches_the_plain_step():
         sl = st.slots[n]
         a, b = g0[sl.offset:sl.offset + sl.numel], g1[sl.offset:sl.offset + sl.numel]
         worst = max(worst, float((a - b).norm() / a.norm()))
-    print(f"\ntrain-mode step, dropout on: loss plain {l0:.5f} split-precision text {l1:.5f}; worst gradient rel-L2 difference {worst:.3e}")
+    print(f"\ntrain-mode step, dropout on: loss plain bf16 text {l0:.5f} fp16 text {l1:.5f}; worst gradient rel-L2 difference {worst:.3e}")
     assert abs(l0 - l1) < 2e-2 and worst < 0.10
 
 
-@pytest.mark.parametrize("tag", ["g7_bench_cond", "g7_bench_plain"])
-def test_text_split_mode_vs_reference(tag):
-    """engine.text_split (MART_TEXT_SPLIT=1): the text stream's forward products on two-term operand splits.  Conditioned weights:
-    north_star's absolute 1e-2 on the bf16 path's logits, asserted as such (and the training step still matches the reference's
-    loss and gradients).  Plain weights: the same control-relative bounds as the default path (chaotic map: see the comment below)."""
+@pytest.mark.parametrize("tag,pre", [("g7_bench_cond", False), ("g7_bench_plain", False), ("g8_pretrain_cond", True)])
+def test_last_layer_row_subset_equals_the_dense_path(tag, pre):
+    """The trainer surface tells the model which rows of trans_hidden_states it reads (5 per example: [MASK] + the relaxation-loss rows; 1 for the
+    pre-train step) and the last text layer + head transform run on those rows only (engine.forward rows=...).  Exact by construction: loss
+    and ALL gradients equal the dense pass's (MART_LAST_ROWS=0) to rounding, the returned rows are the dense pass's rows, the others zero."""
     g = _load(tag)
-    cond = bool(int(g["conditioned"]))
-    model, lit, cfg = _product(g)
-    assert model.engine.text_split is False, "default is the plain bf16 text stream"
-    model.engine.text_split = True
-    batch = _batch(g)
-    B = int(g["B"])
+    model, lit, cfg = _product(g, pretrain=pre)
+    batch = _batch(g, pretrain=pre)
     gb = {k: v.cuda() for k, v in batch.items()}
-    ids = torch.tensor(cfg["analogy_entity_ids"], device="cuda")
-    ar = torch.arange(B, device="cuda")
-    rows = torch.from_numpy(g["trans_row_index"]).cuda()
-    ref_logits, ref_trans = torch.from_numpy(g["mask_logits"]), torch.from_numpy(g["trans_rows"])
-    model.eval()
-    with torch.no_grad():
-        out, trans = model(**{k: gb[k] for k in ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")}, return_dict=True)
-        ml = out.logits[ar, rows[:, 0]][:, ids].float().cpu()
-        tr = trans[ar[:, None], rows].float().cpu()
-    e_l, rms = float((ml - ref_logits).abs().max()), float((ml - ref_logits).pow(2).mean().sqrt())
-    c_l = float(np.abs(g["ctl::mask_logits"] - ref_logits.numpy()).max())
-    c_rms = float(np.sqrt(((g["ctl::mask_logits"] - ref_logits.numpy()) ** 2).mean()))
-    print(f"\n{tag} text_split: max|dlogit| {e_l:.3e} rms {rms:.3e}  (control {c_l:.3e} / {c_rms:.3e}); trans rows rel-L2 {_rel(tr.numpy(), ref_trans.numpy()):.3e}")
+    B, L = gb["input_ids"].shape
     st = model.store
-    st.zero_grad()
-    loss = lit.training_step(dict(gb), 1)
-    loss.backward()
-    torch.cuda.synchronize()
-    print(f"   loss hip {float(loss):.6f} reference {float(g['loss']):.6f}")
-    if cond:
-        assert e_l < 1e-2, "north_star: bf16 logits within 1e-2 of the reference CPU path"
-        assert rms < c_rms
-        assert abs(float(loss) - float(g["loss"])) < 5e-3
-        _grad_report(st, g, tol_rel=0.12, tol_cos=0.99, tol_norm=0.08)
-    else:
-        # plain weights: the map is chaotic (unscaled fusion softmax): one kernel revision of this mode landed BELOW the reference's own
-        # bf16-weight control (0.25 / 1.9e-2), the next one -- a re-associated row sum in the text softmax -- at the saturated level of the
-        # plain bf16 path (1.64 / 7.6e-2).  No mode short of fp32 everywhere is stable here; same bounds as the default path.
-        assert e_l < 5 * c_l + 1e-2 and rms < 4 * c_rms + 1e-2, (e_l, c_l, rms, c_rms)
-        _grad_report(st, g, tol_rel=0.03, tol_cos=0.0, tol_norm=0.03, ctl_mult=4.0)
+    model.eval()
+    assert lit.last_layer_rows is True
+    res = []
+    for on in (False, True):
+        lit.last_layer_rows = on
+        st.zero_grad()
+        loss = lit.training_step(dict(gb), 1)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss.detach()), st.grad.clone()))
+    (l0, g0), (l1, g1) = res
+    worst, wn = 0.0, ""
+    for n, sl in st.slots.items():
+        a, b = g0[sl.offset:sl.offset + sl.numel], g1[sl.offset:sl.offset + sl.numel]
+        na = float(a.norm())
+        if na < 1e-9:
+            assert float(b.abs().max()) == 0.0, n
+            continue
+        r = float((a - b).norm()) / na
+        if r > worst:
+            worst, wn = r, n
+    print(f"\n{tag}: loss dense {l0:.7f} row subset {l1:.7f}; worst gradient rel-L2 difference over {len(st.slots)} tensors {worst:.3e} ({wn})")
+    assert abs(l0 - l1) < 2e-6 * max(1.0, abs(l0)) and worst < 2e-3, (l0, l1, worst, wn)
+    # forward values: requested rows identical to the dense pass, the others zero
+    keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values") + (() if pre else ("sep_idx",))
+    need = torch.stack([gb["rel_idx"][:, 0], gb["rel_idx"][:, 1], gb["q_head_idx"]], 1) if not pre else (gb["input_ids"] == 103).int().argmax(1)[:, None]
+    need = torch.cat([need, need[:, :1]], 1)                     # a repeated position: computed twice, scattered once
+    with torch.no_grad():
+        _, dense = model(**{k: gb[k] for k in keys}, return_dict=True)
+        _, part = model(**{k: gb[k] for k in keys}, return_dict=True, needed_rows=need)
+    ar = torch.arange(B, device="cuda")[:, None]
+    d = float((dense[ar, need] - part[ar, need]).abs().max())
+    mask = torch.ones(B, L, dtype=torch.bool, device="cuda")
+    mask[ar, need] = False
+    print(f"   requested rows: max|dense - subset| {d:.3e}; other rows max {float(part[mask].abs().max()):.1e}")
+    assert d < 1e-5 and float(part[mask].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("tag", ["g8_pretrain_cond", "g8_pretrain_plain", "g8b_pretrain_p196_cond"])
@@ -411,17 +412,6 @@ def test_pretrain_step_vs_reference(tag):
     B = int(g["B"])
     gb = {k: v.cuda() for k, v in batch.items()}
     model.eval()
-    if cond:
-        # split-precision text stream (evaluation default): north_star's 1e-2 on the entity / relation logits of the pre-train heads too
-        model.engine.text_split = True
-        with torch.no_grad():
-            out_s, _ = model(**{k: gb[k] for k in ("input_ids", "attention_mask", "token_type_ids", "pixel_values")}, return_dict=True)
-            rows_s = out_s.logits.mask_rows(gb["input_ids"], 103)
-            es = float(np.abs(rows_s[:, BASE:BASE + NE].float().cpu().numpy() - g["entity_logits"]).max())
-            rs_ = float(np.abs(rows_s[:, BASE + NE:BASE + NE + NR].float().cpu().numpy() - g["relation_logits"]).max())
-        model.engine.text_split = False
-        print(f"\n{tag}: split-precision text stream: entity logits max|err| {es:.3e}, relation logits {rs_:.3e}")
-        assert es < 1e-2 and rs_ < 1e-2
     st = model.store
     st.zero_grad()
     loss = lit.training_step(dict(gb), 1)
@@ -458,8 +448,9 @@ def test_pretrain_step_vs_reference(tag):
         c_rms = float(np.sqrt(((g["ctl::entity_logits"] - g["entity_logits"]) ** 2).mean()))
         c_r = float(np.abs(g["ctl::relation_logits"] - g["relation_logits"]).max())
         print(f"   control: entity logits max {c_e:.3e} rms {c_rms:.3e}; relation logits max {c_r:.3e}")
-        # rms within 1.5 x the control; the maximum over 8 x 11 292 logits is a noisier statistic (1.26-1.58 x across kernel revisions): 2 x
-        assert rms <= 1.5 * c_rms and e_e <= 2.0 * c_e and e_r <= 2.0 * max(c_r, c_e), "within 1.5 x (rms) / 2 x (max) the reference's bf16-weight control"
+        # north_star's 1e-2, absolute, on both pre-train heads (default configuration); and below the reference's own bf16-weight control in rms
+        assert e_e < 1e-2 and e_r < 1e-2, f"north_star: bf16 logits within 1e-2 of the reference (entity {e_e:.3e}, relation {e_r:.3e})"
+        assert rms < c_rms, (rms, c_rms)
         assert r_e < 0.05 and r_r < 0.05 and r_b < 0.02
         _grad_report(st, g, tol_rel=0.12, tol_cos=0.99, tol_norm=0.08)
     else:
@@ -649,9 +640,9 @@ def test_full_bench_batch_forward_vs_oracle():
 
     ml = forward()
     e_l, rms = float((ml - ml_ref).abs().max()), float((ml - ml_ref).pow(2).mean().sqrt())
-    model.engine.text_split = True                              # split-precision text stream (MART_TEXT_SPLIT=1)
+    model.engine.text_f16 = False                               # plain bf16 text stream (MART_TEXT_F16=0), for scale
     mls = forward()
-    model.engine.text_split = False
+    model.engine.text_f16 = True
     e_s, rms_s = float((mls - ml_ref).abs().max()), float((mls - ml_ref).pow(2).mean().sqrt())
     model.set_precision("fp32")
     ml32 = forward()
@@ -665,11 +656,11 @@ def test_full_bench_batch_forward_vs_oracle():
     c_l, c_rms = float(ctl.abs().max()), float(ctl.pow(2).mean().sqrt())
     e_l32 = float((ml[:32] - ml_ref[:32]).abs().max())
     print(f"\nB=256 P=196: bf16 path max|dlogit| {e_l:.3e} (first 32 examples {e_l32:.3e}) rms {rms:.3e}  [control on the first 32: {c_l:.3e} / {c_rms:.3e}]; "
-          f"split-precision text stream max {e_s:.3e} rms {rms_s:.3e}; fp32-accurate path max|dlogit| {e32:.3e}, {same32}/256 ranks identical "
+          f"plain bf16 text stream max {e_s:.3e} rms {rms_s:.3e}; fp32-accurate path max|dlogit| {e32:.3e}, {same32}/256 ranks identical "
           f"(logit scale {float(ml_ref.abs().max()):.2f})")
     assert e32 < 1e-3
-    assert rms <= 1.5 * c_rms and e_l32 <= 1.5 * c_l and e_l < 2.5e-2, "bf16 path: within 1.5 x the reference's bf16-weight control"
-    assert e_s < 1e-2, "north_star's 1e-2 on bf16 logits (split-precision text stream), all 256 examples"
+    assert e_l < 1e-2, f"north_star's 1e-2 on bf16 logits, default configuration, all 256 examples x 2063 entities (got {e_l:.3e})"
+    assert rms < c_rms and rms < rms_s, (rms, c_rms, rms_s)
     lab = ml_ref[torch.arange(B), batch["label"]]
     near = ((ml_ref - lab[:, None]).abs() < 2 * e32).sum(1) - 1
     assert bool(((rank(ml32) - rank(ml_ref)).abs() <= near).all())

@@ -69,10 +69,10 @@ def main():
     print(f"{tag}: logit scale {float(ref.abs().max()):.2f}, {ref.numel()} logits")
     if "ctl::mask_logits" in g:
         report("reference control (bf16 weights)", torch.from_numpy(g["ctl::mask_logits"]))
-    report("bf16 training path", forward())
-    model.engine.text_split = True
-    report("bf16 path, split-precision text", forward())
-    model.engine.text_split = False
+    report("bf16 path (text stream fp16)", forward())
+    model.engine.text_f16 = False
+    report("bf16 path, plain bf16 text", forward())
+    model.engine.text_f16 = True
     model.set_precision("fp32")
     forward()
     pr = model._precise

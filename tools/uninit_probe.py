@@ -16,13 +16,15 @@ keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values") + (() i
 model.eval()
 
 
-def fwd(split=False):
-    model.engine.text_split = split
+def fwd(plain=False, subset=False):
+    """plain: MART_TEXT_F16=0 (bf16 text stream); subset: last text layer + head on the [MASK] rows only (needed_rows)."""
+    model.engine.text_f16 = not plain
     with torch.no_grad():
-        out, trans = model(**{k: gb[k] for k in keys}, return_dict=True)
+        need = (gb["input_ids"] == 103).int().argmax(1) if subset else None
+        out, trans = model(**{k: gb[k] for k in keys}, return_dict=True, needed_rows=need)
         rows = out.logits.mask_rows(gb["input_ids"], 103)
         r = rows[:, 30522:30522 + 11292].float().clone()
-    model.engine.text_split = False
+    model.engine.text_f16 = True
     return r, trans.float().clone()
 
 
@@ -46,9 +48,11 @@ for val in (float("nan"), 3.0e4, -1.0e30):
     a2, t2 = fwd()
     print(f"after poison {val!r:>8}: logits equal {bool(torch.equal(a0, a2))} max|d| {float((a0 - a2).abs().max()):.3e} finite {bool(torch.isfinite(a2).all())}; "
           f"trans equal {bool(torch.equal(t0, t2))}")
-s0, _ = fwd(True)
-a3, t3 = fwd()
-print("after a split-precision pass: logits equal", bool(torch.equal(a0, a3)), f"max|d| {float((a0 - a3).abs().max()):.3e}")
-poison(float("nan"))
-s1, _ = fwd(True)
-print("split pass after poison: equal", bool(torch.equal(s0, s1)), f"max|d| {float((s0 - s1).abs().max()):.3e}", "finite", bool(torch.isfinite(s1).all()))
+for name, kw in (("plain bf16 text stream", dict(plain=True)), ("last-layer row subset", dict(subset=True))):
+    s0, _ = fwd(**kw)
+    a3, t3 = fwd()
+    print(f"after a pass with {name}: default logits equal", bool(torch.equal(a0, a3)), f"max|d| {float((a0 - a3).abs().max()):.3e}")
+    poison(float("nan"))
+    s1, _ = fwd(**kw)
+    print(f"{name} after poison: equal", bool(torch.equal(s0, s1)), f"max|d| {float((s0 - s1).abs().max()):.3e}", "finite", bool(torch.isfinite(s1).all()),
+          f"max|d| vs default {float((s1 - a0).abs().max()):.3e}")
