@@ -450,7 +450,7 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
 #ifndef FWD_LDS_EPI
 #define FWD_LDS_EPI 1
 #endif
-  if (FWD_LDS_EPI && TPW == 1 && !TEXT && !p.ctx_f16 && (((uintptr_t)p.ctx & 15) == 0) && p.ldctx % 8 == 0) {   // (text shape, two active waves: 1.6 us SLOWER)
+  if (FWD_LDS_EPI && TPW == 1 && !TEXT && (((uintptr_t)p.ctx & 15) == 0) && (((uintptr_t)p.ctx_f16 & 15) == 0) && p.ldctx % 8 == 0) {   // (text shape, two active waves: 1.6 us SLOWER)
     // The output tile has "lane = query, registers = 4 consecutive head dims": stored from registers, an instruction writes 8 bytes into each of 32
     // rows that lie 2 * ld bytes apart (32 partial cache lines).  Each wave stages its 32 rows in its own 4 KB of the (now dead) K / V ring and
     // stores them as 16-byte chunks, eight lanes per 128-byte row segment.
@@ -474,6 +474,25 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
         const int row = 8 * i + (lane >> 3), lc = pc ^ swz_key(row);
         if (q0[0] + row < p.Sq)
           *(bf16x8*)((bf16*)p.ctx + ((long long)b * p.Sq + q0[0] + row) * p.ldctx + h * 64 + lc * 8) = *(const bf16x8*)(so + row * 128 + pc * 16);
+      }
+      if (p.ctx_f16) {                                     // fp16 twin (rounded once from f32) through the same wave-private staging tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 v = {ot[0][dt][4 * qd] * inv, ot[0][dt][4 * qd + 1] * inv, ot[0][dt][4 * qd + 2] * inv, ot[0][dt][4 * qd + 3] * inv};
+            *(bf16x4*)(so + l31 * 128 + (((4 * dt + qd) ^ okey) << 4) + 8 * hh) = f4_to_h4raw(v);
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 8 * i + (lane >> 3), lc = pc ^ swz_key(row);
+          if (q0[0] + row < p.Sq)
+            *(bf16x8*)((bf16*)p.ctx_f16 + ((long long)b * p.Sq + q0[0] + row) * p.ldctx + h * 64 + lc * 8) = *(const bf16x8*)(so + row * 128 + pc * 16);
+        }
       }
     }
     return;

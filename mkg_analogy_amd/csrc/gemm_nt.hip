@@ -974,6 +974,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
       return launch<128, 128, 2, 2, 0, (M_), (K_), (P_), (DT_)>(a, batch, st); }
     MART_FAST_H(0, ACT_NONE, 1, true)                                 // Q/K/V (bf16 out, the attention kernels' operand type)
     MART_FAST_H(F_CF32, ACT_NONE, 1, false)                           // attention.output.dense / output.dense: f32 into the LayerNorm
+    MART_FAST_H(F_CF32 | F_RES, ACT_NONE, 1, false)                   // ... of the pre-LN blocks (FLAVA): + the f32 residual stream
     MART_FAST_H(F_CF32 | F_ACT, ACT_GELU, 1, false)                   // head transform
     MART_FAST_H(F_PREACT | F_ACT | F_PGRAD | F_C2, ACT_GELU, 2, false)   // intermediate: fp16 GELU output + its bf16 copy + act'(z)
     MART_FAST_H(F_ACT, ACT_GELU, 2, false)                            // ... under no_grad

@@ -103,9 +103,9 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
 // longer count the outstanding memory operations and waits vmcnt(0) -- which also drains the row that was prefetched.  Here the operand set
 // is fixed, rows past the end are clamped duplicates of the last row (same values to the same addresses; their dgamma / dbeta share is
 // multiplied by 0), every wave runs the same trip count, and the waits are counted: two rows are really in flight per wave.
-template <int VMAX>
+template <int VMAX, int OUT = 0>      // OUT: 0 = bf16 output, 1 = fp16 output (out_h), 2 = both (the fp16 forward operand and the bf16 one the backward pass reads)
 __global__ __launch_bounds__(TPB) void ln_fwd_fast_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                     int M, bf16* __restrict__ out, float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+                                                     int M, bf16* __restrict__ out, float* __restrict__ mean_o, float* __restrict__ rstd_o, bf16* __restrict__ out_h = nullptr) {
   constexpr int H = VMAX * 256;
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -134,13 +134,14 @@ __global__ __launch_bounds__(TPB) void ln_fwd_fast_k(const float* __restrict__ x
     const float rstd = rsqrtf(wave_sum(sq) * (1.f / H) + eps);
     keep_mean = lane == (k & 63) ? mean : keep_mean;
     keep_rstd = lane == (k & 63) ? rstd : keep_rstd;
-    bf16* dst = out + (long long)row_of(k) * H + lane * 4;
+    const long long ro = (long long)row_of(k) * H + lane * 4;
 #pragma unroll
     for (int v = 0; v < VMAX; ++v) {
       f32x4 y;
 #pragma unroll
       for (int e = 0; e < 4; ++e) y[e] = (r[v][e] - mean) * rstd * gam[v][e] + bet[v][e];
-      *(bf16x4*)(dst + v * 256) = f4_to_bf4(y);
+      if constexpr (OUT != 1) *(bf16x4*)(out + ro + v * 256) = f4_to_bf4(y);
+      if constexpr (OUT != 0) *(bf16x4*)(out_h + ro + v * 256) = f4_to_h4raw(y);
     }
   };
   f32x4 ra[VMAX], rb[VMAX];
@@ -776,13 +777,16 @@ extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
   MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "ln_fwd: bad dropout p");
   static const int fast = getenv("MART_LN_FAST") ? atoi(getenv("MART_LN_FAST")) : 1;
   static const int fcap = getenv("MART_LN_FWD_GRID") ? atoi(getenv("MART_LN_FWD_GRID")) : 512;   // 6.15 TB/s (768 / 1024 / 2048: 5.8-5.95)
-  if (fast && d->x_f32 && !d->x_rows && !d->out_f16 && !d->y_bf16 && !d->y_f32 && !d->s_out && !d->out_f32 && d->out_bf16 && d->p_drop == 0.f && (d->H == 768 || d->H == 1024) && d->M >= 4096) {
+  if (fast && d->x_f32 && !d->x_rows && !d->y_bf16 && !d->y_f32 && !d->s_out && !d->out_f32 && (d->out_bf16 || d->out_f16) && d->p_drop == 0.f && (d->H == 768 || d->H == 1024) && d->M >= 4096) {
     int g = (d->M + WPB - 1) / WPB;
     if (g > fcap) g = fcap;
     const int gmin = (d->M + WPB * 64 - 1) / (WPB * 64);          // at most 64 rows per wave (their statistics live in one register across the lanes)
     if (g < gmin) g = gmin;
-    if (d->H == 768) hipLaunchKernelGGL(ln_fwd_fast_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, d->x_f32, d->gamma, d->beta, d->eps, d->M, (bf16*)d->out_bf16, d->mean, d->rstd);
-    else hipLaunchKernelGGL(ln_fwd_fast_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, d->x_f32, d->gamma, d->beta, d->eps, d->M, (bf16*)d->out_bf16, d->mean, d->rstd);
+    const int ov = d->out_f16 ? (d->out_bf16 ? 2 : 1) : 0;
+#define LN_FAST(V_, O_) hipLaunchKernelGGL((ln_fwd_fast_k<V_, O_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, d->x_f32, d->gamma, d->beta, d->eps, d->M, (bf16*)d->out_bf16, d->mean, d->rstd, (bf16*)d->out_f16)
+    if (d->H == 768) { if (ov == 0) LN_FAST(3, 0); else if (ov == 1) LN_FAST(3, 1); else LN_FAST(3, 2); }
+    else { if (ov == 0) LN_FAST(4, 0); else if (ov == 1) LN_FAST(4, 1); else LN_FAST(4, 2); }
+#undef LN_FAST
     MART_LAUNCH_CHECK();
     return 0;
   }

@@ -210,6 +210,8 @@ class UnimoEngine:
         p_a = self.p_attn if train else 0.0
         f16 = self.text_f16
         R = nr = None
+        if self.inject is not None or self.inject_grad is not None:
+            rows = None                               # teacher forcing replaces whole [B, L, H] streams: dense pass
         if rows is not None:
             assert rows.dtype == torch.int32 and rows.dim() == 2 and rows.shape[0] == B and rows.is_contiguous()
             R, nr = rows.view(-1), int(rows.shape[1])

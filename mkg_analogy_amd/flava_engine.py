@@ -18,7 +18,7 @@ import torch
 from . import ops
 from .params import FlatStore
 
-BF, F32 = torch.bfloat16, torch.float32
+BF, F32, HF = torch.bfloat16, torch.float32, torch.float16
 WORD = "flava.text_model.embeddings.word_embeddings.weight"
 
 
@@ -60,6 +60,12 @@ def flava_layout_order(nt: int, ni: int, nm: int) -> List[str]:
     return o
 
 
+def flava_f16_weight(name: str) -> bool:
+    """GEMM weights of the text and multimodal stacks: the tensors that get an fp16 forward shadow (FlavaEngine.f16, as engine.UnimoEngine.text_f16)."""
+    return (name.startswith(("flava.text_model.encoder.layer.", "flava.multimodal_model.encoder.layer.")) and name.endswith(".weight")
+            and "layernorm" not in name)
+
+
 def FLAVA_DEAD(nl: Tuple[int, int, int]) -> Tuple[str, ...]:
     """Tensors whose gradient is None in the reference's MarT usage (golden g5: 26 names at 3/3/2 layers)."""
     nt, ni, nm = nl
@@ -94,32 +100,44 @@ class FlavaEngine:
         self.grad_ready: Optional[Callable[[int], None]] = None
         self.taps: Optional[dict] = None
         self.head_split = os.environ.get("MART_HEAD_SPLIT", "1") == "1"   # head transform + scoring GEMM on two-term operand splits (engine.UnimoEngine.head_split)
+        # the forward linear layers of the TEXT and MULTIMODAL stacks on fp16 operands (same switch and reasoning as engine.UnimoEngine.text_f16:
+        # the logits are read off the multimodal stack's text positions; the image stack -- 2/3 of the FLOPs -- stays bf16)
+        self.f16 = os.environ.get("MART_TEXT_F16", "1") == "1" and getattr(store, "f16_weight", None) is flava_f16_weight
 
     # ------------------------------------------------------------------ one pre-LN block
-    def _layer_fwd(self, p: str, x, M: int, attn_kw: dict, want_bf16: bool):
+    def _layer_fwd(self, p: str, x, M: int, attn_kw: dict, want_bf16: bool, f16: bool = False):
+        """``f16``: the four products multiply fp16 operands (LayerNorm outputs, attention context and GELU output written as fp16 twins, fp16
+        weight shadow); the bf16 twins are kept only when a backward pass will read them."""
         st, H, I, dev = self.st, self.H, self.I, x.device
-        h1, m1, r1 = _e((M, H), BF, dev), _e((M,), F32, dev), _e((M,), F32, dev)
+        keep = bool(getattr(self, "save_for_backward", True))      # False under torch.no_grad(): backward-only outputs are skipped
+        kb = keep or not f16                                        # bf16 twins needed
+        W = (lambda *n: st.h(*n)) if f16 else (lambda *n: st.fused(list(n)))
+        h1, m1, r1 = (_e((M, H), BF, dev) if kb else None), _e((M,), F32, dev), _e((M,), F32, dev)
+        h1h = _e((M, H), HF, dev) if f16 else None
         ops.ln_fwd(x_f32=x, gamma=st.m(p + "layernorm_before.weight"), beta=st.m(p + "layernorm_before.bias"), eps=self.eps, M=M, H=H,
-                   mean=m1, rstd=r1, out_bf16=h1)
+                   mean=m1, rstd=r1, out_bf16=h1, out_f16=h1h)
         a = p + "attention.attention."
         qkv = _e((M, 3 * H), BF, dev)
-        ops.gemm_nt(h1, st.fused([a + f"{n}.weight" for n in ("query", "key", "value")]), qkv,
+        ops.gemm_nt(h1h if f16 else h1, W(*[a + f"{n}.weight" for n in ("query", "key", "value")]), qkv,
                     bias=st.fused([a + f"{n}.bias" for n in ("query", "key", "value")], st.master))
         ctx = _e((M, H), BF, dev)
+        ctxh = _e((M, H), HF, dev) if f16 else None
         lse = _e((attn_kw["B"], self.nh, attn_kw["Sq"]), F32, dev)
         kw = dict(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, lse=lse, nh=self.nh, scale=0.125, **attn_kw)
-        ops.attn_fwd(**kw)
+        ops.attn_fwd(ctx_f16=ctxh, **kw)
         x1 = _e((M, H), F32, dev)
-        ops.gemm_nt(ctx, st.w(p + "attention.output.dense.weight"), x1, bias=st.m(p + "attention.output.dense.bias"), res_f32=x)
-        h2, m2, r2 = _e((M, H), BF, dev), _e((M,), F32, dev), _e((M,), F32, dev)
+        ops.gemm_nt(ctxh if f16 else ctx, W(p + "attention.output.dense.weight"), x1, bias=st.m(p + "attention.output.dense.bias"), res_f32=x)
+        h2, m2, r2 = (_e((M, H), BF, dev) if kb else None), _e((M,), F32, dev), _e((M,), F32, dev)
+        h2h = _e((M, H), HF, dev) if f16 else None
         ops.ln_fwd(x_f32=x1, gamma=st.m(p + "layernorm_after.weight"), beta=st.m(p + "layernorm_after.bias"), eps=self.eps, M=M, H=H,
-                   mean=m2, rstd=r2, out_bf16=h2)
-        keep = bool(getattr(self, "save_for_backward", True))      # False under torch.no_grad(): backward-only outputs are skipped
-        z, f = (_e((M, I), BF, dev) if keep else None), _e((M, I), BF, dev)   # z = gelu'(intermediate.dense output)
-        ops.gemm_nt(h2, st.w(p + "intermediate.dense.weight"), f, bias=st.m(p + "intermediate.dense.bias"), act=ops.ACT_GELU, preact=z, preact_grad=keep)
+                   mean=m2, rstd=r2, out_bf16=h2, out_f16=h2h)
+        z, f = (_e((M, I), BF, dev) if keep else None), (_e((M, I), BF, dev) if kb else None)   # z = gelu'(intermediate.dense output)
+        fh = _e((M, I), HF, dev) if f16 else None
+        ops.gemm_nt(h2h if f16 else h2, W(p + "intermediate.dense.weight"), fh if f16 else f, bias=st.m(p + "intermediate.dense.bias"), act=ops.ACT_GELU,
+                    preact=z, preact_grad=keep, C2=f if f16 else None)
         x2 = _e((M, H), F32, dev)
         x2b = _e((M, H), BF, dev) if want_bf16 else None
-        ops.gemm_nt(f, st.w(p + "output.dense.weight"), x2, bias=st.m(p + "output.dense.bias"), res_f32=x1, C2=x2b)
+        ops.gemm_nt(fh if f16 else f, W(p + "output.dense.weight"), x2, bias=st.m(p + "output.dense.bias"), res_f32=x1, C2=x2b)
         return x2, x2b, dict(x=x, m1=m1, r1=r1, h1=h1, qkv=qkv, kw=kw, x1=x1, m2=m2, r2=r2, h2=h2, z=z, f=f)
 
     def _layer_bwd(self, p: str, key: str, s: dict, M: int, dx, dxb, dw=None):
@@ -199,7 +217,7 @@ class FlavaEngine:
                        sep_stride=sep_idx.shape[1] if sep_idx is not None else 0,
                        w0=st.m(a + "adaptive_weight.0") if sep_idx is not None else None,
                        w1=st.m(a + "adaptive_weight.1") if sep_idx is not None else None, rw_skip_row0=True)
-            xt, xtb, sv[f"t{l}"] = self._layer_fwd(pfx, xt, Mt, tkw, l == self.nt - 1)
+            xt, xtb, sv[f"t{l}"] = self._layer_fwd(pfx, xt, Mt, tkw, l == self.nt - 1, self.f16)
         if self.taps is not None:
             self.taps["img"], self.taps["txt"] = xi.view(B, Nv, H).clone(), xt.view(B, Lq, H).clone()
         # ---- multimodal input: [cls | image_to_mm(img) | text_to_mm(txt)]  (:1430,1450,1455-1456; cls :1182-1184)
@@ -213,7 +231,7 @@ class FlavaEngine:
         xm = xm.view(Mm, H)
         mkw = dict(B=B, Sq=Sm, Sk=Sm)
         for l in range(self.nm):
-            xm, _, sv[f"m{l}"] = self._layer_fwd(f"flava.multimodal_model.encoder.layer.{l}.", xm, Mm, mkw, False)
+            xm, _, sv[f"m{l}"] = self._layer_fwd(f"flava.multimodal_model.encoder.layer.{l}.", xm, Mm, mkw, False, self.f16)
         # ---- final multimodal layernorm, text positions, MLM head transform (:1209, :2187-2188, :1676-1680)
         mm_b, mmean, mrstd = _e((Mm, H), BF, dev), _e((Mm,), F32, dev), _e((Mm,), F32, dev)
         split = self.head_split

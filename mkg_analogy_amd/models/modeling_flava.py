@@ -18,7 +18,7 @@ from torch import nn
 
 from .. import functional as Fn
 from .. import ops
-from ..flava_engine import FlavaEngine, flava_gemm_groups, flava_layout_order, FLAVA_DEAD
+from ..flava_engine import FlavaEngine, flava_f16_weight, flava_gemm_groups, flava_layout_order, FLAVA_DEAD
 from ..params import FlatStore
 from .modeling_unimo import MaskedLMOutput, _Container
 
@@ -215,7 +215,8 @@ class FlavaForMaskedLM(nn.Module):
             device = p0.device if p0.is_cuda else torch.device("cuda", torch.cuda.current_device())
         c = self.config
         nl = (c.text_config.num_hidden_layers, c.image_config.num_hidden_layers, c.multimodal_config.num_hidden_layers)
-        self._store = FlatStore(named, 0, torch.device(device), order=flava_layout_order(*nl), gemm_groups=flava_gemm_groups(*nl), dead=FLAVA_DEAD(nl))
+        self._store = FlatStore(named, 0, torch.device(device), order=flava_layout_order(*nl), gemm_groups=flava_gemm_groups(*nl), dead=FLAVA_DEAD(nl),
+                                f16_weight=flava_f16_weight)
         self.tie_weights()
         self._engine = FlavaEngine(self._store, c)
         self._anchor = torch.zeros(1, device=device, requires_grad=True)

@@ -160,7 +160,12 @@ def test_flava_vs_reference_at_real_dimensions():
     e_l, rms = float((ml - ref_l).abs().max()), float((ml - ref_l).pow(2).mean().sqrt())
     scale = max(1.0, float(ref_l.abs().max()))
     r_t = float((tr - ref_t).norm() / ref_t.norm())
-    print(f"   bf16 path max|dlogit| {e_l:.3e} rms {rms:.3e} (logit scale {scale:.2f}) trans rows rel-L2 {r_t:.3e}")
+    print(f"   bf16 path max|dlogit| {e_l:.3e} rms {rms:.3e} (logit scale {scale:.2f}) trans rows rel-L2 {r_t:.3e}   [text + multimodal stacks on fp16 operands: {model.engine.f16}]")
+    f16_0 = model.engine.f16
+    model.engine.f16 = False
+    mlp, _ = forward()
+    model.engine.f16 = f16_0
+    print(f"   MART_TEXT_F16=0 (all three stacks bf16): max|dlogit| {float((mlp - ref_l).abs().max()):.3e} rms {float((mlp - ref_l).pow(2).mean().sqrt()):.3e}")
     assert r_t < 2e-2 and e_l < 1.5e-2 * scale
     st = model.store
     st.zero_grad()
