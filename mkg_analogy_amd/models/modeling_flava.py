@@ -283,6 +283,7 @@ class FlavaForMaskedLM(nn.Module):
         self._engine.save_for_backward = torch.is_grad_enabled()
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx,
                                       bool(self.training), (self.base_seed * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFF, holder)
+        st.join_pending()                           # gradient zero-fill / W^T refresh issued next to this forward pass (optim.FusedAdamW)
         logits = Fn.LazyLogits(trans, holder["trans_bf16"], st, word_name="flava.text_model.embeddings.word_embeddings.weight",
                                bias_name="cls.bias", head_split=self._engine.head_split)
         loss = None

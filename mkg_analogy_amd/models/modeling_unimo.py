@@ -318,6 +318,7 @@ class UnimoForMaskedLM(nn.Module):
             pixel_values = pixel_values.to(dev, torch.float32)
         train = bool(self.training)
         if self.precision == "fp32":
+            st.join_pending()                       # (the fp32-accurate engines read W^T / write gradients from their first kernels on)
             if labels is not None:
                 raise NotImplementedError("precision='fp32': no full-vocabulary labels path; score slices of .logits instead")
             if torch.is_grad_enabled():
@@ -349,6 +350,7 @@ class UnimoForMaskedLM(nn.Module):
             rows = (torch.arange(B, device=dev, dtype=torch.int64)[:, None] * L + nr_).to(torch.int32).contiguous()
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
                                       image_table, image_index, rows)
+        st.join_pending()                           # gradient zero-fill / W^T refresh issued next to this forward pass (optim.FusedAdamW)
         logits = Fn.LazyLogits(trans, holder["trans_bf16"], st, head_split=self._engine.head_split)
         loss = None
         if labels is not None:                      # CrossEntropyLoss over the full vocabulary (:880-882); not used by MarT

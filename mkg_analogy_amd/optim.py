@@ -33,9 +33,28 @@ class FusedAdamW(torch.optim.Optimizer):
         self._store_id = id(store)
         self._stream = None
         self._streaming = False
+        # step-boundary work that the NEXT forward pass does not need -- the gradient zero-fill and the refresh of the transposed weight
+        # shadows (read by data-gradient GEMMs only) -- stays on the optimizer stream; the backward pass joins it (FlatStore.join_pending)
+        self.async_step = os.environ.get("MART_ASYNC_STEP", "1") == "1"
+
+    def _side(self):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(priority=int(os.environ.get("MART_OPT_PRIO", "0")))
+        return self._stream
 
     def zero_grad(self, set_to_none: bool = False):
-        self.model.store.zero_grad()
+        """The 0.94 GB fill runs on the optimizer stream, next to the forward pass (which never touches the gradient buffer); whatever
+        writes gradients waits for it first (FlatStore.join_pending: the model's forward call joins before returning, and every
+        backward kernel is enqueued later).  ``MART_ASYNC_STEP=0``: the plain in-order fill."""
+        store = self.model.store
+        if not (self.async_step and store.grad.is_cuda):
+            store.zero_grad()
+            return
+        st = self._side()
+        st.wait_stream(torch.cuda.current_stream())                      # readers / writers of the gradients enqueued so far
+        with torch.cuda.stream(st):
+            store.grad.zero_()
+        store.pending(st)
 
     # ---- streamed step: the update of a parameter range is launched as soon as its gradients are final (the backward
     # pass reports "everything below flat offset X is final", layout order == completion order), on its own stream, under
@@ -78,8 +97,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if not self.m.is_cuda:
             self._launch(j)
             return
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(priority=int(os.environ.get("MART_OPT_PRIO", "0")))
+        self._side()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self._stream.wait_event(ev)
@@ -97,8 +115,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self._launch(store.n_chunks)
         self._streaming = False
         if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
-        store.refresh_transposed()
+            torch.cuda.current_stream().wait_stream(self._stream)       # master + bf16 / fp16 shadows are final for the next forward pass
+        if self.async_step and self._stream is not None and store.grad.is_cuda:
+            with torch.cuda.stream(self._stream):
+                store.refresh_transposed()                               # W^T shadows: only the NEXT backward pass reads them
+            store.pending(self._stream)
+        else:
+            store.refresh_transposed()
 
     def state_dict(self):
         return {"m": self.m, "v": self.v, "steps": self.steps, "lr": self.param_groups[0]["lr"]}

@@ -236,6 +236,20 @@ class FlatStore:
     def zero_grad(self) -> None:
         self.grad.zero_()
 
+    # ---- work enqueued on another stream that the gradient writers / the readers of the transposed shadows must not overtake
+    def pending(self, stream) -> None:
+        """``stream`` carries a gradient zero-fill or a W^T refresh issued off the compute stream (optim.FusedAdamW)."""
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._pending = getattr(self, "_pending", []) + [ev]
+
+    def join_pending(self) -> None:
+        """The current stream waits for everything ``pending`` announced (called by the model's forward, after its last kernel: every
+        backward kernel is enqueued after it)."""
+        for ev in getattr(self, "_pending", []):
+            torch.cuda.current_stream().wait_event(ev)
+        self._pending = []
+
     def buckets(self, bucket_elems: int = 16 << 20) -> List[Tuple[int, int]]:
         """Contiguous (start, end) slices of the gradient buffer in backward-completion order."""
         out = []

@@ -56,7 +56,7 @@ def test_flava_forward_backward_vs_oracle():
     e_l = float((ml.detach().float().cpu() - ml_ref.detach()).abs().max())
     scale = max(1.0, float(ml_ref.detach().abs().max()))
     print(f"\nflava: loss hip {float(loss.detach()):.5f} oracle {float(loss_ref.detach()):.5f}; trans rel-L2 {rel_t:.3e}; logits max|err| {e_l:.3e} (scale {scale:.2f})")
-    assert rel_t < 2e-2 and e_l < 1e-2 * scale * 1.5 and abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-2
+    assert rel_t < 2e-2 and e_l < 1e-2 * scale and abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-2
     ev = lit._eval(dict(gb), 0)
     ranks_ref = O.ranks_double_sort(ml_ref.detach(), batch["label"])
     amb = ((ml_ref.detach() - ml_ref.detach()[torch.arange(B), batch["label"]][:, None]).abs() < 2 * e_l).sum(1).numpy() - 1
@@ -166,7 +166,8 @@ def test_flava_vs_reference_at_real_dimensions():
     mlp, _ = forward()
     model.engine.f16 = f16_0
     print(f"   MART_TEXT_F16=0 (all three stacks bf16): max|dlogit| {float((mlp - ref_l).abs().max()):.3e} rms {float((mlp - ref_l).pow(2).mean().sqrt()):.3e}")
-    assert r_t < 2e-2 and e_l < 1.5e-2 * scale
+    assert r_t < 2e-2
+    assert e_l < 1e-2, f"north_star: bf16 logits within 1e-2 of the reference (FLAVA, text + multimodal stacks on fp16 operands): {e_l:.3e}"
     st = model.store
     st.zero_grad()
     loss = lit.training_step(dict(gb), 1)
