@@ -8,6 +8,7 @@
 // (the dropped lo*lo term is 2^-16 relative).  Attention and the image-text fusion softmax(ctx vis^T) vis run in plain
 // fp32 FMA arithmetic in attn_f32_k (no MFMA: 7 % of the FLOPs, and the softmax path is the precision-critical part).
 // Evaluation runs the forward half; the backward half (end of this file) exists for verification: gradients against the fp32 reference.
+#include <cstdlib>
 #include "common.h"
 #include "mart_hip.h"
 
@@ -168,6 +169,119 @@ __global__ __launch_bounds__(256) void attn_f32_k(mart_attn_f32_desc p) {
       const int rr = rg * RPG + r;
       if (rr < nq) p.ctx[(b * p.Sq + q0 + rr) * p.ldctx + h * D + d] = acc[r];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- fp32 attention on the matrix pipe
+// v_mfma_f32_32x32x2_f32: f32 operands, f32 accumulate, bitwise an fmaf chain, at the f32 vector rate (157 TF/s per chip, 1/16 of bf16) -- 10-20x what the
+// FMA loops of attn_f32_k reach, which is what made the fp32-accurate evaluation pass 6.4x the bf16 one.  Head dim 64 (every multi-head attention of the
+// path; the D = 768 fusion keeps attn_f32_k).
+//   one wave = 32 queries, "lane = owner query": S^T[key][q] = sum_d K[key][d] Q[q][d] has the wave's queries as COLUMNS, so the online softmax state of a
+//   query is lane-local up to one exchange between the two lane halves (which hold complementary key rows of a tile);
+//   Q lives in registers (32 per lane: d = half + 2s), K / V stream through LDS in 32-key tiles shared by the workgroup's 4 waves (row stride 65 floats:
+//   the per-lane scalar reads K[key = lane][d] and V[key][d = lane] are both bank-conflict free), the next tile's global loads are in flight during the
+//   64 MFMAs (4096 cycles) of the current one;
+//   O^T[d][q] += sum_key V[key][d] P[q][key] contracts the keys in the order the S^T registers hold them (register s of half h is key (s&3) + 8(s>>2) + 4h):
+//   the probabilities never leave their registers.
+// Text options exactly as attn_f32_k (scale, adaptive reweight incl. the FLAVA row-0 variant, additive key mask), vision options: the [prefix | own] key set.
+constexpr int AM_WAVES = 4, AM_KT = 32, AM_LD = 65;
+__global__ __launch_bounds__(64 * AM_WAVES) void attn_f32_mfma_k(mart_attn_f32_desc p) {
+  __shared__ float Ks[AM_KT * AM_LD], Vs[AM_KT * AM_LD];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y;
+  const long long b = blockIdx.z;
+  const int Stot = p.Lp + p.Sk;
+  const int qi = blockIdx.x * (32 * AM_WAVES) + wave * 32 + l31;
+  float qreg[32];
+  {
+    const float* qp = p.q + (b * p.Sq + min(qi, p.Sq - 1)) * p.ldq + h * 64 + hf;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) qreg[s] = qp[2 * s];
+  }
+  float w0 = 1.f, w1 = 1.f; int sp = 0x7fffffff;
+  if (p.sep) {
+    sp = (int)p.sep[b * p.sep_stride];
+    w0 = fminf(fmaxf(*p.w0, 0.f), 0.5f);
+    w1 = fminf(fmaxf(*p.w1, 0.5f), 1.f);
+  }
+  const float rw = (p.sep && !(p.rw_skip_row0 && qi == 0)) ? (qi < sp ? w0 : w1) : 1.f;     // factor of this query's scores at keys >= sp
+  f32x16 ot[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
+  float m_run = -3.0e38f, l_run = 0.f;
+  // staging: thread -> key row tid >> 3, 8 consecutive dims (tid & 7) * 8 of K and of V
+  const int srow = tid >> 3, scol = (tid & 7) * 8;
+  f32x4 kp[2], vp[2];
+  auto fetch = [&](int t) {
+    const int j = min(t * AM_KT + srow, Stot - 1);                      // rows past the last key: clamped copies (masked below)
+    const float* kr = j < p.Lp ? p.pk + (b * p.Lp + j) * p.ldp + h * 64 : p.k + (b * p.Sk + (j - p.Lp)) * p.ldk + h * 64;
+    const float* vr = j < p.Lp ? p.pv + (b * p.Lp + j) * p.ldp + h * 64 : p.v + (b * p.Sk + (j - p.Lp)) * p.ldv + h * 64;
+    kp[0] = *(const f32x4*)(kr + scol); kp[1] = *(const f32x4*)(kr + scol + 4);
+    vp[0] = *(const f32x4*)(vr + scol); vp[1] = *(const f32x4*)(vr + scol + 4);
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { Ks[srow * AM_LD + scol + 4 * u + e] = kp[u][e]; Vs[srow * AM_LD + scol + 4 * u + e] = vp[u][e]; }
+  };
+  const int ntiles = (Stot + AM_KT - 1) / AM_KT;
+  fetch(0);
+  stash();
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) fetch(t + 1);
+    // ---- S^T tile
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * AM_LD + hf + 2 * s], qreg[s], st, 0, 0, 0);
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = t * AM_KT + (r & 3) + 8 * (r >> 2) + 4 * hf;        // key of this register
+      float v = st[r] * p.scale;
+      if (j >= sp) v *= rw;
+      if (p.attn_mask && j < Stot && p.attn_mask[b * p.Sk + j] == 0) v += -10000.0f;
+      if (j >= Stot) v = -3.0e38f;
+      st[r] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = (t * AM_KT + (r & 3) + 8 * (r >> 2) + 4 * hf) < Stot ? expf(st[r] - m_new) : 0.f;
+      st[r] = e;
+      sum += e;
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float alpha = expf(m_run - m_new);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+    // ---- O^T += V^T P^T, keys in register order
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int key = (s & 3) + 8 * (s >> 2) + 4 * hf;
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * AM_LD + l31], st[s], ot[0], 0, 0, 0);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * AM_LD + 32 + l31], st[s], ot[1], 0, 0, 0);
+    }
+    __syncthreads();                                                   // every wave is through tile t
+    if (t + 1 < ntiles) { stash(); __syncthreads(); }
+  }
+  if (qi < p.Sq) {
+    const float inv = 1.f / l_run;
+    float* op = p.ctx + (b * p.Sq + qi) * p.ldctx + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)(op + dt * 32 + 8 * g + 4 * hf) = f32x4{ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv, ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv};
   }
 }
 
@@ -435,6 +549,13 @@ extern "C" int mart_attn_fwd_f32(const mart_attn_f32_desc* d, void* stream) {
   MART_CHECK(d->ldq % 4 == 0 && d->ldk % 4 == 0 && d->ldv % 4 == 0 && (d->Lp == 0 || (d->pk && d->pv && d->ldp % 4 == 0)), "attn_f32: bad strides / prefix");
   MART_CHECK((d->w0 == nullptr) == (d->w1 == nullptr) && (!d->sep || (d->w0 && d->Lp == 0)), "attn_f32: reweight needs w0/w1 and no prefix");
   MART_CHECK(!d->attn_mask || d->Lp == 0, "attn_f32: mask with prefix unsupported");
+  static const int scalar = getenv("MART_ATTN_F32_SCALAR") ? atoi(getenv("MART_ATTN_F32_SCALAR")) : 0;   // 1: the FMA-loop kernel (A/B, tests)
+  if (d->D == 64 && !scalar && d->ldctx % 4 == 0 && ((uintptr_t)d->ctx & 15) == 0 && ((uintptr_t)d->k & 15) == 0 && ((uintptr_t)d->v & 15) == 0 &&
+      (!d->pk || (((uintptr_t)d->pk & 15) == 0 && ((uintptr_t)d->pv & 15) == 0))) {
+    hipLaunchKernelGGL(attn_f32_mfma_k, dim3((d->Sq + 32 * AM_WAVES - 1) / (32 * AM_WAVES), d->nh, d->B), dim3(64 * AM_WAVES), 0, (hipStream_t)stream, *d);
+    MART_LAUNCH_CHECK();
+    return 0;
+  }
   if (d->D == 64) return launch_attn<64>(d, (hipStream_t)stream);
   if (d->D == 768) return launch_attn<768>(d, (hipStream_t)stream);
   mart_set_error("attn_f32: head dim must be 64 (multi-head attention) or 768 (fusion)");
