@@ -48,6 +48,38 @@ __global__ void split3_k(const float* __restrict__ src, long long ld, bf16* __re
   }
 }
 
+// The two-term split of a dense [rows, K] matrix (K % 8 == 0): the shape behind every GEMM of the fp32-accurate evaluation pass (140 launches, 13 ms of
+// its 108 at one element quad per thread and iteration: a dependent load -> three 8-byte stores chain at 1.3 TB/s).  Here a thread owns 16 consecutive
+// elements: four 16-byte loads in flight, 16-byte stores, nontemporal both ways (the result is read once, by the GEMM that follows).
+__global__ __launch_bounds__(256) void split3_fast_k(const float* __restrict__ src, long long ld, bf16* __restrict__ dst, int rows, int K, int role) {
+  const int per_row = K / 16;                              // 16-element groups per row
+  const long long total = (long long)rows * per_row;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / per_row;
+    const int c = (int)(i % per_row) * 16;
+    const float* sp = src + r * ld + c;
+    f32x4 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = __builtin_nontemporal_load((const f32x4*)(sp + 4 * u));
+    bf16x8 h[2], m[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bf16x4 hh = f4_to_bf4(x[u]);
+      const f32x4 hf = bf4_to_f4(hh);
+      const bf16x4 mm = f4_to_bf4(f32x4{x[u][0] - hf[0], x[u][1] - hf[1], x[u][2] - hf[2], x[u][3] - hf[3]});
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { h[u >> 1][(u & 1) * 4 + e] = hh[e]; m[u >> 1][(u & 1) * 4 + e] = mm[e]; }
+    }
+    bf16* o = dst + r * 3LL * K + c;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      __builtin_nontemporal_store(h[u], (bf16x8*)(o + 8 * u));
+      __builtin_nontemporal_store(role == 0 ? m[u] : h[u], (bf16x8*)(o + K + 8 * u));
+      __builtin_nontemporal_store(role == 0 ? h[u] : m[u], (bf16x8*)(o + 2 * K + 8 * u));
+    }
+  }
+}
+
 // pixels [B,2,3,S,S] f32 (or table rows through index) -> f32 patch matrix [(b,img,py,px), (c,ky,kx)]
 __global__ void patchify_f32_k(const float* __restrict__ pix, const int32_t* __restrict__ index, float* __restrict__ out, int S, int p) {
   const int g = S / p, P = g * g, K = 3 * p * p;
@@ -230,8 +262,10 @@ __global__ __launch_bounds__(64 * AM_WAVES) void attn_f32_mfma_k(mart_attn_f32_d
   fetch(0);
   stash();
   __syncthreads();
+  const bool wave_on = blockIdx.x * (32 * AM_WAVES) + wave * 32 < p.Sq;      // a wave past the last query only helps staging (393 queries = 12.3 waves of 16)
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) fetch(t + 1);
+    if (wave_on) {
     // ---- S^T tile
     f32x16 st;
 #pragma unroll
@@ -270,6 +304,7 @@ __global__ __launch_bounds__(64 * AM_WAVES) void attn_f32_mfma_k(mart_attn_f32_d
       const int key = (s & 3) + 8 * (s >> 2) + 4 * hf;
       ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * AM_LD + l31], st[s], ot[0], 0, 0, 0);
       ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * AM_LD + 32 + l31], st[s], ot[1], 0, 0, 0);
+    }
     }
     __syncthreads();                                                   // every wave is through tile t
     if (t + 1 < ntiles) { stash(); __syncthreads(); }
@@ -520,6 +555,13 @@ extern "C" int mart_split_bf16x3_rows(const float* src, long long ld, const int3
 
 extern "C" int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16, int rows, int K, int role, int terms, void* stream) {
   MART_CHECK((terms == 2 || terms == 3) && src && dst_bf16 && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3: bad args");
+  if (terms == 2 && K % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst_bf16 & 15) == 0) {
+    const long long groups = (long long)rows * (K / 16);
+    const int blk = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
+    hipLaunchKernelGGL(split3_fast_k, dim3(blk), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role);
+    MART_LAUNCH_CHECK();
+    return 0;
+  }
   const long long total = (long long)rows * (K / 4);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   hipLaunchKernelGGL(split3_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role, (const int32_t*)nullptr, terms);

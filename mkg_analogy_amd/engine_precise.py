@@ -529,3 +529,173 @@ class PreciseFlavaForward(_PreciseBase):
                     act=ops.ACT_GELU)
         trans = self._ln(y, "cls.transform.LayerNorm.weight", "cls.transform.LayerNorm.bias", self.eps)
         return trans.view(B, Lq, H)
+
+
+class PreciseFlavaTrain(PreciseFlavaForward):
+    """fp32-accurate FLAVA forward WITH saved activations + backward (verification mode behind ``set_precision("fp32")`` with gradients enabled):
+    the FLAVA twin of ``PreciseUnimoTrain``, built from the same pieces -- every contraction on three-term bf16 operand splits (six products, fp32
+    accumulation), attention / LayerNorm / GELU and their gradients in fp32.  Autograd of MarT/models/modeling_flava.py:1373-1476 (FlavaModel.forward),
+    :635-665 (FlavaLayer), :460-496 (self-attention with the row-0-exempt adaptive reweight), :2150-2204 (FlavaForMaskedLM.forward).  Same interface as
+    ``flava_engine.FlavaEngine``; eval-mode gradients (all FLAVA dropouts are 0 in this configuration anyway)."""
+
+    grad_ready = None
+    grad_ready_async = None
+    save_for_backward = True
+    head_split = True
+    w3t = PreciseUnimoTrain.w3t
+    _pad64 = PreciseUnimoTrain._pad64
+    lin_bwd = PreciseUnimoTrain.lin_bwd
+    _ln_s = PreciseUnimoTrain._ln_s
+    _ln_b = PreciseUnimoTrain._ln_b
+    score = PreciseUnimoForward.score
+    w3 = PreciseUnimoForward.w3
+    lin = PreciseUnimoForward.lin
+
+    def __init__(self, store: FlatStore, config):
+        super().__init__(store, config)
+        self._w3t: Dict[str, Tuple[int, torch.Tensor]] = {}
+        self.terms = int(os.environ.get("MART_PRECISE_TERMS", "3"))
+
+    def _block_s(self, p: str, x: torch.Tensor, B: int, S: int, **attn):
+        H, I = self.H, self.I
+        a = p + "attention.attention."
+        h1, ln1 = self._ln_s(x, p + "layernorm_before.weight", p + "layernorm_before.bias", self.eps)
+        qn = [a + n for n in ("query", "key", "value")]
+        qkv = self.lin(h1, [n + ".weight" for n in qn], [n + ".bias" for n in qn], 3 * H)
+        ctx = _e((x.shape[0], H), F32, x.device)
+        kw = dict(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], B=B, nh=self.nh, D=64, Sq=S, Sk=S, scale=0.125, **attn)
+        ops.attn_fwd_f32(ctx=ctx, **kw)
+        x1 = self.lin(ctx, [p + "attention.output.dense.weight"], [p + "attention.output.dense.bias"], H, res_f32=x)
+        h2, ln2 = self._ln_s(x1, p + "layernorm_after.weight", p + "layernorm_after.bias", self.eps)
+        z = self.lin(h2, [p + "intermediate.dense.weight"], [p + "intermediate.dense.bias"], I)
+        f = ops.act_f32(z, ops.ACT_GELU)
+        out = self.lin(f, [p + "output.dense.weight"], [p + "output.dense.bias"], H, res_f32=x1)
+        return out, dict(ln1=ln1, h1=h1, qn=qn, kw=kw, ctx=ctx, ln2=ln2, h2=h2, z=z, f=f)
+
+    def _block_b(self, p: str, s: dict, dx: torch.Tensor, dw=None) -> torch.Tensor:
+        """d(loss)/d(block output) -> d(loss)/d(block input); parameter gradients accumulate into FlatStore.grad."""
+        H = self.H
+        df = self.lin_bwd(dx, s["f"], [p + "output.dense.weight"], [p + "output.dense.bias"])
+        dz = ops.act_bwd_f32(df, s["z"], ops.ACT_GELU)
+        dh2 = self.lin_bwd(dz, s["h2"], [p + "intermediate.dense.weight"], [p + "intermediate.dense.bias"])
+        dx1 = self._ln_b(dh2, s["ln2"], add=dx)
+        dctx = self.lin_bwd(dx1, s["ctx"], [p + "attention.output.dense.weight"], [p + "attention.output.dense.bias"])
+        dqkv = torch.zeros((dx.shape[0], 3 * H), device=dx.device, dtype=F32)
+        ops.attn_bwd_f32(dctx=dctx, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:], dw=dw, **s["kw"])
+        dh1 = self.lin_bwd(dqkv, s["h1"], [n + ".weight" for n in s["qn"]], [n + ".bias" for n in s["qn"]])
+        return self._ln_b(dh1, s["ln1"], add=dx1)
+
+    def forward(self, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train=False, seed=0, image_table=None, image_index=None):
+        st, H = self.st, self.H
+        dev = input_ids.device
+        B, Lq = input_ids.shape
+        ic = self.cfg.image_config
+        S, p = ic.image_size, ic.patch_size
+        P = (S // p) ** 2
+        Nv = 1 + 2 * P
+        Sm = 1 + Nv + Lq
+        Mi, Mt, Mm = B * Nv, B * Lq, B * Sm
+        Kp = 3 * p * p
+        sv: Dict[str, object] = dict(B=B, L=Lq, P=P, Nv=Nv, Sm=Sm, ids=input_ids, tt=token_type_ids)
+        patches = _e((B * 2 * P, Kp), F32, dev)
+        if image_index is not None:
+            ops.patchify_f32(image_table, image_index.contiguous().view(-1), patches, B, S, p)
+        else:
+            ops.patchify_f32(pixel_values.contiguous(), None, patches, B, S, p)
+        e = "flava.image_model.embeddings."
+        pe = self.lin(patches, [e + "patch_embeddings.projection.weight"], [e + "patch_embeddings.projection.bias"], H)
+        xi = _e((Mi, H), F32, dev)
+        ops.vision_assemble_f32(pe, st.m(e + "cls_token"), st.m(e + "position_embeddings"), xi, B, P, H, tail_shift=1)
+        sv["patches"] = patches
+        taps = getattr(self, "taps", None)                    # tests: per-layer outputs (golden G9b)
+        for l in range(self.ni):
+            xi, sv[f"i{l}"] = self._block_s(f"flava.image_model.encoder.layer.{l}.", xi, B, Nv)
+            if taps is not None:
+                taps[f"i{l}"] = xi.view(B, Nv, H).clone()
+        t = "flava.text_model.embeddings."
+        s_t, tmean, trstd, xt = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev), _e((Mt, H), F32, dev)
+        ops.text_embed_fwd(ids=input_ids, tt=token_type_ids, word=st.m(t + "word_embeddings.weight"), pos=st.m(t + "position_embeddings.weight"),
+                           type_=st.m(t + "token_type_embeddings.weight"), gamma=st.m(t + "LayerNorm.weight"), beta=st.m(t + "LayerNorm.bias"),
+                           eps=self.eps, p_drop=0.0, seed=0, B=B, Lq=Lq, H=H, s_out=s_t, mean=tmean, rstd=trstd, out_f32=xt, out_bf16=None)
+        sv["temb"] = (s_t, tmean, trstd, t + "LayerNorm.weight", t + "LayerNorm.bias")
+        on = sep_idx is not None
+        for l in range(self.nt):
+            pfx = f"flava.text_model.encoder.layer.{l}."
+            a = pfx + "attention.attention."
+            xt, sv[f"t{l}"] = self._block_s(pfx, xt, B, Lq, attn_mask=attention_mask, sep=sep_idx[:, 2:] if on else None,
+                                            sep_stride=sep_idx.shape[1] if on else 0, w0=st.m(a + "adaptive_weight.0") if on else None,
+                                            w1=st.m(a + "adaptive_weight.1") if on else None, rw_skip_row0=True)
+            if taps is not None:
+                taps[f"t{l}"] = xt.view(B, Lq, H).clone()
+        sv["xi"], sv["xt"], sv["on"] = xi, xt, on
+        xm = _e((B, Sm, H), F32, dev)
+        xm[:, 0, :].copy_(st.m("flava.multimodal_model.cls_token").view(1, H))
+        T = 3 if self.terms == 2 else 6
+        ops.gemm_nt(ops.split_bf16x3(xi, 0, terms=self.terms), self.w3(["flava.image_to_mm_projection.weight"]), xm[0, 1:],
+                    bias=st.m("flava.image_to_mm_projection.bias"), M=Nv, batch=B, stride_a=Nv * T * H, stride_c=Sm * H)
+        ops.gemm_nt(ops.split_bf16x3(xt, 0, terms=self.terms), self.w3(["flava.text_to_mm_projection.weight"]), xm[0, 1 + Nv:],
+                    bias=st.m("flava.text_to_mm_projection.bias"), M=Lq, batch=B, stride_a=Lq * T * H, stride_c=Sm * H)
+        xm = xm.view(Mm, H)
+        for l in range(self.nm):
+            xm, sv[f"m{l}"] = self._block_s(f"flava.multimodal_model.encoder.layer.{l}.", xm, B, Sm)
+            if taps is not None:
+                taps[f"m{l}"] = xm.view(B, Sm, H).clone()
+        mm, lnm = self._ln_s(xm, "flava.multimodal_model.layernorm.weight", "flava.multimodal_model.layernorm.bias", self.eps)
+        rows = (torch.arange(B, device=dev, dtype=torch.int32)[:, None] * Sm + (1 + Nv) +
+                torch.arange(Lq, device=dev, dtype=torch.int32)[None]).reshape(-1).contiguous()
+        seq = _e((Mt, H), F32, dev)
+        ops.gather_rows_f32(mm, rows, seq)
+        zh = self.lin(seq, ["cls.transform.dense.weight"], ["cls.transform.dense.bias"], H)
+        y = ops.act_f32(zh, ops.ACT_GELU)
+        trans, lnh = self._ln_s(y, "cls.transform.LayerNorm.weight", "cls.transform.LayerNorm.bias", self.eps)
+        sv["head"] = (seq, zh, lnh, lnm, rows)
+        return trans.view(B, Lq, H), None, sv
+
+    def backward(self, sv, dtrans: torch.Tensor) -> None:
+        st, H = self.st, self.H
+        dev = dtrans.device
+        B, Lq, P, Nv, Sm = sv["B"], sv["L"], sv["P"], sv["Nv"], sv["Sm"]
+        Mi, Mt, Mm = B * Nv, B * Lq, B * Sm
+        seq, zh, lnh, lnm, rows = sv["head"]
+        dy = self._ln_b(dtrans.contiguous().view(Mt, H).to(F32), lnh)
+        dzh = ops.act_bwd_f32(dy, zh, ops.ACT_GELU)
+        dseq = self.lin_bwd(dzh, seq, ["cls.transform.dense.weight"], ["cls.transform.dense.bias"])
+        dmm = torch.zeros((Mm, H), device=dev, dtype=F32)
+        ops.scatter_add_rows_f32(dseq, rows, dmm)
+        dx = self._ln_b(dmm, lnm)
+        for l in reversed(range(self.nm)):
+            dx = self._block_b(f"flava.multimodal_model.encoder.layer.{l}.", sv[f"m{l}"], dx)
+            sv[f"m{l}"] = None
+        dx3 = dx.view(B, Sm, H)
+        st.g("flava.multimodal_model.cls_token").view(H).add_(dx3[:, 0, :].sum(0))
+        dpi = dx3[:, 1:1 + Nv].reshape(Mi, H).contiguous()
+        dpt = dx3[:, 1 + Nv:].reshape(Mt, H).contiguous()
+        dxi = self.lin_bwd(dpi, sv["xi"], ["flava.image_to_mm_projection.weight"], ["flava.image_to_mm_projection.bias"])
+        dxt = self.lin_bwd(dpt, sv["xt"], ["flava.text_to_mm_projection.weight"], ["flava.text_to_mm_projection.bias"])
+        for l in reversed(range(self.nt)):
+            pfx = f"flava.text_model.encoder.layer.{l}."
+            dw = st.g(pfx + "attention.attention.adaptive_weight.0") if sv["on"] else None
+            dxt = self._block_b(pfx, sv[f"t{l}"], dxt, dw=dw)
+            sv[f"t{l}"] = None
+        dse = self._ln_b(dxt, sv["temb"])
+        t = "flava.text_model.embeddings."
+        ops.text_embed_scatter(dse, sv["ids"], sv["tt"], st.g(t + "word_embeddings.weight"), st.g(t + "position_embeddings.weight"),
+                               st.g(t + "token_type_embeddings.weight"), B, Lq, H)
+        for l in reversed(range(self.ni)):
+            dxi = self._block_b(f"flava.image_model.encoder.layer.{l}.", sv[f"i{l}"], dxi)
+            sv[f"i{l}"] = None
+        # assemble backward (FlavaImageEmbeddings :308-343): cls token = row 0; position rows: first image 1..P, second image 0..P-1 (the tail quirk)
+        e = "flava.image_model.embeddings."
+        ps = torch.zeros(Nv * H, device=dev, dtype=F32)
+        ops.colsum_f32(dxi.view(B, Nv * H), ps)
+        ps = ps.view(Nv, H)
+        st.g(e + "cls_token").view(H).add_(ps[0])
+        gp = st.g(e + "position_embeddings").view(-1, H)
+        gp[0].add_(ps[0])
+        gp[1:P + 1].add_(ps[1:P + 1])
+        gp[0:P].add_(ps[P + 1:])
+        dpe = dxi.view(B, Nv, H)[:, 1:].reshape(B * 2 * P, H).contiguous()
+        self.lin_bwd(dpe, sv["patches"], [e + "patch_embeddings.projection.weight"], [e + "patch_embeddings.projection.bias"], need_dx=False)
+
+    def score_train(self, trans: torch.Tensor, rows: torch.Tensor, ids: torch.Tensor, word_name: str, bias_name: str) -> torch.Tensor:
+        return _PreciseScoreFn.apply(trans, rows, ids, self, word_name, bias_name)

@@ -202,6 +202,8 @@ class FlavaEngine:
         ikw = dict(B=B, Sq=Nv, Sk=Nv)
         for l in range(self.ni):
             xi, xib, sv[f"i{l}"] = self._layer_fwd(f"flava.image_model.encoder.layer.{l}.", xi, Mi, ikw, l == self.ni - 1)
+            if self.taps is not None:
+                self.taps[f"i{l}"] = xi.view(B, Nv, H).clone()             # per-layer outputs (tests: golden G9b)
         # ---- text embeddings + stack (FlavaTextEmbeddings :406-438; FLAVA reweight :494-496)
         t = "flava.text_model.embeddings."
         s_t, tmean, trstd = _e((Mt, H), F32, dev), _e((Mt,), F32, dev), _e((Mt,), F32, dev)
@@ -218,6 +220,8 @@ class FlavaEngine:
                        w0=st.m(a + "adaptive_weight.0") if sep_idx is not None else None,
                        w1=st.m(a + "adaptive_weight.1") if sep_idx is not None else None, rw_skip_row0=True)
             xt, xtb, sv[f"t{l}"] = self._layer_fwd(pfx, xt, Mt, tkw, l == self.nt - 1, self.f16)
+            if self.taps is not None:
+                self.taps[f"t{l}"] = xt.view(B, Lq, H).clone()
         if self.taps is not None:
             self.taps["img"], self.taps["txt"] = xi.view(B, Nv, H).clone(), xt.view(B, Lq, H).clone()
         # ---- multimodal input: [cls | image_to_mm(img) | text_to_mm(txt)]  (:1430,1450,1455-1456; cls :1182-1184)
@@ -232,6 +236,8 @@ class FlavaEngine:
         mkw = dict(B=B, Sq=Sm, Sk=Sm)
         for l in range(self.nm):
             xm, _, sv[f"m{l}"] = self._layer_fwd(f"flava.multimodal_model.encoder.layer.{l}.", xm, Mm, mkw, False, self.f16)
+            if self.taps is not None:
+                self.taps[f"m{l}"] = xm.view(B, Sm, H).clone()
         # ---- final multimodal layernorm, text positions, MLM head transform (:1209, :2187-2188, :1676-1680)
         mm_b, mmean, mrstd = _e((Mm, H), BF, dev), _e((Mm,), F32, dev), _e((Mm,), F32, dev)
         split = self.head_split

@@ -268,8 +268,22 @@ class FlavaForMaskedLM(nn.Module):
             sep_idx = sep_idx.to(dev, torch.int64).contiguous()
         pixel_values = pixel_values.to(dev, torch.float32)
         if getattr(self, "precision", "bf16") == "fp32":
-            if self.training or labels is not None:
-                raise NotImplementedError("precision='fp32' is the evaluation path (forward only, no labels); call model.eval() or set_precision('bf16')")
+            st.join_pending()
+            if labels is not None:
+                raise NotImplementedError("precision='fp32': no full-vocabulary labels path; score slices of .logits instead")
+            if torch.is_grad_enabled():
+                # verification mode: fp32-accurate forward AND backward (engine_precise.PreciseFlavaTrain); eval-mode gradients
+                prt = getattr(self, "_precise_train", None)
+                if prt is None or prt.st is not st:
+                    from ..engine_precise import PreciseFlavaTrain
+                    prt = self._precise_train = PreciseFlavaTrain(st, self.config)
+                holder: Dict[str, torch.Tensor] = {}
+                trans = Fn._MKGformerFn.apply(self._anchor, prt, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, False, 0, holder)
+                out = MaskedLMOutput(loss=None, logits=Fn.LazyLogits(trans, None, st, word_name="flava.text_model.embeddings.word_embeddings.weight",
+                                                                     bias_name="cls.bias", precise=prt), hidden_states=None, attentions=None)
+                return (out, trans) if return_dict else ((out.logits,), trans)
+            if self.training:
+                raise NotImplementedError("precision='fp32' under no_grad is the evaluation path: call model.eval() (or set_precision('bf16'))")
             pr = getattr(self, "_precise", None)
             if pr is None or pr.st is not st:
                 from ..engine_precise import PreciseFlavaForward

@@ -197,10 +197,14 @@ def forward(sd, c: FlavaCfg, input_ids, attention_mask, token_type_ids, pixel_va
     img = image_embed(sd, c, pixel_values)
     for i in range(c.image_layers):
         img = layer(sd, c, f"flava.image_model.encoder.layer.{i}.", img, None, None)
+        if taps is not None:
+            taps[f"i{i}"] = img                      # per-layer outputs (golden G9b holds the reference's for layers 0 / 11)
     txt = text_embed(sd, c, input_ids, token_type_ids)
     em = extended_mask(attention_mask)
     for i in range(c.text_layers):
         txt = layer(sd, c, f"flava.text_model.encoder.layer.{i}.", txt, em, sep_idx)
+        if taps is not None:
+            taps[f"t{i}"] = txt
     if taps is not None:
         taps["img"], taps["txt"] = img, txt
     # projections of the PRE-final-layernorm last hidden states (:1430,1450)
@@ -208,6 +212,8 @@ def forward(sd, c: FlavaCfg, input_ids, attention_mask, token_type_ids, pixel_va
     mm = torch.cat([sd["flava.multimodal_model.cls_token"].expand(mm.shape[0], -1, -1), mm], dim=1)
     for i in range(c.mm_layers):
         mm = layer(sd, c, f"flava.multimodal_model.encoder.layer.{i}.", mm, None, None)    # all-ones mask -> additive zeros
+        if taps is not None:
+            taps[f"m{i}"] = mm
     mm = _ln(mm, sd["flava.multimodal_model.layernorm.weight"], sd["flava.multimodal_model.layernorm.bias"], c.layer_norm_eps)
     seq = mm[:, -input_ids.shape[1]:, :]
     t = gelu_erf(_lin(seq, sd, "cls.transform.dense"))

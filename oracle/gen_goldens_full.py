@@ -15,7 +15,7 @@ G7  BASELINE configs[1] shape: the first 32 examples of bench.py's rank-0 batch 
     gradient norms, strided samples of ~45 gradient tensors, and per-layer hidden states (reference forward hooks)
     of layers 0, 7, 8, 11 for examples 0-1 (pins the oracle's per-layer taps at real dimensions).
 G8b the same pre-train step at P=196 (ViT-B/16 patches, 393 vision tokens), B=8, conditioned weights.
-G9  BASELINE configs[3]: the reference's FlavaForMaskedLM at real dimensions, B=2 (see g9_flava).
+G9  BASELINE configs[3]: the reference's FlavaForMaskedLM at real dimensions, B=2 (see g9_flava); G9b: B=8 with per-layer taps (g9b_flava).
 G8  BASELINE configs[4] shape: MarKG pre-train step, L=96, no sep_idx, mixed pre_type, B=8, CLIP-B/32 patches
     (P=49, the geometry of the reference's pre-train script), full E=11292 / R=192 heads: loss, entity and relation
     ranks, gradient norms and samples (incl. the tied word-embedding rows of the entity slice and cls.predictions.bias).
@@ -252,6 +252,92 @@ def g9_flava(out_dir):
     print(f"g9_flava_real: loss {float(loss):.6f} ranks {np.asarray(ranks).tolist()} none-grad {len(none_grad)} ({time.time() - t0:.1f} s)", flush=True)
 
 
+G9B_TAPS = (("text_model", (0, 6, 11)), ("image_model", (0, 11)), ("multimodal_model", (0, 5)))
+
+
+def g9b_tap_rows(S: int) -> np.ndarray:
+    """Token rows of a tap that the golden keeps (the streams are [8, S, 768] f32: 2.4 / 9.6 / 11 MB each in full): the first two, the last one, every 16th."""
+    return np.unique(np.concatenate([np.arange(0, S, 16), np.array([0, 1, S - 1])]))
+
+
+def g9b_flava(out_dir):
+    """G9b (round 4): G9 at B = 8 (first 8 examples of the B=8 batch of seed 17) with PER-LAYER taps -- the outputs of text layers 0 / 6 / 11, image
+    layers 0 / 11 and multimodal layers 0 / 5 of the reference (forward hooks on its FlavaLayer modules; token rows g9b_tap_rows) -- next to what G9
+    stores (trans_hidden rows, mask logits, loss, ranks, every gradient norm, strided gradient samples).  Same weights as G9 (seed 13)."""
+    from oracle import flava_oracle as FO
+    from oracle.gen_goldens import load_reference_flava
+    from transformers import FlavaConfig
+    t0 = time.time()
+    fl = load_reference_flava()
+    cfgd = D.data_config(seed=1234)
+    c0 = FO.FlavaCfg(vocab_size=D.VOCAB - 1)
+    sd0 = FO.init_params(c0, seed=13)
+    W = sd0["flava.text_model.embeddings.word_embeddings.weight"]
+    sd = dict(sd0)
+    sd["flava.text_model.embeddings.word_embeddings.weight"] = torch.cat([W, W[torch.tensor(cfgd["analogy_relation_ids"])].mean(0, keepdim=True)], 0)
+    sd["cls.bias"] = torch.cat([sd0["cls.bias"], torch.zeros(1)])
+    cfg = FlavaConfig(text_config=dict(vocab_size=D.VOCAB), image_config=dict(), multimodal_config=dict())
+    torch.manual_seed(0)
+    model = fl.FlavaForMaskedLM(cfg)
+    model.cls.decoder.weight = model.flava.text_model.embeddings.word_embeddings.weight
+    model.flava.text_model.embeddings.word_embeddings.padding_idx = None
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    named = dict(model.named_parameters())
+    assert set(named) == set(sd), (set(named) ^ set(sd))
+    model.eval()
+    B, L = 8, 64
+    batch = D.make_batch(B, L, seed=17)
+    taps = {}
+    hooks = []
+    for mod, ls in G9B_TAPS:
+        for l in ls:
+            layer = getattr(model.flava, mod).encoder.layer[l]
+            hooks.append(layer.register_forward_hook(lambda m, i, o, key=f"{mod[0]}{l}": taps.__setitem__(key, (o[0] if isinstance(o, tuple) else o).detach())))
+    ids = torch.tensor(cfgd["analogy_entity_ids"])
+    out, trans = model(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], token_type_ids=batch["token_type_ids"],
+                       pixel_values=batch["pixel_values"], sep_idx=batch["sep_idx"], return_dict=True)
+    for h in hooks:
+        h.remove()
+    ar = torch.arange(B)
+    _, mask_idx = (batch["input_ids"] == 103).nonzero(as_tuple=True)
+    mask_logits = out.logits[ar, mask_idx][:, ids]
+    loss = O.label_smooth_ce(mask_logits, batch["label"], 0.1) + 0.45 * O.relaxation_loss(trans, batch["rel_idx"], batch["q_head_idx"],
+                                                                                          batch["a_head_idx"])
+    loss.backward()
+    rows = torch.stack([mask_idx, batch["q_head_idx"], batch["a_head_idx"], batch["rel_idx"][:, 0], batch["rel_idx"][:, 1]], 1)
+    none_grad = sorted(n for n, p in named.items() if p.grad is None)
+    norms = {n: float(p.grad.double().norm()) for n, p in named.items() if p.grad is not None}
+    names = ["cls.transform.dense.weight", "cls.bias", "flava.text_model.embeddings.word_embeddings.weight",
+             "flava.image_model.embeddings.position_embeddings", "flava.image_model.embeddings.patch_embeddings.projection.weight",
+             "flava.multimodal_model.cls_token", "flava.image_to_mm_projection.weight", "flava.text_to_mm_projection.weight",
+             "flava.multimodal_model.layernorm.weight", "flava.text_model.embeddings.LayerNorm.bias"]
+    for mod, ls in G9B_TAPS:
+        for l in ls:
+            p = f"flava.{mod}.encoder.layer.{l}."
+            names += [p + "attention.attention.query.weight", p + "attention.attention.value.weight", p + "attention.output.dense.weight",
+                      p + "layernorm_before.weight", p + "intermediate.dense.weight", p + "output.dense.weight", p + "layernorm_after.bias"]
+            if mod == "text_model":
+                names += [p + "attention.attention.adaptive_weight.0", p + "attention.attention.adaptive_weight.1"]
+    samples = {"gs::" + n: grad_sample(named[n].grad) for n in names if named[n].grad is not None}
+    tap_out = {}
+    for k, v in taps.items():
+        assert v.shape[0] == B and v.shape[2] == 768, (k, v.shape)
+        r = g9b_tap_rows(v.shape[1])
+        tap_out["tap::" + k] = v[:, torch.from_numpy(r)].numpy()
+        tap_out["tapnorm::" + k] = np.float64(float(v.double().norm()))
+    ranks = O.ranks_double_sort(mask_logits.detach(), batch["label"])
+    pix = batch["pixel_values"]
+    np.savez_compressed(
+        os.path.join(out_dir, "g9b_flava_b8.npz"), B=np.int64(B), L=np.int64(L), weight_seed=np.int64(13), batch_seed=np.int64(17),
+        pixel_sum=np.float64(float(pix.double().sum())), pixel_abs_sum=np.float64(float(pix.double().abs().sum())),
+        **{"in::" + k: v.numpy() for k, v in batch.items() if k != "pixel_values"},
+        mask_logits=mask_logits.detach().numpy(), trans_rows=trans.detach()[ar[:, None], rows].numpy(), trans_row_index=rows.numpy(),
+        loss=np.float64(float(loss.detach())), ranks=np.asarray(ranks), none_grad=np.array(none_grad),
+        grad_norm_names=np.array(sorted(norms)), grad_norm_vals=np.array([norms[k] for k in sorted(norms)]), **samples, **tap_out)
+    print(f"g9b_flava_b8: loss {float(loss):.6f} ranks {np.asarray(ranks).tolist()} taps {sorted(taps)} none-grad {len(none_grad)} ({time.time() - t0:.1f} s)", flush=True)
+
+
 def main():
     p = ap.ArgumentParser()
     p.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -273,6 +359,8 @@ def main():
         run(lit, unimo, a.out, **j)
     if not a.only or a.only in "g9_flava_real":
         g9_flava(a.out)
+    if not a.only or a.only in "g9b_flava_b8":
+        g9b_flava(a.out)
 
 
 if __name__ == "__main__":

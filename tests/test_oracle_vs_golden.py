@@ -356,3 +356,40 @@ def test_g9_flava_oracle_matches_reference_at_real_dimensions(golden_dir):
             continue
         got = float(sdg[n].grad.double().norm()) if sdg[n].grad is not None else 0.0
         assert abs(got - ref) <= 3e-3 * ref + 1e-7, (n, got, ref)
+
+
+def test_g9b_flava_oracle_per_layer_taps(golden_dir):
+    """G9b: the FLAVA oracle layer by layer against the reference's own per-layer outputs (forward hooks on FlavaLayer: text 0 / 6 / 11, image 0 / 11,
+    multimodal 0 / 5) at real dimensions, first 2 of the golden's 8 examples (eval mode: examples are independent), plus their mask logits."""
+    from mkg_analogy_amd import data_synth as D
+    from oracle import flava_oracle as FO
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8))))
+    g = dict(np.load(os.path.join(golden_dir, "g9b_flava_b8.npz"), allow_pickle=False))
+    cfg = D.data_config(seed=1234)
+    sd0 = FO.init_params(FO.FlavaCfg(vocab_size=D.VOCAB - 1), seed=int(g["weight_seed"]))
+    W = sd0["flava.text_model.embeddings.word_embeddings.weight"]
+    sd = dict(sd0)
+    sd["flava.text_model.embeddings.word_embeddings.weight"] = torch.cat([W, W[torch.tensor(cfg["analogy_relation_ids"])].mean(0, keepdim=True)], 0)
+    sd["cls.bias"] = torch.cat([sd0["cls.bias"], torch.zeros(1)])
+    c = FO.FlavaCfg(vocab_size=D.VOCAB)
+    batch = D.make_batch(int(g["B"]), int(g["L"]), seed=int(g["batch_seed"]))
+    for k, v in batch.items():
+        if k != "pixel_values":
+            assert np.array_equal(v.numpy(), g["in::" + k]), k
+    n = 2
+    taps = {}
+    with torch.no_grad():
+        trans = FO.forward(sd, c, batch["input_ids"][:n], batch["attention_mask"][:n], batch["token_type_ids"][:n], batch["pixel_values"][:n],
+                           batch["sep_idx"][:n], taps=taps)
+        rows = torch.from_numpy(g["trans_row_index"])[:n]
+        ml = FO.score(sd, trans[torch.arange(n), rows[:, 0]], torch.tensor(cfg["analogy_entity_ids"]))
+    np.testing.assert_allclose(ml.numpy(), g["mask_logits"][:n], atol=2e-4)
+    keys = sorted(k[5:] for k in g if k.startswith("tap::"))
+    assert keys == ["i0", "i11", "m0", "m5", "t0", "t11", "t6"]
+    for k in keys:
+        ref = g["tap::" + k][:n]
+        S = taps[k].shape[1]
+        r = np.unique(np.concatenate([np.arange(0, S, 16), np.array([0, 1, S - 1])]))
+        got = taps[k][:, torch.from_numpy(r)].numpy()
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert rel < 2e-5, (k, rel)
