@@ -358,16 +358,16 @@ def main():
         n, fl, kms, by = fam.get("gemm_nt_256", [0, 0.0, 0.0, 0.0])
         n_ov, fl_ov, kms_ov, _ = fam_ov.get("gemm_nt_256", [0, 0.0, 0.0, 0.0])
         ach = fl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-        # HBM traffic of the dominant kernel: PMC passes of this same command (tools/pmc.sh, profiles/r03_pmc_gemm_nt.json).  The file
+        # HBM traffic of the dominant kernel: PMC passes of this same command (tools/pmc.sh, profiles/r04_pmc_gemm_nt.json).  The file
         # names the kernel source it was collected on; when gemm_nt.hip has changed since, the number is withheld instead of going stale.
         traffic, traffic_note = None, "no PMC collection for this configuration"
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_gemm_nt.json")
+        pmc = os.path.join(ROOT, "profiles", "r04_pmc_gemm_nt.json")
         if os.path.exists(pmc) and a.batch == 256 and a.patch == 16 and a.seq_len == 64 and a.model == "mkgformer" and not pre:
             pj = json.load(open(pmc))
             if pj.get("source_sha16") == source_sha16("gemm_nt.hip", "common.h"):
-                traffic, traffic_note = pj.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, {pj.get('launches_averaged')} launches (profiles/r03_pmc_gemm_nt.json)"
+                traffic, traffic_note = pj.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, {pj.get('launches_averaged')} launches (profiles/r04_pmc_gemm_nt.json)"
             else:
-                traffic_note = "profiles/r03_pmc_gemm_nt.json was collected on an older gemm_nt.hip: withheld"
+                traffic_note = "profiles/r04_pmc_gemm_nt.json was collected on an older gemm_nt.hip: withheld"
 
         def famrow(key, name, bound_tf=2500.0):
             c, f, m, _ = fam.get(key, [0, 0.0, 0.0, 0.0])

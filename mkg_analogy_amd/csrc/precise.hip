@@ -49,33 +49,32 @@ __global__ void split3_k(const float* __restrict__ src, long long ld, bf16* __re
 }
 
 // The two-term split of a dense [rows, K] matrix (K % 8 == 0): the shape behind every GEMM of the fp32-accurate evaluation pass (140 launches, 13 ms of
-// its 108 at one element quad per thread and iteration: a dependent load -> three 8-byte stores chain at 1.3 TB/s).  Here a thread owns 16 consecutive
-// elements: four 16-byte loads in flight, 16-byte stores, nontemporal both ways (the result is read once, by the GEMM that follows).
+// its 108 at one element quad per thread and iteration: a dependent load -> three 8-byte stores chain at 1.3 TB/s).  Here a thread has four quads in
+// flight, 256 quads apart, so that every wave-instruction still covers one contiguous kilobyte (sixteen CONSECUTIVE elements per thread put the lanes of a
+// load 64 bytes apart: twice as slow as the plain kernel).
 __global__ __launch_bounds__(256) void split3_fast_k(const float* __restrict__ src, long long ld, bf16* __restrict__ dst, int rows, int K, int role) {
-  const int per_row = K / 16;                              // 16-element groups per row
-  const long long total = (long long)rows * per_row;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / per_row;
-    const int c = (int)(i % per_row) * 16;
-    const float* sp = src + r * ld + c;
-    f32x4 x[4];
+  const int qpr = K / 4;                                   // element quads per row
+  const long long total = (long long)rows * qpr;
+  constexpr int U = 4;                                     // quads per thread and iteration: four independent 16-byte loads in flight, each wave-instruction contiguous
+  for (long long base = (long long)blockIdx.x * (256 * U); base < total; base += (long long)gridDim.x * (256 * U)) {
+    f32x4 x[U];
+    long long r[U]; int c[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = __builtin_nontemporal_load((const f32x4*)(sp + 4 * u));
-    bf16x8 h[2], m[2];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bf16x4 hh = f4_to_bf4(x[u]);
-      const f32x4 hf = bf4_to_f4(hh);
-      const bf16x4 mm = f4_to_bf4(f32x4{x[u][0] - hf[0], x[u][1] - hf[1], x[u][2] - hf[2], x[u][3] - hf[3]});
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { h[u >> 1][(u & 1) * 4 + e] = hh[e]; m[u >> 1][(u & 1) * 4 + e] = mm[e]; }
+    for (int u = 0; u < U; ++u) {
+      const long long i = min(base + u * 256 + threadIdx.x, total - 1);
+      r[u] = i / qpr; c[u] = (int)(i % qpr) * 4;
+      x[u] = __builtin_nontemporal_load((const f32x4*)(src + r[u] * ld + c[u]));
     }
-    bf16* o = dst + r * 3LL * K + c;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      __builtin_nontemporal_store(h[u], (bf16x8*)(o + 8 * u));
-      __builtin_nontemporal_store(role == 0 ? m[u] : h[u], (bf16x8*)(o + K + 8 * u));
-      __builtin_nontemporal_store(role == 0 ? h[u] : m[u], (bf16x8*)(o + 2 * K + 8 * u));
+    for (int u = 0; u < U; ++u) {
+      if (base + u * 256 + threadIdx.x >= total) continue;
+      const bf16x4 h = f4_to_bf4(x[u]);
+      const f32x4 hf = bf4_to_f4(h);
+      const bf16x4 m = f4_to_bf4(f32x4{x[u][0] - hf[0], x[u][1] - hf[1], x[u][2] - hf[2], x[u][3] - hf[3]});
+      bf16* o = dst + r[u] * 3LL * K + c[u];
+      *(bf16x4*)(o) = h;
+      *(bf16x4*)(o + K) = role == 0 ? m : h;
+      *(bf16x4*)(o + 2 * K) = role == 0 ? h : m;
     }
   }
 }
@@ -262,23 +261,37 @@ __global__ __launch_bounds__(64 * AM_WAVES) void attn_f32_mfma_k(mart_attn_f32_d
   fetch(0);
   stash();
   __syncthreads();
+  const bool has_mask = p.attn_mask != nullptr;
   const bool wave_on = blockIdx.x * (32 * AM_WAVES) + wave * 32 < p.Sq;      // a wave past the last query only helps staging (393 queries = 12.3 waves of 16)
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles) fetch(t + 1);
     if (wave_on) {
     // ---- S^T tile
+    // operands of a whole MFMA chain are fetched from LDS BEFORE the chain (the compiler otherwise places each ds_read right in front of the two MFMAs
+    // that use it and waits for it there: one exposed LDS round trip per 128 cycles of matrix work); the V operands of the second chain are requested
+    // here as well, so that their latency hides behind the softmax arithmetic
+    float ka[32], va[2][16];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) ka[s] = Ks[l31 * AM_LD + hf + 2 * s];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int key = (s & 3) + 8 * (s >> 2) + 4 * hf;
+      va[0][s] = Vs[key * AM_LD + l31];
+      va[1][s] = Vs[key * AM_LD + 32 + l31];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * AM_LD + hf + 2 * s], qreg[s], st, 0, 0, 0);
+    for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qreg[s], st, 0, 0, 0);
     float mx = -3.0e38f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = t * AM_KT + (r & 3) + 8 * (r >> 2) + 4 * hf;        // key of this register
       float v = st[r] * p.scale;
       if (j >= sp) v *= rw;
-      if (p.attn_mask && j < Stot && p.attn_mask[b * p.Sk + j] == 0) v += -10000.0f;
+      if (has_mask) v += (p.attn_mask[b * p.Sk + min(j, Stot - 1)] == 0) ? -10000.0f : 0.f;
       if (j >= Stot) v = -3.0e38f;
       st[r] = v;
       mx = fmaxf(mx, v);
@@ -301,9 +314,8 @@ __global__ __launch_bounds__(64 * AM_WAVES) void attn_f32_mfma_k(mart_attn_f32_d
     // ---- O^T += V^T P^T, keys in register order
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const int key = (s & 3) + 8 * (s >> 2) + 4 * hf;
-      ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * AM_LD + l31], st[s], ot[0], 0, 0, 0);
-      ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * AM_LD + 32 + l31], st[s], ot[1], 0, 0, 0);
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0][s], st[s], ot[0], 0, 0, 0);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[1][s], st[s], ot[1], 0, 0, 0);
     }
     }
     __syncthreads();                                                   // every wave is through tile t
@@ -317,6 +329,145 @@ __global__ __launch_bounds__(64 * AM_WAVES) void attn_f32_mfma_k(mart_attn_f32_d
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *(f32x4*)(op + dt * 32 + 8 * g + 4 * hf) = f32x4{ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv, ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv};
+  }
+}
+
+// ---- the image-text fusion op (BertFusion, modeling_unimo.py:400-414: one head of 768, unscaled, unmasked) on the f32 matrix pipe.
+// One 8-wave workgroup per (example, 32 queries).  Phase 1: S^T[key][q] = sum_d vis[key][d] ctx[q][d], d streamed through LDS in 32-wide chunks, wave w
+// owning the 32-key tiles {w, w + 8} (lane = query, registers = keys).  Phase 2: softmax over all keys of a query = lane-local + one exchange between the
+// lane halves + one through LDS between the waves; the probabilities go to an LDS image P[key][q].  Phase 3: O^T[d][q] = sum_key vis[key][d] P[key][q],
+// keys streamed in 16-row chunks, wave w owning the 32-wide output column tiles {3w, 3w + 1, 3w + 2}.  ~90 us per layer at B = 256 against 1.4 ms for
+// the FMA loops of attn_f32_k<768>.
+constexpr int FM_DC = 32, FM_KC = 16, FM_LD = 33, FM_VLD = 769;
+__global__ __launch_bounds__(512) void fusion_f32_mfma_k(mart_attn_f32_desc p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  const int NKP = ntiles * 32;
+  const int areg = max(NKP * FM_LD, FM_KC * FM_VLD);
+  float* Va = fsm;                         // phase 1: vis chunk [NKP][33]; phase 3: vis chunk [16][769]
+  float* Ps = fsm + areg;                  // [NKP][33] probabilities
+  float* Qs = Ps + NKP * FM_LD;            // [32][33] query chunk
+  float* red = Qs + 32 * FM_LD;            // [2][8][32] cross-wave max / sum
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long b = blockIdx.z;
+  const int q0 = blockIdx.x * 32;
+  const int Sk = p.Sk;
+  const bool own1 = wave + 8 < ntiles;     // (wave < ntiles always holds for tile 0 when ntiles >= 8; guarded below for small key counts)
+  const bool own0 = wave < ntiles;
+  f32x16 st[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { st[0][r] = 0.f; st[1][r] = 0.f; }
+  // ---------------- phase 1
+  for (int dc = 0; dc < 768 / FM_DC; ++dc) {
+    __syncthreads();
+    {
+      const int q = tid >> 4, dd = (tid & 15) * 2;
+      const float* qp = p.q + (b * p.Sq + min(q0 + q, p.Sq - 1)) * p.ldq + dc * FM_DC + dd;
+      Qs[q * FM_LD + dd] = qp[0]; Qs[q * FM_LD + dd + 1] = qp[1];
+    }
+    for (int i = tid; i < NKP * 8; i += 512) {
+      const int key = i >> 3, c4 = (i & 7) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (key < Sk) v = *(const f32x4*)(p.k + (b * Sk + key) * p.ldk + dc * FM_DC + c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Va[key * FM_LD + c4 + e] = v[e];
+    }
+    __syncthreads();
+    float qa[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qa[s] = Qs[l31 * FM_LD + hf + 2 * s];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 0 ? !own0 : !own1) continue;
+      const int t = wave + 8 * u;
+      float ka[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) ka[s] = Va[(t * 32 + l31) * FM_LD + hf + 2 * s];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) st[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qa[s], st[u], 0, 0, 0);
+    }
+  }
+  // ---------------- phase 2: softmax over keys (rows of S^T), per query column
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (wave + 8 * u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+      const bool ok = (u == 0 ? own0 : own1) && key < Sk;
+      st[u][r] = ok ? st[u][r] * p.scale : -3.0e38f;
+      mx = fmaxf(mx, st[u][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (hf == 0) red[wave * 32 + l31] = mx;
+  __syncthreads();
+  float gm = -3.0e38f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) gm = fmaxf(gm, red[w * 32 + l31]);
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = st[u][r] > -1.0e38f ? expf(st[u][r] - gm) : 0.f;
+      st[u][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  if (hf == 0) red[256 + wave * 32 + l31] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) tot += red[256 + w * 32 + l31];
+  const float inv = 1.f / tot;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (u == 0 ? !own0 : !own1) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ps[((wave + 8 * u) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * FM_LD + l31] = st[u][r] * inv;
+  }
+  // ---------------- phase 3
+  f32x16 ot[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[j][r] = 0.f;
+  const int nkc = (Sk + FM_KC - 1) / FM_KC;
+  for (int kc = 0; kc < nkc; ++kc) {
+    __syncthreads();                                       // previous chunk consumed (first pass: the P image is complete, the phase-1 chunk is dead)
+#pragma unroll
+    for (int u = 0; u < (FM_KC * 192) / 512; ++u) {
+      const int i = u * 512 + tid, key = i / 192, c4 = (i % 192) * 4;
+      const int kk = kc * FM_KC + key;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (kk < Sk) v = *(const f32x4*)(p.v + (b * Sk + kk) * p.ldv + c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Va[key * FM_VLD + c4 + e] = v[e];
+    }
+    __syncthreads();
+    float pb[8], va[3][8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k2 = 2 * s + hf;
+      pb[s] = (kc * FM_KC + k2 < NKP) ? Ps[(kc * FM_KC + k2) * FM_LD + l31] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) va[j][s] = Va[k2 * FM_VLD + (3 * wave + j) * 32 + l31];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ot[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[j][s], pb[s], ot[j], 0, 0, 0);
+  }
+  const int qi = q0 + l31;
+  if (qi < p.Sq) {
+    float* op = p.ctx + (b * p.Sq + qi) * p.ldctx;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)(op + (3 * wave + j) * 32 + 8 * g + 4 * hf) = f32x4{ot[j][4 * g], ot[j][4 * g + 1], ot[j][4 * g + 2], ot[j][4 * g + 3]};
   }
 }
 
@@ -555,9 +706,9 @@ extern "C" int mart_split_bf16x3_rows(const float* src, long long ld, const int3
 
 extern "C" int mart_split_bf16x3(const float* src, long long ld, void* dst_bf16, int rows, int K, int role, int terms, void* stream) {
   MART_CHECK((terms == 2 || terms == 3) && src && dst_bf16 && rows > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0 && (role == 0 || role == 1), "split_bf16x3: bad args");
-  if (terms == 2 && K % 16 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst_bf16 & 15) == 0) {
-    const long long groups = (long long)rows * (K / 16);
-    const int blk = (int)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
+  if (terms == 2 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst_bf16 & 7) == 0) {
+    const long long groups = ((long long)rows * (K / 4) + 1023) / 1024;
+    const int blk = (int)(groups < 8192 ? groups : 8192);
     hipLaunchKernelGGL(split3_fast_k, dim3(blk), dim3(256), 0, (hipStream_t)stream, src, ld, (bf16*)dst_bf16, rows, K, role);
     MART_LAUNCH_CHECK();
     return 0;
@@ -595,6 +746,24 @@ extern "C" int mart_attn_fwd_f32(const mart_attn_f32_desc* d, void* stream) {
   if (d->D == 64 && !scalar && d->ldctx % 4 == 0 && ((uintptr_t)d->ctx & 15) == 0 && ((uintptr_t)d->k & 15) == 0 && ((uintptr_t)d->v & 15) == 0 &&
       (!d->pk || (((uintptr_t)d->pk & 15) == 0 && ((uintptr_t)d->pv & 15) == 0))) {
     hipLaunchKernelGGL(attn_f32_mfma_k, dim3((d->Sq + 32 * AM_WAVES - 1) / (32 * AM_WAVES), d->nh, d->B), dim3(64 * AM_WAVES), 0, (hipStream_t)stream, *d);
+    MART_LAUNCH_CHECK();
+    return 0;
+  }
+  if (d->D == 768 && !scalar && d->nh == 1 && d->Lp == 0 && !d->attn_mask && !d->sep && d->Sk <= 512 && d->ldq % 4 == 0 && d->ldctx % 4 == 0 &&
+      ((uintptr_t)d->ctx & 15) == 0 && ((uintptr_t)d->k & 15) == 0 && ((uintptr_t)d->v & 15) == 0) {
+    const int ntiles = (d->Sk + 31) / 32, NKP = ntiles * 32;
+    const int areg = NKP * FM_LD > FM_KC * FM_VLD ? NKP * FM_LD : FM_KC * FM_VLD;
+    const size_t lds = (size_t)(areg + NKP * FM_LD + 32 * FM_LD + 512) * sizeof(float);
+    static MartAttrOnce once;
+    bool* attr_set = once.slot();
+    if (!*attr_set) {
+      if (hipFuncSetAttribute((const void*)fusion_f32_mfma_k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        mart_set_error("attn_f32: hipFuncSetAttribute failed");
+        return -2;
+      }
+      *attr_set = true;
+    }
+    hipLaunchKernelGGL(fusion_f32_mfma_k, dim3((d->Sq + 31) / 32, 1, d->B), dim3(512), lds, (hipStream_t)stream, *d, ntiles);
     MART_LAUNCH_CHECK();
     return 0;
   }

@@ -97,6 +97,29 @@ def test_attn_f32_kernel():
     assert e1 < 2e-5 and e2 < 2e-5 and e3 < 2e-4
 
 
+def test_attn_f32_mfma_kernels_at_real_shapes():
+    """The f32 matrix-pipe kernels (v_mfma_f32_32x32x2_f32) at the benchmark's shapes: vision attention 393 queries x (64 prefix + 393 own) keys, the
+    FLAVA text variant (row 0 exempt from the reweight), and the fusion op 64 x 393 x 768 with a sharp softmax."""
+    from mkg_analogy_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, nh, H, Nv, L = 2, 12, 768, 393, 64
+    qkv, pre = torch.randn(B * Nv, 3 * H, generator=g), torch.randn(B * L, 3 * H, generator=g)
+    ctx = torch.empty(B * Nv, H, device=DEV)
+    dq, dp = qkv.to(DEV), pre.to(DEV)
+    ops.attn_fwd_f32(q=dq[:, :H], k=dq[:, H:2 * H], v=dq[:, 2 * H:], ctx=ctx, B=B, nh=nh, D=64, Sq=Nv, Sk=Nv, scale=0.125, pk=dp[:, H:2 * H], pv=dp[:, 2 * H:], Lp=L)
+    ref = _ref_attn(qkv[:, :H].reshape(B, Nv, H), qkv[:, H:2 * H].reshape(B, Nv, H), qkv[:, 2 * H:].reshape(B, Nv, H), nh, 0.125,
+                    pre[:, H:2 * H].reshape(B, L, H), pre[:, 2 * H:].reshape(B, L, H))
+    e1 = (ctx.cpu().double().view(B, Nv, H) - ref).abs().max().item()
+    c = 0.3 * torch.randn(B * L, H, generator=g)
+    vis = torch.randn(B * Nv, H, generator=g)
+    fus = torch.empty(B * L, H, device=DEV)
+    ops.attn_fwd_f32(q=c.to(DEV), k=vis.to(DEV), v=vis.to(DEV), ctx=fus, B=B, nh=1, D=H, Sq=L, Sk=Nv, scale=1.0)
+    ref = _ref_attn(c.view(B, L, H), vis.view(B, Nv, H), vis.view(B, Nv, H), 1, 1.0)
+    e3 = (fus.cpu().double().view(B, L, H) - ref).abs().max().item()
+    print(f"\nf32 MFMA kernels at real shapes: vision 393 x 457 max|err| {e1:.2e}, fusion 64 x 393 x 768 {e3:.2e}")
+    assert e1 < 2e-5 and e3 < 2e-4
+
+
 def _setup(patch, seed, conditioned):
     from tests.test_model_gpu import _product, _oracle_sd
     model, lit, cfg, vc = _product(patch, seed=seed, conditioned=conditioned)

@@ -1,0 +1,44 @@
+#!/bin/bash
+# Evidence of a round's final state, one gpurun call: the bench line, rocprofv3 kernel-trace summaries (serial + shipped schedule), PMC passes of the
+# dominant kernel (-> roofline.traffic), the other BASELINE configurations.  Everything lands in gpurun_out/; what is judged is copied to profiles/.
+# usage: bash tools/profile_round.sh r04
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=${1:-r04}
+mkdir -p gpurun_out
+timeout 600 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json
+for mode in serial overlap; do
+  if [ $mode = serial ]; then export MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0; else export MART_OVERLAP_WGRAD=1 MART_TWO_STREAM=1; fi
+  rm -rf gpurun_out/prof_tmp
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --train-only > gpurun_out/prof_$mode.log 2>&1
+  DB=$(find gpurun_out/prof_tmp -name "*.db" | head -1)
+  python tools/rocpd_stats.py $DB > gpurun_out/${TAG}_bench_kernel_stats_$mode.csv
+  tail -1 gpurun_out/prof_$mode.log | cut -c1-200
+  rm -rf gpurun_out/prof_tmp
+done
+export MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --train-only"
+bash tools/pmc.sh "gemm_nt_kernel<256" gpurun_out/${TAG}_pmc_gemm_nt.txt -- $CMD > /dev/null 2>&1
+python tools/pmc_to_json.py gpurun_out/${TAG}_pmc_gemm_nt.txt gpurun_out/${TAG}_pmc_gemm_nt.json "MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0 rocprofv3 --pmc <group> -- $CMD (one pass per counter group: tools/pmc.sh)" | cut -c1-300
+bash tools/pmc.sh "gemm_tn8" gpurun_out/${TAG}_pmc_gemm_tn.txt -- $CMD > /dev/null 2>&1
+unset MART_OVERLAP_WGRAD MART_TWO_STREAM
+run() { # tag, bench args...
+  tag=$1; shift
+  timeout 600 python bench.py "$@" --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_$tag.json
+  rm -rf gpurun_out/prof_tmp
+  MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -- python bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --train-only > /dev/null 2>&1
+  DB=$(find gpurun_out/prof_tmp -name "*.db" | head -1)
+  python tools/rocpd_stats.py $DB > gpurun_out/${TAG}_kernel_stats_${tag}_serial.csv
+  rm -rf gpurun_out/prof_tmp
+  python -c "import json; d=json.load(open('gpurun_out/${TAG}_bench_$tag.json')); print('$tag', d['value'], d['unit'], d['ms_per_step'], 'ms/step', (d.get('roofline') or {}).get('step_frac_of_mfma_peak'))"
+}
+run p49 --patch 32
+run head2063 --entity-head 2063
+run pretrain --task pretrain --seq-len 96
+run pretrain_p49 --task pretrain --seq-len 96 --patch 32
+run flava --model flava --batch 128
+run cond --weights conditioned
+python - <<PY
+import json
+d = json.load(open("gpurun_out/${TAG}_bench.json"))
+print("BENCH", d["value"], d["ms_per_step"], "traffic", d["roofline"]["traffic"], d["roofline"]["traffic_source"])
+PY
