@@ -15,7 +15,7 @@ SOURCES = ["util.hip", "gemm_nt.hip", "gemm_tn.hip", "norm_embed.hip", "attentio
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # per-file extras: attention keeps MFMA results in arch VGPRs (the softmax consumes them with VALU right away; the
 # default AGPR form cost ~150 v_accvgpr moves per 16 MFMAs)
-EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "precise.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result", "-Wno-pass-failed"]
 

@@ -94,7 +94,7 @@ constexpr bool epi_packed(int EPI, int DT) {     // 16-bit outputs only, no stre
 constexpr int epi_outputs(int EPI) { return 1 + ((EPI & 4) != 0 ? 1 : 0) + ((EPI & 32) != 0 ? 1 : 0); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0, bool PERSIST = false, int DT = 0>   // ACTK: activation kind of the fast masks (literal: no erf code in the quick-GELU kernels)
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gemm_nt_kernel(Args p) {   // PIPE 3: two 4-wave workgroups per CU (<= 256 VGPRs)
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int BK = 64;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if constexpr (PIPE == 1) {
+  if constexpr (PIPE == 1 || PIPE == 3) {
     // ---- 4-slot ring of 32-deep K-steps (32 KB per slot), LDS-DMA three steps ahead behind COUNTED vmcnt waits: the
     // memory pipe always has 2-3 steps (64-96 KB per CU) in flight instead of one 64 KB burst per barrier.
     //   slot image: 64-byte rows, 16-byte chunk c' = c ^ ((row>>2)&3)  (conflict-free for the b128 service groups)
@@ -218,10 +218,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
       oB[r] = (unsigned)gn * (unsigned)p.ldb + lc * 8;
     }
     const int ns1 = p.K / 32, ns = ns1 + p.K2 / 32;
+    // PIPE 1: 4 slots, three steps ahead.  PIPE 3 (experiment: 128x256 tile, 4 waves, TWO workgroups per CU so that one workgroup's epilogue runs under
+    // the other's K loop): 3 slots of (BM + BN) x 64 B = 24 KB -> 72 KB per workgroup, two steps ahead.
+    constexpr int NSLOT = PIPE == 3 ? 3 : 4, AHEAD = NSLOT - 1;
     auto issue = [&](int t) {
       const bf16* Ap = A; const bf16* Bp = B; int k0 = t * 32;
       if (t >= ns1) { Ap = A2; Bp = B2; k0 = (t - ns1) * 32; }
-      char* sA = smem + (t & 3) * SLOT;
+      char* sA = smem + (t % NSLOT) * SLOT;
       char* sB = sA + SA;
 #pragma unroll
       for (int r = 0; r < QA; ++r) glds16(Ap + oA[r] + k0, sA + (r * NT + wave * 64) * 16);
@@ -235,16 +238,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
     for (int j = 0; j < TN; ++j) keyB[j] = (rowB[j] >> 2) & 3;
     issue(0);
     if (ns > 1) issue(1);
-    if (ns > 2) issue(2);
+    if (AHEAD > 2 && ns > 2) issue(2);
     for (int t = 0; t < ns; ++t) {
-      const int ahead = min(ns - 1 - t, 2);                 // newer steps that may stay in flight
+      const int ahead = min(ns - 1 - t, AHEAD - 1);         // newer steps that may stay in flight
       if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (QA + QB)) : "memory");
       else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QA + QB) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                          // step t visible to all; slot of step t-1 free
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 3 < ns) issue(t + 3);
-      const char* sA = smem + (t & 3) * SLOT;
+      if (t + AHEAD < ns) issue(t + AHEAD);
+      const char* sA = smem + (t % NSLOT) * SLOT;
       const char* sB = sA + SA;
       bf16x8 af[2][TM], bfr[2][TN];
 #pragma unroll
@@ -833,7 +836,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_nt_kernel(Args p)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int PIPE = 0, int EPI = -1, int ACTK = 0, bool PERSIST = false, int DT = 0>
 int launch(const Args& a, int batch, hipStream_t st) {
   constexpr int NT = 64 * WAVES_M * WAVES_N;
-  constexpr int LDS_LOOP = 2 * (BM + BN) * 64 * 2;
+  constexpr int LDS_LOOP = PIPE == 3 ? 3 * (BM + BN) * 64 : 2 * (BM + BN) * 64 * 2;
   // epilogue staging per wave: packed bf16 rows (one or two outputs) in the bf16-only lane, one f32 block otherwise
   constexpr bool PACKED = epi_packed(EPI, DT);
   constexpr int EPI_WAVE = PACKED ? epi_outputs(EPI) * 32 * (BN / WAVES_N * 2 + 16) : 32 * (BN / WAVES_N + 4) * 4;
@@ -917,6 +920,18 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   MART_CHECK(!d->b_blocked || cfg == 256, "gemm_nt: b_blocked requires the 256x256 tile");
 #ifdef MART_EXPERIMENTS
   if (cfg == 2560) return launch<256, 256, 2, 4, 1>(a, batch, st);
+  // 1282: 128x256 tiles, 4 waves, 3-slot ring of 32-deep steps, two workgroups per CU (fast epilogues where the shape allows)
+  if (cfg == 1282) {
+    const bool al = (d->ldc % (d->c_f32 ? 4 : 8) == 0) && (d->N % 256 == 0) && !d->res_bf16 && !d->bias_by_brow && !d->a_rows && !d->b_rows && d->K2 == 0 && !d->in_f16;
+    const int mk = (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->preact_grad ? F_PGRAD : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
+                   (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
+    const int kd = d->mulz ? d->mul_act : d->act;
+    if (al && mk == 0) return launch<128, 256, 1, 4, 3, 0, ACT_NONE>(a, batch, st);
+    if (al && mk == (F_CF32 | F_RES)) return launch<128, 256, 1, 4, 3, F_CF32 | F_RES, ACT_NONE>(a, batch, st);
+    if (al && mk == F_MULZ && kd == ACT_STORED) return launch<128, 256, 1, 4, 3, F_MULZ, ACT_STORED>(a, batch, st);
+    if (al && mk == (F_PREACT | F_ACT | F_PGRAD) && kd == ACT_QGELU) return launch<128, 256, 1, 4, 3, F_PREACT | F_ACT | F_PGRAD, ACT_QGELU>(a, batch, st);
+    return launch<128, 256, 1, 4, 3>(a, batch, st);
+  }
 #endif
   // fast epilogue instantiations: full-width tiles, 16-byte aligned rows, no gathers / bf16 residual / debug modes
   const int tile = cfg == 256 ? 256 : 128;

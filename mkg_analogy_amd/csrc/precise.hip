@@ -285,28 +285,38 @@ __global__ __launch_bounds__(64 * AM_WAVES) void attn_f32_mfma_k(mart_attn_f32_d
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 32; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qreg[s], st, 0, 0, 0);
+    // f32 MFMA shares the SIMD's f32 ALUs with VALU work (PMC: 10 VALU per MFMA held the matrix pipe at 45 %), so the softmax of a tile is kept lean:
+    // the text options and the key-range test run only where they can matter (wave-uniform branches), the exponential is exp2 of a pre-scaled
+    // argument (v_exp_f32, 1 ulp; the scaling adds |x| * 6e-8 relative: 1e-6 at the score ranges of this model).
+    const bool plain_tile = !p.sep && !has_mask && (t + 1) * AM_KT <= Stot;
     float mx = -3.0e38f;
+    if (plain_tile) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = t * AM_KT + (r & 3) + 8 * (r >> 2) + 4 * hf;        // key of this register
-      float v = st[r] * p.scale;
-      if (j >= sp) v *= rw;
-      if (has_mask) v += (p.attn_mask[b * p.Sk + min(j, Stot - 1)] == 0) ? -10000.0f : 0.f;
-      if (j >= Stot) v = -3.0e38f;
-      st[r] = v;
-      mx = fmaxf(mx, v);
+      for (int r = 0; r < 16; ++r) { st[r] *= p.scale; mx = fmaxf(mx, st[r]); }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = t * AM_KT + (r & 3) + 8 * (r >> 2) + 4 * hf;        // key of this register
+        float v = st[r] * p.scale;
+        if (j >= sp) v *= rw;
+        if (has_mask) v += (p.attn_mask[b * p.Sk + min(j, Stot - 1)] == 0) ? -10000.0f : 0.f;
+        if (j >= Stot) v = -3.0e38f;
+        st[r] = v;
+        mx = fmaxf(mx, v);
+      }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
+    constexpr float L2E = 1.44269504088896340736f;
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = (t * AM_KT + (r & 3) + 8 * (r >> 2) + 4 * hf) < Stot ? expf(st[r] - m_new) : 0.f;
+      const float e = __builtin_amdgcn_exp2f((st[r] - m_new) * L2E);     // masked / out-of-range keys: exp2(-huge) = 0
       st[r] = e;
       sum += e;
     }
     sum += __shfl_xor(sum, 32, 64);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);
     l_run = l_run * alpha + sum;
     m_run = m_new;
 #pragma unroll

@@ -181,6 +181,8 @@ class FlatStore:
         return self.master[s.offset:s.offset + s.numel].view(s.shape)
 
     def g(self, name: str) -> torch.Tensor:
+        if getattr(self, "_pending", None):
+            self.join_pending()                      # an off-stream zero-fill may still be in flight (optim.FusedAdamW.zero_grad)
         s = self.slots[name]
         return self.grad[s.offset:s.offset + s.numel].view(s.shape)
 
@@ -208,6 +210,8 @@ class FlatStore:
 
     def wt(self, key: str) -> torch.Tensor:
         """bf16 transposed shadow [in, sum(out)] of a GEMM weight group."""
+        if getattr(self, "_pending", None):
+            self.join_pending()                      # an off-stream refresh may still be in flight (optim.FusedAdamW.step)
         off, rows, cols = self.tslots[key]
         return self.shadow_t[off:off + rows * cols].view(cols, rows)
 
@@ -222,6 +226,7 @@ class FlatStore:
     def refresh_shadows(self) -> None:
         """master -> bf16 shadow and W^T shadow (after loading weights; AdamW keeps the first one fresh itself)."""
         from . import ops
+        self.join_pending()                          # an off-stream W^T refresh of the previous optimizer step may still be in flight
         self.version += 1
         ops.cast_f32_bf16(self.master, self.shadow)
         ops.cast_f32_f16(self.master, self.shadow_h)
@@ -234,6 +239,7 @@ class FlatStore:
         ops.transpose_table(self.shadow, self.shadow_t, self.ttable, self.ttable.shape[0])
 
     def zero_grad(self) -> None:
+        self.join_pending()
         self.grad.zero_()
 
     # ---- work enqueued on another stream that the gradient writers / the readers of the transposed shadows must not overtake

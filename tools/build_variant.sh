@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 src=$1; out=$2; shift 2
-extra=""; [ "$src" = attention.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+extra=""; { [ "$src" = attention.hip ] || [ "$src" = precise.hip ]; } && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Imkg_analogy_amd/csrc -Wno-unused-result -Wno-pass-failed $extra "$@" -c mkg_analogy_amd/csrc/$src -o /tmp/variant_${src%.hip}.o
 objs=""; for o in util gemm_nt gemm_tn norm_embed attention fusion head_optim precise; do
   if [ "$o.hip" = "$src" ]; then objs="$objs /tmp/variant_$o.o"; else objs="$objs mkg_analogy_amd/build/$o.o"; fi; done

@@ -112,8 +112,9 @@ int main(int argc, char** argv) {
       std::vector<char> h0(obytes), h1(obytes), h2(obytes);
       // old loop
       CK(hipMemsetAsync(b.C[0], 0xff, obytes, st)); CK(hipMemsetAsync(b.C[1], 0xff, obytes, st));
-      make_desc(d, c, b, 0, 0, 2563); if (mart_gemm_nt(&d, st)) { printf("old launch failed: %s\n", mart_last_error()); return 1; }
-      make_desc(d, c, b, 0, 1, 0); d.tile_cfg = 256; if (mart_gemm_nt(&d, st)) { printf("new launch failed: %s\n", mart_last_error()); return 1; }
+      const int ccfg[2] = {argc > 3 ? atoi(argv[3]) : 2563, argc > 4 ? atoi(argv[4]) : 256};       // check <rounds> [cfgA cfgB]: bitwise A == B
+      make_desc(d, c, b, 0, 0, ccfg[0]); if (mart_gemm_nt(&d, st)) { printf("old launch failed: %s\n", mart_last_error()); return 1; }
+      make_desc(d, c, b, 0, 1, 0); d.tile_cfg = ccfg[1]; if (mart_gemm_nt(&d, st)) { printf("new launch failed: %s\n", mart_last_error()); return 1; }
       CK(hipStreamSynchronize(st));
       CK(hipMemcpy(h0.data(), b.C[0], obytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), b.C[1], obytes, hipMemcpyDeviceToHost));
       bool same = !memcmp(h0.data(), h1.data(), obytes);
