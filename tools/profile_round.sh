@@ -12,6 +12,7 @@ for mode in serial overlap; do
   timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --train-only > gpurun_out/prof_$mode.log 2>&1
   DB=$(find gpurun_out/prof_tmp -name "*.db" | head -1)
   python tools/rocpd_stats.py $DB > gpurun_out/${TAG}_bench_kernel_stats_$mode.csv
+  [ $mode = overlap ] && python tools/rocpd_streams.py $DB > gpurun_out/${TAG}_streams_overlap.txt 2>&1
   tail -1 gpurun_out/prof_$mode.log | cut -c1-200
   rm -rf gpurun_out/prof_tmp
 done
