@@ -123,6 +123,8 @@ typedef struct {
   int bf16_total;                                                  /* 1: ds_bf16 = bf16(ds + add_f32) (no dropout mask) */
   float* ws; long long ws_bytes;                                   /* optional caller-owned workspace (768 * 2 * H floats suffice): per-workgroup dgamma / dbeta
                                                                       partials, added in workgroup order by a second kernel (deterministic); NULL: f32 atomics */
+  const float* add2_f32;                                           /* optional second residual operand (needs add_f32): ds = LNbwd(dy) + add_f32 + add2_f32 -- the
+                                                                      d(visual) of the fusion op of the text layer below, delivered through a side buffer */
 } mart_ln_bwd_desc;
 int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream);
 

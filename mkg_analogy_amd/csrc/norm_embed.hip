@@ -184,6 +184,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
         const long long o = (long long)m * p.H + (v * 64 + lane) * 4;
         r.add[v] = f32x4{0.f, 0.f, 0.f, 0.f}; r.dyf[v] = r.add[v]; r.dyh[v] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
         if (p.add_f32) r.add[v] = __builtin_nontemporal_load((const f32x4*)(p.add_f32 + o));
+        if (p.add2_f32) r.add[v] += __builtin_nontemporal_load((const f32x4*)(p.add2_f32 + o));
         if (p.dy_f32) r.dyf[v] = __builtin_nontemporal_load((const f32x4*)(p.dy_f32 + o));
         if (dyb) r.dyh[v] = __builtin_nontemporal_load((const bf16x4*)(dyb + o));
         r.s[v] = __builtin_nontemporal_load((const f32x4*)(p.s + o));
@@ -265,10 +266,10 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
 
 // vision-stream shape of the backward pass: dy bf16, x f32, residual gradient f32 in; f32 total + its bf16 copy out; dgamma / dbeta partials to the
 // workspace.  Straight-line and pipelined like ln_fwd_fast_k (rows past the end: clamped duplicates, weight 0 in dgamma / dbeta).
-template <int VMAX>
+template <int VMAX, bool ADD2 = false>     // ADD2: a second f32 residual operand (the fusion op's d(visual) side buffer, engine.backward)
 __global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma, int M, float* __restrict__ ds_f32, bf16* __restrict__ ds_bf16,
-                                                     float* __restrict__ ws) {
+                                                     float* __restrict__ ws, const float* __restrict__ add2 = nullptr) {
   constexpr int H = VMAX * 256;
   __shared__ float red[WPB][2][VMAX * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy
 #pragma unroll
   for (int v = 0; v < VMAX; ++v) { dg[v] = f32x4{0.f, 0.f, 0.f, 0.f}; db[v] = dg[v]; gam[v] = *(const f32x4*)(gamma + (v * 64 + lane) * 4); }
   const int iters = (M + nwaves - 1) / nwaves;
-  struct Row { f32x4 a[VMAX], s[VMAX]; bf16x4 d[VMAX]; float mean, rstd; };
+  struct Row { f32x4 a[VMAX], a2[ADD2 ? VMAX : 1], s[VMAX]; bf16x4 d[VMAX]; float mean, rstd; };
   auto row_of = [&](int k) { return min(wave_g + k * nwaves, M - 1); };
   auto fetch = [&](int k, Row& r) {
     const int m = row_of(k);
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy
 #pragma unroll
     for (int v = 0; v < VMAX; ++v) {
       r.a[v] = __builtin_nontemporal_load((const f32x4*)(add + o + v * 256));
+      if constexpr (ADD2) r.a2[v] = __builtin_nontemporal_load((const f32x4*)(add2 + o + v * 256));
       r.d[v] = __builtin_nontemporal_load((const bf16x4*)(dy + o + v * 256));
       r.s[v] = __builtin_nontemporal_load((const f32x4*)(x + o + v * 256));
     }
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy
       f32x4 t;
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] = r.rstd * (d[v][e] * gam[v][e] - c1 - xh[v][e] * c2) + r.a[v][e];
+      if constexpr (ADD2) t += r.a2[v];
       __builtin_nontemporal_store(t, (f32x4*)(ds_f32 + o + v * 256));
       *(bf16x4*)(ds_bf16 + o + v * 256) = f4_to_bf4(t);
     }
@@ -799,6 +802,7 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   MART_CHECK(d && (d->dy_f32 || d->dy_bf16), "ln_bwd: need dy_f32 or dy_bf16");
   MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_bwd: H must be a multiple of 256 and <= 1024");
   MART_CHECK(d->s && d->mean && d->rstd && d->gamma && (d->ds_f32 || d->ds_bf16), "ln_bwd: null pointer");
+  MART_CHECK(!d->add2_f32 || d->add_f32, "ln_bwd: add2_f32 is a second residual operand (needs add_f32)");
   int g = row_grid(d->M);
   // Two rows in flight per wave cost 206 VGPRs: two waves per SIMD, i.e. two 4-wave workgroups per CU -> grid = 512 is exactly ONE round
   // (768, one and a half rounds: 4.65 TB/s; 512: 5.66 TB/s at M = 100608; the one-row kernel ran 4.97 TB/s at its best grid of 768)
@@ -806,12 +810,14 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   static const int fastb = getenv("MART_LN_FAST") ? atoi(getenv("MART_LN_FAST")) : 1;
   const bool fast_shape = fastb && d->dy_bf16 && !d->dy_f32 && d->add_f32 && d->ds_f32 && d->ds_bf16 && d->bf16_total && d->p_drop == 0.f && d->ws && d->dgamma && d->dbeta &&
                           (d->H == 768 || d->H == 1024) && d->M >= 4096 &&
-                          d->add_f32 != d->ds_f32 && d->s != d->ds_f32 && d->dy_bf16 != d->ds_bf16;   // clamped duplicate rows re-read their inputs: no in-place operands
+                          d->add_f32 != d->ds_f32 && d->s != d->ds_f32 && d->dy_bf16 != d->ds_bf16 && d->add2_f32 != d->ds_f32;   // clamped duplicate rows re-read their inputs: no in-place operands
   const int cap = cap_env ? cap_env : 512;      // two workgroups per CU in one round: 6.1 TB/s for the straight-line kernel (768: 5.9, 384: 5.6, 256: 5.0), 5.66 for the general one
   if (g > cap) g = cap;
   MART_CHECK(!d->ws || d->ws_bytes >= (long long)g * 2 * d->H * (long long)sizeof(float), "ln_bwd: workspace too small (768 * 2 * H floats always suffice)");
-  if (fast_shape && d->H == 768) hipLaunchKernelGGL(ln_bwd_fast_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws);
-  else if (fast_shape) hipLaunchKernelGGL(ln_bwd_fast_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws);
+#define LNB_FAST(V_, A_) hipLaunchKernelGGL((ln_bwd_fast_k<V_, A_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws, d->add2_f32)
+  if (fast_shape && d->H == 768) { if (d->add2_f32) LNB_FAST(3, true); else LNB_FAST(3, false); }
+  else if (fast_shape) { if (d->add2_f32) LNB_FAST(4, true); else LNB_FAST(4, false); }
+#undef LNB_FAST
   else if (d->H <= 768) hipLaunchKernelGGL(ln_bwd_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(ln_bwd_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();

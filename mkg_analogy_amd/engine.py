@@ -82,6 +82,7 @@ class UnimoEngine:
         # pass is unchanged (bf16 operands: gradients need the range).  Replaces round 3's split-precision text stream (2.5x the text
         # forward FLOPs for the same logit error).  MART_TEXT_F16=0: plain bf16 text stream (A/B).
         self.text_f16 = os.environ.get("MART_TEXT_F16", "1") == "1"
+        self.fusion_side = os.environ.get("MART_FUSION_SIDE", "1") == "1"   # d(visual) of the fusion op through a side buffer (see backward)
         self._w3cache: Dict[str, tuple] = {}
 
     # ------------------------------------------------------------------ helpers
@@ -484,10 +485,23 @@ class UnimoEngine:
         dxv = torch.zeros((Mv, H), device=dev, dtype=F32)             # gradient w.r.t. the vision stream
         dxvb = _e((Mv, H), BF, dev)
         ev_vdone = self._main_record()                                # dxv / dxvb exist
-        ev_vattn = ev_tfus = None
-        for l in reversed(range(self.n_layers)):
-            # ================= text layer l
-            dxvb_fresh = False
+        ev_vattn = None
+        # d(visual) of the fusion op of text layer l (l = 8 .. 10) through a SIDE buffer: fusion_bwd used to accumulate into dxv in place, i.e. it
+        # could start only when vision layer l + 1 had finished its backward pass and vision layer l could start only when it had finished -- a
+        # 0.25-0.3 ms text-sized kernel alone on the critical path, three times per step.  With the side buffer the text stream runs it while
+        # vision layer l + 1 is still going, and that layer's LayerNorm-1 backward (the kernel that produces dxv) adds the buffer as a second
+        # residual operand (+25 % bytes in one HBM-bound launch).  The top layer keeps the in-place form (its dxv is the zero buffer above).
+        side_mode = (self.fusion_side and self._tstream is not None and self.inject_grad is None and self.taps is None and
+                     self.fused_fusion and ops.fusion_supported(Lq, Nv, H))
+        T = dict(d_f32=d_f32, d_b16=d_b16, ev_tfus={}, A={}, A_side={}, fresh=False)
+
+        def will_side(l):
+            t_ = sv.get(f"t{l}") if l >= 0 else None
+            return bool(side_mode and t_ is not None and 0 <= l < self.n_layers - 1 and t_["fus"] is not None and t_["visT"] is None)
+
+        def text_A(l):
+            """Text layer l backward, first part: output LayerNorm, FFN, the fusion op (d(visual) -> dxv in place, or -> a side buffer)."""
+            d_f32, d_b16 = T["d_f32"], T["d_b16"]
             if self.taps is not None and d_f32.shape[0] == Mt:
                 self.taps[f"dtxt{l}"] = (d_f32 + d_b16.float() if d_b16 is not None else d_f32.clone()).view(B, Lq, H)
             if self.inject_grad is not None and f"txt{l}" in self.inject_grad:
@@ -508,7 +522,7 @@ class UnimoEngine:
                 self._wgrad(dzt, s["ab"], t + "intermediate.dense.weight", t + "intermediate.dense.bias")
                 da2 = _e((Ms, H), BF, dev)
                 ops.gemm_nt(dzt, st.wt(f"t{l}.int"), da2)
-                dctx_fus = None
+                dctx_fus = side = None
                 if fused:
                     self._wgrad(dzt, s["fus"], t + "intermediate.fusion_dense.weight", t + "intermediate.fusion_dense.bias")
                     if sub:                                                        # d(fusion_output) of the requested rows, zero elsewhere
@@ -521,9 +535,13 @@ class UnimoEngine:
                         ops.gemm_nt(dzt, st.wt(f"t{l}.fus"), dfus)
                     if s["visT"] is None:                                          # fused kernel ran forward: its backward twin
                         dctx_fus = _e((Mt, H), BF, dev)
-                        self._text_wait(ev_vdone)                                  # dxv holds the gradient left by vision layer l+1
-                        ops.fusion_bwd(s["ctx"], s["visb"], dfus, s["probs"], dctx_fus, dxv, dxvb, B, Lq, Nv, H)   # d(vis) added in place, bf16 copy refreshed
-                        dxvb_fresh = True
+                        if will_side(l):
+                            side = torch.zeros((Mv, H), device=dev, dtype=F32)     # consumed by vision layer l + 1's LayerNorm-1 backward
+                            ops.fusion_bwd(s["ctx"], s["visb"], dfus, s["probs"], dctx_fus, side, None, B, Lq, Nv, H)
+                        else:
+                            self._text_wait(T["ev_vdone"])                         # dxv holds the gradient left by vision layer l+1
+                            ops.fusion_bwd(s["ctx"], s["visb"], dfus, s["probs"], dctx_fus, dxv, dxvb, B, Lq, Nv, H)   # d(vis) added in place, bf16 copy refreshed
+                            T["fresh"] = True
                     else:
                         dprobs = _e((Mt, Nvp), F32, dev)
                         ops.gemm_nt(dfus, s["visb"], dprobs, M=Lq, N=Nv, batch=B, stride_a=Lq * H, stride_b=Nv * H, stride_c=Lq * Nvp)
@@ -542,15 +560,25 @@ class UnimoEngine:
                             ctxT, dfT = _e((B * H, Lq), BF, dev), _e((B * H, Lq), BF, dev)
                             ops.transpose_bf16(s["ctx"], ctxT, Lq, H, Lq, batch=B, stride_i=Lq * H, stride_o=H * Lq)
                             ops.transpose_bf16(dfus, dfT, Lq, H, Lq, batch=B, stride_i=Lq * H, stride_o=H * Lq)
-                            self._text_wait(ev_vdone)                              # dxv holds the gradient left by vision layer l+1
+                            self._text_wait(T["ev_vdone"])                         # dxv holds the gradient left by vision layer l+1
                             ops.gemm_nt(dscT, ctxT, dxv, A2=prT, B2=dfT, M=Nv, N=H, batch=B, stride_a=Nv * Lq, stride_b=H * Lq,
                                         stride_c=Nv * H, stride_aux=Nv * H, res_f32=dxv, C2=dxvb)     # ... and refreshes the bf16 copy
-                            dxvb_fresh = True
+                            T["fresh"] = True
                         else:
-                            self._text_wait(ev_vdone)
+                            self._text_wait(T["ev_vdone"])
                             ops.gemm_tn(dsc, s["ctx"], dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
                             ops.gemm_tn(s["probs"], dfus, dxv, M=Lq, NX=Nv, NY=H, batch=B, stride_x=Lq * Nvp, stride_y=Lq * H, stride_o=Nv * H, splits=1)
-                    ev_tfus = self._text_record()
+                    T["ev_tfus"][l] = self._text_record()
+            T["A"][l] = dict(ds2=ds2, da2=da2, dctx_fus=dctx_fus, Ms=Ms, sub=sub)
+            T["A_side"][l] = side
+
+        def text_B(l):
+            """Second part: attention-output LayerNorm, attention, Q/K/V -> the gradient w.r.t. the layer's input."""
+            a = T["A"].pop(l)
+            ds2, da2, dctx_fus, Ms, sub = a["ds2"], a["da2"], a["dctx_fus"], a["Ms"], a["sub"]
+            with self._text_ctx():
+                t = f"unimo.encoder.text_layer.{l}."
+                s = sv[f"t{l}"]
                 ds1, dso = _e((Ms, H), F32, dev), _e((Ms, H), BF, dev)
                 ops.ln_bwd(dy_f32=ds2, dy_bf16=da2, s=s["s1"], mean=s["m1"], rstd=s["r1"], gamma=st.m(t + "attention.output.LayerNorm.weight"), M=Ms, H=H,
                            ds_f32=ds1, ds_bf16=dso, p_drop=p_h, seed=seed + 11 + 4 * l,
@@ -575,7 +603,7 @@ class UnimoEngine:
                 delta = _e((B, nh, Lq), F32, dev)
                 sep_on = s["tkw"]["sep"] is not None
                 if has_prefix_grad:
-                    self._text_wait(ev_vattn)                              # prefix gradients written by vision layer l+1's attention backward
+                    self._text_wait(T["ev_vattn"])                         # prefix gradients written by vision layer l+1's attention backward
                 ops.attn_bwd(dctx=dctx, delta=delta, dq=dqkv[:, :H], dk=dqkv[:, H:2 * H], dv=dqkv[:, 2 * H:], accum_dkv=has_prefix_grad,
                              dw=st.g(t + "attention.self.adaptive_weight.0") if sep_on else None, **s["tkw"])
                 names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
@@ -586,13 +614,21 @@ class UnimoEngine:
                 if sub:                                                    # residual-path gradient of the requested rows into the [B * L, H] stream
                     d_f32 = torch.zeros((Mt, H), device=dev, dtype=F32)
                     ops.scatter_rows(ds1, R, nr, d_f32, accumulate=True)
-                    d_b16 = dtb
+                    T["d_f32"], T["d_b16"] = d_f32, dtb
                 else:
-                    d_f32, d_b16 = ds1, dtb
+                    T["d_f32"], T["d_b16"] = ds1, dtb
 
+        T["ev_vdone"], T["ev_vattn"] = ev_vdone, ev_vattn
+        text_A(self.n_layers - 1)
+        for l in reversed(range(self.n_layers)):
+            # ================= text layer l (its first part was issued ahead: right above for the top layer, inside vision layer l + 1 below)
+            text_B(l)
+            side_next = None                                           # d(visual) of the fusion of text layer l - 1, when it travels through a side buffer
             # ================= vision layer l
-            if l >= self.fuse_from:
-                self._main_wait(ev_tfus)                                   # text layer l added d(vis) into dxv
+            if l in T["ev_tfus"] and T["A_side"].get(l) is None:
+                self._main_wait(T["ev_tfus"][l])                           # text layer l added d(vis) into dxv in place
+            dxvb_fresh = T["fresh"] or T["A_side"].get(l) is not None      # in place: fusion_bwd refreshed the bf16 copy; side buffer: LayerNorm-1 of layer l + 1 did
+            T["fresh"] = False
             v = f"unimo.encoder.vision_layers.{l}."
             s = sv[f"v{l}"]
             if self.taps is not None:
@@ -630,16 +666,27 @@ class UnimoEngine:
                          q=q[:, :H], k=q[:, H:2 * H], v=q[:, 2 * H:], ctx=s["ctx"], lse=s["lse"], B=B, nh=nh, Sq=Nv, Sk=Nv, scale=0.125,
                          pk=pre[:, H:2 * H] if pre is not None else None, pv=pre[:, 2 * H:] if pre is not None else None,
                          Lp=Lq if pre is not None else 0)
-            ev_vattn = self._main_record()
+            T["ev_vattn"] = self._main_record()
             names = [v + f"self_attn.{n}" for n in ("q_proj", "k_proj", "v_proj")]
             self._tn(dqkv, s["h1"], st.fused([n + ".weight" for n in names], st.grad), colsum=st.fused([n + ".bias" for n in names], st.grad))
             dh1 = dctx
             ops.gemm_nt(dqkv, st.wt(f"v{l}.qkv"), dh1)
             del dqkv
+            early = will_side(l - 1)
+            if early:
+                # first part of text layer l - 1 (through its fusion op), issued here so that its side-buffer d(visual) can enter the LayerNorm-1
+                # backward below; it depends on text layer l's second part (issued above) and on nothing of this vision layer
+                text_A(l - 1)
+                side_next = T["A_side"][l - 1]
+                self._main_wait(T["ev_tfus"][l - 1])
+                side_next.record_stream(torch.cuda.current_stream())   # allocated on the text stream, read here
             self._join()                                               # dxvb (read by the fc2 weight-gradient GEMM) is rewritten next
             ops.ln_bwd(dy_bf16=dh1, s=s["x"], mean=s["m1"], rstd=s["r1"], gamma=st.m(v + "layer_norm1.weight"), M=Mv, H=H, add_f32=dx1,
-                       ds_f32=dxv, ds_bf16=dxvb, bf16_total=True, dgamma=st.g(v + "layer_norm1.weight"), dbeta=st.g(v + "layer_norm1.bias"))
-            ev_vdone = self._main_record()
+                       add2_f32=side_next, ds_f32=dxv, ds_bf16=dxvb, bf16_total=True, dgamma=st.g(v + "layer_norm1.weight"),
+                       dbeta=st.g(v + "layer_norm1.bias"))
+            T["ev_vdone"] = self._main_record()
+            if l > 0 and not early:
+                text_A(l - 1)                                          # (in-place form: its fusion backward adds into the dxv written just above)
             sv[f"v{l}"] = None
             sv[f"t{l}"] = None
             if l > 0:
@@ -652,7 +699,7 @@ class UnimoEngine:
             s_t, tmean, trstd = sv["temb"]
             u = "unimo.text_embeddings."
             dyd = _e((Mt, H), F32, dev)
-            ops.dropout_bwd_f32(d_f32, d_b16, dyd, Mt * H, p_h, seed + 1)
+            ops.dropout_bwd_f32(T["d_f32"], T["d_b16"], dyd, Mt * H, p_h, seed + 1)
             dse = _e((Mt, H), F32, dev)
             ops.ln_bwd(dy_f32=dyd, s=s_t, mean=tmean, rstd=trstd, gamma=st.m(u + "LayerNorm.weight"), M=Mt, H=H, ds_f32=dse,
                        dgamma=st.g(u + "LayerNorm.weight"), dbeta=st.g(u + "LayerNorm.bias"))

@@ -114,8 +114,9 @@ def ln_fwd(*, x_f32=None, y_bf16=None, y_f32=None, gamma, beta, eps, M, H, mean,
 
 
 def ln_bwd(*, dy_f32=None, dy_bf16=None, s, mean, rstd, gamma, M, H, add_f32=None, ds_f32=None, ds_bf16=None,
-           p_drop=0.0, seed=0, dgamma=None, dbeta=None, bf16_total=False):
+           p_drop=0.0, seed=0, dgamma=None, dbeta=None, bf16_total=False, add2_f32=None):
     d = L.LnBwd()
+    d.add2_f32 = _p(add2_f32)
     d.dy_f32, d.dy_bf16, d.s, d.mean, d.rstd, d.gamma = _p(dy_f32), _p(dy_bf16), _p(s), _p(mean), _p(rstd), _p(gamma)
     d.add_f32, d.M, d.H, d.ds_f32, d.ds_bf16 = _p(add_f32), M, H, _p(ds_f32), _p(ds_bf16)
     d.p_drop, d.seed, d.dgamma, d.dbeta = p_drop, seed, _p(dgamma), _p(dbeta)

@@ -244,3 +244,24 @@ def test_row_subset_helpers(ops):
     for r in range(B * nr):
         expb[int(R[r])] = (expb[int(R[r])].float() + vals[r]).to(BF)
     assert torch.equal(outb, expb)
+
+
+@pytest.mark.parametrize("M", [4096 + 3, 1000])
+def test_ln_bwd_second_residual_operand(ops, M):
+    """mart_ln_bwd.add2_f32 (the fusion op's d(visual) side buffer entering the vision LayerNorm-1 backward): the same as adding it to add_f32
+    beforehand, for the straight-line vision-stream kernel (M >= 4096) and the general one."""
+    H = 768
+    dy, x = rnd(M, H, seed=1).to(BF), rnd(M, H, seed=2)
+    a1, a2 = rnd(M, H, seed=3), rnd(M, H, seed=4, scale=0.1)
+    gamma = 1 + 0.1 * rnd(H, seed=5)
+    mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    outs = []
+    for add, add2 in ((a1, a2), (a1 + a2, None)):
+        ds, dsb = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV, dtype=BF)
+        dg, db = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+        ops.ln_bwd(dy_bf16=dy, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_f32=add, add2_f32=add2, ds_f32=ds, ds_bf16=dsb, bf16_total=True,
+                   dgamma=dg, dbeta=db)
+        outs.append((ds, dsb, dg, db))
+    close(outs[0][0], outs[1][0], 2e-6, 2e-6, "ds with the second residual operand")
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    assert float((outs[0][1].float() - outs[1][1].float()).abs().max()) <= 2.0 ** -7 * float(outs[1][0].abs().max())
