@@ -667,3 +667,36 @@ def test_full_bench_batch_forward_vs_oracle():
     lab = ml_ref[torch.arange(B), batch["label"]]
     near = ((ml_ref - lab[:, None]).abs() < 2 * e32).sum(1) - 1
     assert bool(((rank(ml32) - rank(ml_ref)).abs() <= near).all())
+
+
+def test_fusion_side_buffer_schedule_equals_the_in_place_one():
+    """engine.fusion_side (MART_FUSION_SIDE=1): the fusion op's d(visual) of text layers 8-10 goes through a side buffer that the LayerNorm-1
+    backward of the vision layer above adds as a second residual operand, instead of being accumulated into the vision-stream gradient in place.
+    Same gradients up to the order of two f32 additions."""
+    g = _load("g7_bench_cond")
+    model, lit, cfg = _product(g)
+    batch = _batch(g)
+    gb = {k: v[:16].cuda() for k, v in batch.items()}
+    st = model.store
+    model.eval()
+    res = []
+    for side in (False, True):
+        model.engine.fusion_side = side
+        st.zero_grad()
+        loss = lit.training_step(dict(gb), 1)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss.detach()), st.grad.clone()))
+    model.engine.fusion_side = False
+    (l0, g0), (l1, g1) = res
+    worst, wn = 0.0, ""
+    for n, sl in st.slots.items():
+        a, b = g0[sl.offset:sl.offset + sl.numel], g1[sl.offset:sl.offset + sl.numel]
+        na = float(a.norm())
+        if na < 1e-9:
+            continue
+        r = float((a - b).norm()) / na
+        if r > worst:
+            worst, wn = r, n
+    print(f"\nfusion d(visual) in place vs side buffer: loss {l0:.7f} / {l1:.7f}; worst gradient rel-L2 difference {worst:.3e} ({wn})")
+    assert l0 == l1 and worst < 5e-3
