@@ -125,8 +125,14 @@ typedef struct {
                                                                       partials, added in workgroup order by a second kernel (deterministic); NULL: f32 atomics */
   const float* add2_f32;                                           /* optional second residual operand (needs add_f32): ds = LNbwd(dy) + add_f32 + add2_f32 -- the
                                                                       d(visual) of the fusion op of the text layer below, delivered through a side buffer */
+  int defer_reduce;                                                /* 1 (needs ws): only the partials are written; the caller adds them with mart_ln_dgb_reduce
+                                                                      (same order, same result) -- e.g. on the weight-gradient stream, off the data-gradient chain */
 } mart_ln_bwd_desc;
 int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream);
+/* number of per-workgroup partial rows mart_ln_bwd writes into ws for M rows ([partials][2][H] floats: dgamma, dbeta) */
+int mart_ln_bwd_partials(int M);
+/* dgamma[c] += sum_g ws[g][0][c], dbeta[c] += sum_g ws[g][1][c] in a fixed order: the second half of mart_ln_bwd's deterministic path */
+int mart_ln_dgb_reduce(const float* ws, int partials, int H, float* dgamma, float* dbeta, void* stream);
 
 /* ---------------------------------------------------------------- embeddings
  * pixels f32 [B,2,3,S,S] -> bf16 patch matrix [B*2*P, 3*p*p] (k = c*p*p + ky*p + kx): the im2col-free

@@ -44,7 +44,7 @@ class LnFwd(C.Structure):
 class LnBwd(C.Structure):
     _fields_ = [("dy_f32", vp), ("dy_bf16", vp), ("s", vp), ("mean", vp), ("rstd", vp), ("gamma", vp), ("add_f32", vp),
                 ("M", i32), ("H", i32), ("ds_f32", vp), ("ds_bf16", vp), ("p_drop", f32), ("seed", u64),
-                ("dgamma", vp), ("dbeta", vp), ("bf16_total", i32), ("ws", vp), ("ws_bytes", i64), ("add2_f32", vp)]
+                ("dgamma", vp), ("dbeta", vp), ("bf16_total", i32), ("ws", vp), ("ws_bytes", i64), ("add2_f32", vp), ("defer_reduce", i32)]
 
 
 class TextEmbed(C.Structure):
@@ -106,6 +106,8 @@ _SIGS = {
     "mart_gemm_tn_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "mart_ln_fwd": (i32, [C.POINTER(LnFwd), vp]),
     "mart_ln_bwd": (i32, [C.POINTER(LnBwd), vp]),
+    "mart_ln_bwd_partials": (i32, [i32]),
+    "mart_ln_dgb_reduce": (i32, [vp, i32, i32, vp, vp, vp]),
     "mart_patchify": (i32, [vp, vp, i32, i32, i32, vp]),
     "mart_patchify_gather": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "mart_gather_images": (i32, [vp, vp, vp, i32, i32, vp]),
@@ -159,7 +161,7 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
-EXPECTED_ABI = 4            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
+EXPECTED_ABI = 5            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
 _lib = None
 
 

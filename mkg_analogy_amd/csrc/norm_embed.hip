@@ -803,6 +803,7 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_bwd: H must be a multiple of 256 and <= 1024");
   MART_CHECK(d->s && d->mean && d->rstd && d->gamma && (d->ds_f32 || d->ds_bf16), "ln_bwd: null pointer");
   MART_CHECK(!d->add2_f32 || d->add_f32, "ln_bwd: add2_f32 is a second residual operand (needs add_f32)");
+  MART_CHECK(!d->defer_reduce || d->ws, "ln_bwd: defer_reduce needs the workspace");
   int g = row_grid(d->M);
   // Two rows in flight per wave cost 206 VGPRs: two waves per SIMD, i.e. two 4-wave workgroups per CU -> grid = 512 is exactly ONE round
   // (768, one and a half rounds: 4.65 TB/s; 512: 5.66 TB/s at M = 100608; the one-row kernel ran 4.97 TB/s at its best grid of 768)
@@ -821,10 +822,22 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   else if (d->H <= 768) hipLaunchKernelGGL(ln_bwd_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(ln_bwd_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
-  if (d->ws && (d->dgamma || d->dbeta)) {
+  if (d->ws && (d->dgamma || d->dbeta) && !d->defer_reduce) {
     hipLaunchKernelGGL(ln_dgb_reduce_k, dim3(2 * d->H / 64), dim3(1024), 0, (hipStream_t)stream, d->ws, g, d->H, d->dgamma, d->dbeta);   // H % 256 == 0
     MART_LAUNCH_CHECK();
   }
+  return 0;
+}
+extern "C" int mart_ln_bwd_partials(int M) {           // the grid rule of mart_ln_bwd
+  static const int cap_env = getenv("MART_LN_BWD_GRID") ? atoi(getenv("MART_LN_BWD_GRID")) : 0;
+  const int cap = cap_env ? cap_env : 512;
+  const int g = row_grid(M);
+  return g > cap ? cap : g;
+}
+extern "C" int mart_ln_dgb_reduce(const float* ws, int partials, int H, float* dgamma, float* dbeta, void* stream) {
+  MART_CHECK(ws && partials > 0 && H > 0 && H % 256 == 0 && (dgamma || dbeta), "ln_dgb_reduce: bad args");
+  hipLaunchKernelGGL(ln_dgb_reduce_k, dim3(2 * H / 64), dim3(1024), 0, (hipStream_t)stream, ws, partials, H, dgamma, dbeta);
+  MART_LAUNCH_CHECK();
   return 0;
 }
 extern "C" int mart_text_embed_fwd(const mart_text_embed_desc* d, void* stream) {

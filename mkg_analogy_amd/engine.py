@@ -56,6 +56,7 @@ class UnimoEngine:
         self.inject: Optional[dict] = None
         self.inject_grad: Optional[dict] = None
         import os
+        self.ln_defer = os.environ.get("MART_LN_DEFER", "1") == "1"            # LayerNorm dgamma / dbeta reductions on the weight-gradient stream
         self.overlap_wgrad = os.environ.get("MART_OVERLAP_WGRAD", "1") == "1"   # weight-gradient GEMMs on a side stream (+2.5 % step rate)
         self._side: Optional[torch.cuda.Stream] = None
         self._side_busy = False
@@ -125,6 +126,23 @@ class UnimoEngine:
             ops.gemm_tn(X, Y, out, **kw)
         X.record_stream(self._side)
         Y.record_stream(self._side)
+        self._side_busy = True
+
+    def _ln_bwd(self, **kw):
+        """LayerNorm backward.  Its ordered dgamma / dbeta reduction (a 14 us launch that only feeds the flat gradient buffer) is issued on the
+        weight-gradient stream instead of sitting between two kernels of the data-gradient chain (``MART_LN_DEFER=0``: in order, as before)."""
+        if not (self.overlap_wgrad and self.ln_defer and ops.TN_DETERMINISTIC and (kw.get("dgamma") is not None or kw.get("dbeta") is not None)):
+            ops.ln_bwd(**kw)
+            return
+        ws, n = ops.ln_bwd(defer_reduce=True, **kw)
+        if self._side is None:
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("MART_WGRAD_PRIO", "0")))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            ops.ln_dgb_reduce(ws, n, kw["H"], kw.get("dgamma"), kw.get("dbeta"))
+        ws.record_stream(self._side)
         self._side_busy = True
 
     # ---- text stream (two_stream): the text layers are issued on their own HIP stream; events mirror the cross-wiring of
@@ -473,7 +491,7 @@ class UnimoEngine:
                 dtr = _e((Mh, H), F32, dev)
                 ops.gather_rows_first_f32(dtrans.view(Mt, H), R, nr, dtr)
             dyb = _e((Mh, H), BF, dev)
-            ops.ln_bwd(dy_f32=dtr, s=y, mean=hm, rstd=hr, gamma=st.m(hp + "LayerNorm.weight"), M=Mh, H=H, ds_bf16=dyb,
+            self._ln_bwd(dy_f32=dtr, s=y, mean=hm, rstd=hr, gamma=st.m(hp + "LayerNorm.weight"), M=Mh, H=H, ds_bf16=dyb,
                        dgamma=st.g(hp + "LayerNorm.weight"), dbeta=st.g(hp + "LayerNorm.bias"))
             dzh = _e((Mh, H), BF, dev)
             ops.act_bwd(dyb, zh, ops.ACT_GELU, dzh)
@@ -516,7 +534,7 @@ class UnimoEngine:
                 sub = bool(s["sub"])                                      # the post-attention part of this layer ran on the requested rows only
                 Ms = d_f32.shape[0] if sub else Mt
                 ds2, doo = _e((Ms, H), F32, dev), _e((Ms, H), BF, dev)
-                ops.ln_bwd(dy_f32=d_f32, dy_bf16=d_b16, s=s["s2"], mean=s["m2"], rstd=s["r2"], gamma=st.m(t + "output.LayerNorm.weight"), M=Ms, H=H,
+                self._ln_bwd(dy_f32=d_f32, dy_bf16=d_b16, s=s["s2"], mean=s["m2"], rstd=s["r2"], gamma=st.m(t + "output.LayerNorm.weight"), M=Ms, H=H,
                            ds_f32=ds2, ds_bf16=doo, p_drop=p_h, seed=seed + 12 + 4 * l,
                            dgamma=st.g(t + "output.LayerNorm.weight"), dbeta=st.g(t + "output.LayerNorm.bias"))
                 self._wgrad(doo, s["ht"], t + "output.dense.weight", t + "output.dense.bias")
@@ -583,7 +601,7 @@ class UnimoEngine:
                 t = f"unimo.encoder.text_layer.{l}."
                 s = sv[f"t{l}"]
                 ds1, dso = _e((Ms, H), F32, dev), _e((Ms, H), BF, dev)
-                ops.ln_bwd(dy_f32=ds2, dy_bf16=da2, s=s["s1"], mean=s["m1"], rstd=s["r1"], gamma=st.m(t + "attention.output.LayerNorm.weight"), M=Ms, H=H,
+                self._ln_bwd(dy_f32=ds2, dy_bf16=da2, s=s["s1"], mean=s["m1"], rstd=s["r1"], gamma=st.m(t + "attention.output.LayerNorm.weight"), M=Ms, H=H,
                            ds_f32=ds1, ds_bf16=dso, p_drop=p_h, seed=seed + 11 + 4 * l,
                            dgamma=st.g(t + "attention.output.LayerNorm.weight"), dbeta=st.g(t + "attention.output.LayerNorm.bias"))
                 if sub:
@@ -650,7 +668,7 @@ class UnimoEngine:
             ops.gemm_nt(dz, st.wt(f"v{l}.fc1"), dh2)
             del dz
             dx1, dx1b = _e((Mv, H), F32, dev), _e((Mv, H), BF, dev)
-            ops.ln_bwd(dy_bf16=dh2, s=s["x1"], mean=s["m2"], rstd=s["r2"], gamma=st.m(v + "layer_norm2.weight"), M=Mv, H=H, add_f32=dxv,
+            self._ln_bwd(dy_bf16=dh2, s=s["x1"], mean=s["m2"], rstd=s["r2"], gamma=st.m(v + "layer_norm2.weight"), M=Mv, H=H, add_f32=dxv,
                        ds_f32=dx1, ds_bf16=dx1b, bf16_total=True, dgamma=st.g(v + "layer_norm2.weight"), dbeta=st.g(v + "layer_norm2.bias"))
             self._wgrad(dx1b, s["ctx"], v + "self_attn.out_proj.weight", v + "self_attn.out_proj.bias")
             dctx = dh2                                                 # reuse
@@ -684,7 +702,7 @@ class UnimoEngine:
                 self._main_wait(T["ev_tfus"][l - 1])
                 side_next.record_stream(torch.cuda.current_stream())   # allocated on the text stream, read here
             self._join()                                               # dxvb (read by the fc2 weight-gradient GEMM) is rewritten next
-            ops.ln_bwd(dy_bf16=dh1, s=s["x"], mean=s["m1"], rstd=s["r1"], gamma=st.m(v + "layer_norm1.weight"), M=Mv, H=H, add_f32=dx1,
+            self._ln_bwd(dy_bf16=dh1, s=s["x"], mean=s["m1"], rstd=s["r1"], gamma=st.m(v + "layer_norm1.weight"), M=Mv, H=H, add_f32=dx1,
                        add2_f32=side_next, ds_f32=dxv, ds_bf16=dxvb, bf16_total=True, dgamma=st.g(v + "layer_norm1.weight"),
                        dbeta=st.g(v + "layer_norm1.bias"))
             T["ev_vdone"] = self._main_record()
@@ -704,14 +722,14 @@ class UnimoEngine:
             dyd = _e((Mt, H), F32, dev)
             ops.dropout_bwd_f32(T["d_f32"], T["d_b16"], dyd, Mt * H, p_h, seed + 1)
             dse = _e((Mt, H), F32, dev)
-            ops.ln_bwd(dy_f32=dyd, s=s_t, mean=tmean, rstd=trstd, gamma=st.m(u + "LayerNorm.weight"), M=Mt, H=H, ds_f32=dse,
+            self._ln_bwd(dy_f32=dyd, s=s_t, mean=tmean, rstd=trstd, gamma=st.m(u + "LayerNorm.weight"), M=Mt, H=H, ds_f32=dse,
                        dgamma=st.g(u + "LayerNorm.weight"), dbeta=st.g(u + "LayerNorm.bias"))
             ops.text_embed_scatter(dse, sv["ids"], sv["tt"], st.g(u + "word_embeddings.weight"), st.g(u + "position_embeddings.weight"),
                                    st.g(u + "token_type_embeddings.weight"), B, Lq, H)
         # ---- vision embeddings backward: pre-LN -> assemble -> patch GEMM weight gradient
         patches, s_v, vmean, vrstd = sv["vemb"]
         dsv = _e((Mv, H), F32, dev)
-        ops.ln_bwd(dy_f32=dxv, s=s_v, mean=vmean, rstd=vrstd, gamma=st.m("unimo.vision_pre_layrnorm.weight"), M=Mv, H=H, ds_f32=dsv,
+        self._ln_bwd(dy_f32=dxv, s=s_v, mean=vmean, rstd=vrstd, gamma=st.m("unimo.vision_pre_layrnorm.weight"), M=Mv, H=H, ds_f32=dsv,
                    dgamma=st.g("unimo.vision_pre_layrnorm.weight"), dbeta=st.g("unimo.vision_pre_layrnorm.bias"))
         dpe = _e((B * 2 * P, H), BF, dev)
         ops.vision_assemble_bwd(dsv, dpe, st.g("unimo.vision_embeddings.class_embedding"), st.g("unimo.vision_embeddings.position_embedding.weight"),

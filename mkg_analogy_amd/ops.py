@@ -114,7 +114,9 @@ def ln_fwd(*, x_f32=None, y_bf16=None, y_f32=None, gamma, beta, eps, M, H, mean,
 
 
 def ln_bwd(*, dy_f32=None, dy_bf16=None, s, mean, rstd, gamma, M, H, add_f32=None, ds_f32=None, ds_bf16=None,
-           p_drop=0.0, seed=0, dgamma=None, dbeta=None, bf16_total=False, add2_f32=None):
+           p_drop=0.0, seed=0, dgamma=None, dbeta=None, bf16_total=False, add2_f32=None, defer_reduce=False):
+    """LayerNorm backward.  ``defer_reduce`` (deterministic path only): the dgamma / dbeta partials stay in the returned workspace and the caller
+    adds them with :func:`ln_dgb_reduce` (same kernel, same order) -- e.g. on the weight-gradient stream; returns ``(ws, partials)`` then."""
     d = L.LnBwd()
     d.add2_f32 = _p(add2_f32)
     d.dy_f32, d.dy_bf16, d.s, d.mean, d.rstd, d.gamma = _p(dy_f32), _p(dy_bf16), _p(s), _p(mean), _p(rstd), _p(gamma)
@@ -125,7 +127,14 @@ def ln_bwd(*, dy_f32=None, dy_bf16=None, s, mean, rstd, gamma, M, H, add_f32=Non
     if TN_DETERMINISTIC and (dgamma is not None or dbeta is not None):     # ordered reduction of the per-workgroup dgamma / dbeta partials
         ws = torch.empty(768 * 2 * H, device=s.device, dtype=F32)
         d.ws, d.ws_bytes = _p(ws), ws.numel() * 4
+    defer = bool(defer_reduce) and ws is not None
+    d.defer_reduce = int(defer)
     L.check(L.lib().mart_ln_bwd(C.byref(d), _stream()), "mart_ln_bwd")
+    return (ws, int(L.lib().mart_ln_bwd_partials(M))) if defer else None
+
+
+def ln_dgb_reduce(ws, partials, H, dgamma, dbeta):
+    L.check(L.lib().mart_ln_dgb_reduce(_p(ws), partials, H, _p(dgamma), _p(dbeta), _stream()), "mart_ln_dgb_reduce")
 
 
 def patchify(pixels, out, B, S, p):

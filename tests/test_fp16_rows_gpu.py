@@ -265,3 +265,34 @@ def test_ln_bwd_second_residual_operand(ops, M):
     close(outs[0][0], outs[1][0], 2e-6, 2e-6, "ds with the second residual operand")
     assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
     assert float((outs[0][1].float() - outs[1][1].float()).abs().max()) <= 2.0 ** -7 * float(outs[1][0].abs().max())
+
+
+@pytest.mark.parametrize("M", [4096 + 3, 1000])
+def test_ln_bwd_deferred_reduction_is_the_same_sum(ops, M):
+    """mart_ln_bwd.defer_reduce + mart_ln_dgb_reduce (the dgamma / dbeta reduction issued by the caller, on another stream): bit-identical to the
+    in-order form -- same partials, same kernel, same order."""
+    H = 768
+    dy, x, a1 = rnd(M, H, seed=1).to(BF), rnd(M, H, seed=2), rnd(M, H, seed=3)
+    gamma = 1 + 0.1 * rnd(H, seed=5)
+    mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    outs = []
+    side = torch.cuda.Stream()
+    for defer in (False, True):
+        ds, dsb = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV, dtype=BF)
+        dg, db = torch.full((H,), 0.5, device=DEV), torch.full((H,), -0.25, device=DEV)      # the reduction ADDS into the gradient buffers
+        r = ops.ln_bwd(dy_bf16=dy, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_f32=a1, ds_f32=ds, ds_bf16=dsb, bf16_total=True,
+                       dgamma=dg, dbeta=db, defer_reduce=defer)
+        if defer:
+            ws, n = r
+            assert 0 < n <= 768
+            ev = torch.cuda.Event(); ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                ops.ln_dgb_reduce(ws, n, H, dg, db)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            assert r is None
+        outs.append((ds, dg, db))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert float((outs[0][1] - 0.5).abs().max()) > 0
