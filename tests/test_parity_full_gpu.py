@@ -669,6 +669,26 @@ def test_full_bench_batch_forward_vs_oracle():
     assert bool(((rank(ml32) - rank(ml_ref)).abs() <= near).all())
 
 
+def test_deferred_layernorm_reduction_schedule_is_bit_identical():
+    """engine.ln_defer (MART_LN_DEFER=1): the dgamma / dbeta reductions run on the weight-gradient stream; the sums are the same sums."""
+    g = _load("g7_bench_cond")
+    model, lit, cfg = _product(g)
+    batch = _batch(g)
+    gb = {k: v[:16].cuda() for k, v in batch.items()}
+    st = model.store
+    model.eval()
+    res = []
+    for defer in (False, True):
+        model.engine.ln_defer = defer
+        st.zero_grad()
+        loss = lit.training_step(dict(gb), 1)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss.detach()), st.grad.clone()))
+    model.engine.ln_defer = False
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+
+
 def test_fusion_side_buffer_schedule_equals_the_in_place_one():
     """engine.fusion_side (MART_FUSION_SIDE=1): the fusion op's d(visual) of text layers 8-10 goes through a side buffer that the LayerNorm-1
     backward of the vision layer above adds as a second residual operand, instead of being accumulated into the vision-stream gradient in place.
