@@ -247,12 +247,20 @@ __device__ __forceinline__ float mask_add(uint64_t mb_lane, int c) { return ((mb
 #ifndef ATTN_FWD_MINW1
 #define ATTN_FWD_MINW1 4
 #endif
-template <bool TEXT, int TPW>
-__global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void attn_fwd_k(mart_attn_fwd_desc p) {
+// RES (vision, round 4; an experiment, compiled only with -DMART_EXPERIMENTS -- measured 40 % SLOWER): the K / V of the whole head RESIDENT in LDS.  One 16-wave workgroup per (batch, head): every thread brings in one 16-byte
+// chunk of every 64-key tile of K (waves 0-7) or V (waves 8-15) with one LDS-DMA instruction per tile -- the head is staged ONCE instead of once
+// per 128-query part (four times at 393 queries, the fourth for 9 rows), by straight-line address code in a prologue instead of the branchy
+// per-tile staging of the ring -- then ONE barrier, and every wave walks the image with its 32 queries at its own pace: no barrier, no DMA wait and
+// no staging instruction in the tile loop.  Same 128 VGPRs / four waves per SIMD as the ring kernel.  LDS: 16 KB per 64 keys (112 KB at 393 keys,
+// 128 KB at 457: one workgroup per CU).
+constexpr int RES_NTH = 1024;
+template <bool TEXT, int TPW, bool RES = false>
+__global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2)) void attn_fwd_k(mart_attn_fwd_desc p) {
+  static_assert(!RES || (TPW == 1 && !TEXT), "the resident form is the vision kernel, one query tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const WgId wg = wg_id(p.nh, p.B);
+  const WgId wg = RES ? WgId{0, (int)blockIdx.x, (int)blockIdx.y} : wg_id(p.nh, p.B);
   const int b = wg.b, h = wg.h;
   const int Stot = p.Lp + p.Sk;
   const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
   float m_run[TPW], l_run[TPW];
 #pragma unroll
   for (int u = 0; u < TPW; ++u) {
-    q0[u] = wg.part * (128 * TPW) + (wave * TPW + u) * 32;
+    q0[u] = RES ? wave * 32 : wg.part * (128 * TPW) + (wave * TPW + u) * 32;
     qi[u] = q0[u] + l31;
     active[u] = q0[u] < p.Sq;                          // wave-uniform
     const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + min(qi[u], p.Sq - 1)) * p.ldq + h * 64;
@@ -294,12 +302,23 @@ __global__ __launch_bounds__(NTH, (TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2) void
       stage_tile(V, b, h, (r0_), (buf_) + TILE_BYTES, tid, wave);                                      \
     }                                                                                                  \
   } while (0)
-  stage_kv(0, smem);
-  for (int kt = 0; kt < ntiles; ++kt) {
+  if constexpr (RES) {
+    const bool isv = wave >= 8;                        // wave-uniform: waves 0-7 bring in K, waves 8-15 V
+    const Side& S = isv ? V : K;
+    const int c = tid & 511, row = c >> 3, lc = (c & 7) ^ swz_key(row);
+    char* img = smem + (isv ? ntiles * TILE_BYTES : 0) + ((wave & 7) * 64) * 16;
+    for (int kt = 0; kt < ntiles; ++kt) glds16(side_row(S, b, h, kt * 64 + row) + lc * 8, img + kt * TILE_BYTES);   // rows past the last key: clamped copies (finite)
     tile_barrier();
-    if (kt + 1 < ntiles) stage_kv((kt + 1) * 64, smem + ((kt + 1) & 1) * STAGE_BYTES);
-    const char* sK = smem + (kt & 1) * STAGE_BYTES;
-    const char* sV = sK + TILE_BYTES;
+  } else {
+    stage_kv(0, smem);
+  }
+  for (int kt = 0; kt < ntiles; ++kt) {
+    if constexpr (!RES) {
+      tile_barrier();
+      if (kt + 1 < ntiles) stage_kv((kt + 1) * 64, smem + ((kt + 1) & 1) * STAGE_BYTES);
+    }
+    const char* sK = RES ? smem + kt * TILE_BYTES : smem + (kt & 1) * STAGE_BYTES;
+    const char* sV = RES ? smem + (ntiles + kt) * TILE_BYTES : sK + TILE_BYTES;
     if (!active[0]) continue;                         // wave past the last query row: only stages tiles and keeps the barriers
     // S^T[key][q] = K q^T
     f32x16 st[TPW][2];
@@ -1519,6 +1538,9 @@ int set_attrs() {
   bool ok = true;
   for (int i = 0; i < 8; ++i) ok = ok && hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
   ok = ok && hipFuncSetAttribute((const void*)attn_bwd_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS) == hipSuccess;
+#ifdef MART_EXPERIMENTS
+  ok = ok && hipFuncSetAttribute((const void*)attn_fwd_k<false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * TILE_BYTES) == hipSuccess;
+#endif
   if (!ok) {
     mart_set_error("attn: hipFuncSetAttribute failed");
     return -2;
@@ -1533,6 +1555,16 @@ extern "C" int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream) {
   if (int rc = set_attrs()) return rc;
   const bool text = d->attn_mask || d->sep || d->p_drop > 0.f || (d->Lp & 31) != 0;   // general instantiation: every option, any prefix length
   static const int tpw = getenv("MART_ATTN_TPW") ? atoi(getenv("MART_ATTN_TPW")) : 1;
+#ifdef MART_EXPERIMENTS   // (tools/build_variant.sh attention.hip <out.so> -DMART_EXPERIMENTS; MART_ATTN_RES=1)
+  static const int res = getenv("MART_ATTN_RES") ? atoi(getenv("MART_ATTN_RES")) : 0;
+  const int Stot = d->Lp + d->Sk;
+  if (!text && res && d->Sq > 128 && d->Sq <= 512 && Stot <= 512) {          // K / V of the head resident in LDS, one 16-wave workgroup per head
+    const int nt = (Stot + 63) / 64, lds = nt * 2 * TILE_BYTES < 16 * 4096 ? 16 * 4096 : nt * 2 * TILE_BYTES;   // (>= the 16 output staging tiles)
+    hipLaunchKernelGGL((attn_fwd_k<false, 1, true>), dim3(d->nh, d->B), dim3(RES_NTH), lds, (hipStream_t)stream, *d);
+    MART_LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   if (text) hipLaunchKernelGGL((attn_fwd_k<true, 1>), dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
   else if (tpw == 2 && d->Sq > 128) hipLaunchKernelGGL((attn_fwd_k<false, 2>), dim3((d->Sq + 255) / 256, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL((attn_fwd_k<false, 1>), dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
