@@ -312,6 +312,11 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
   } else {
     stage_kv(0, smem);
   }
+  // The Q fragments (plain global loads, above) are first USED inside the loop, so the compiler put its own s_waitcnt vmcnt(3..0) for them in front
+  // of the first four MFMAs of EVERY iteration -- and the hardware counter also counts the LDS-DMA of the next tile, issued (as opaque assembly) at the
+  // top of the iteration: every S phase waited for the prefetch it had just started, i.e. the ring never ran ahead.  A compiler-visible wait here
+  // retires the Q loads before the loop; the tile loop then carries no vmcnt wait but the one in tile_barrier().
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), expcnt / lgkmcnt untouched
   for (int kt = 0; kt < ntiles; ++kt) {
     if constexpr (!RES) {
       tile_barrier();
