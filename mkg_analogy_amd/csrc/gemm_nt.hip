@@ -67,7 +67,6 @@ struct Args {
   int b_blocked;
   int stagger_ticks;                 // >0: first-wave workgroups start g*ticks (100 MHz) late, g = 0..7
   int dbg;                           // 1: skip the LDS-DMA after the first tile (timing experiment only)
-  int krot_a, krot_b;                // K-tile rotation: tile (tm, tn) starts its K loop at K-tile (tn * krot_a + tm * krot_b) mod nk (0, 0: off)
 };
 
 // Epilogue feature mask of the specialised ("fast") instantiations.  EPI < 0 = the general epilogue (tails, gathers,
@@ -135,16 +134,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
   int vb = blockIdx.x, m0 = 0, n0 = 0;
   unsigned offA[RA], offB[RB];
   long long blkB1 = 0, blkB2 = 0;
-  const int nk1 = p.K / BK, nk = nk1 + p.K2 / BK;
-  // K rotation (round 4).  The tiles_n workgroups that share an A panel sit on one XCD and walk K in lockstep, so every one of them reaches a fresh
-  // (HBM-resident) A line at the same moment and all of them wait for the same fill; started krot apart, one of them takes the miss and the
-  // others find the line in L2 a K-tile later.  The sum runs over the same K-tiles in a rotated order (deterministic; rounding differs per tile).
-  int krot = 0;
-  auto rk = [&](int t) { const int tt = t + krot; return tt >= nk ? tt - nk : tt; };
   auto set_tile = [&](int vbid) {
     const int lid = xcd_remap(vbid, total_tiles);
     m0 = (lid / tiles_n) * BM; n0 = (lid % tiles_n) * BN;
-    krot = (int)(((unsigned)(lid % tiles_n) * (unsigned)p.krot_a + (unsigned)(lid / tiles_n) * (unsigned)p.krot_b) % (unsigned)nk);
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
@@ -166,8 +158,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
   };
   set_tile(vb);
 
+  const int nk1 = p.K / BK, nk = nk1 + p.K2 / BK;
+
   auto stage = [&](int t, int buf) {
-    t = rk(t);
     const bf16* Ap = A; const bf16* Bp = B + blkB1; int k0 = t * BK;
     if (t >= nk1) { Ap = A2; Bp = B2 + blkB2; k0 = (t - nk1) * BK; }
     const long long kb = p.b_blocked ? (long long)(k0 >> 6) * 16384 : k0;      // blocked: whole 256x64 blocks per K-tile
@@ -303,9 +296,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
     bf16x8 af[2][4], bfr[2][4];                            // A fragments [block of the pair][k-step], B fragments [j][k-step]
     // operand pointers of a K-tile (dual-K switch, tile-blocked weights) are resolved ONCE per loop iteration on the scalar unit and
     // handed to the issue lambdas: computed inside every issue they were ~20 SALU instructions per phase in the DMA-issuing wave
-    auto tileA = [&](int t) -> const bf16* { t = rk(t); return t >= nk1 ? A2 + (t - nk1) * BK : A + t * BK; };
+    auto tileA = [&](int t) -> const bf16* { return t >= nk1 ? A2 + (t - nk1) * BK : A + t * BK; };
     auto tileB = [&](int t) -> const bf16* {
-      t = rk(t);
       const bf16* Bp = B + blkB1; int k0 = t * BK;
       if (t >= nk1) { Bp = B2 + blkB2; k0 = (t - nk1) * BK; }
       return Bp + (p.b_blocked ? (long long)(k0 >> 6) * 16384 : (long long)k0);
@@ -908,15 +900,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   a.dbg = 0;
   a.stagger_ticks = 0;
   a.b_blocked = d->b_blocked;
-  {
-    // K rotation: MART_NT_KROT=0 off; 1 (default): column tiles of a row panel spread evenly over the K-tiles, row panels one K-tile apart
-    static const int krot = getenv("MART_NT_KROT") ? atoi(getenv("MART_NT_KROT")) : 0;
-    const int nk_ = (d->K + d->K2) / 64, tn_ = (d->N + 255) / 256;
-    a.krot_a = krot ? (nk_ / tn_ > 1 ? nk_ / tn_ : 1) : 0;
-    a.krot_b = krot ? 1 : 0;
-  }
 #ifdef MART_EXPERIMENTS
-  if (cfg == 2566) { a.krot_a = a.krot_b = 0; cfg = 256; }                     // harness A/B: the shipped kernel without the K rotation
   if (cfg == 999) { a.dbg = 1; cfg = 256; }
   if (cfg >= 70000 && cfg < 80000) { a.stagger_ticks = cfg - 70000; cfg = 256; }
   if (cfg == 9992 || cfg == 9993) { a.dbg = cfg - 9990; cfg = 256; }           // 9992: no epilogue, 9993: no LDS-DMA and no epilogue
