@@ -54,6 +54,9 @@ static void make_desc(mart_gemm_nt_desc& d, const Case& c, const Bufs& b, int ro
   d.A = b.A[rot % 12]; d.B = b.B; d.lda = c.K > c.K2 ? c.K : c.K2; d.ldb = d.lda; d.M = c.M; d.N = c.N; d.K = c.K; d.K2 = c.K2;
   if (c.K2) { d.A2 = b.A2; d.B2 = b.B2; }
   d.batch = 1; d.alpha = 1.0f; d.C = b.C[which]; d.ldc = c.N; d.tile_cfg = cfg; d.bias = b.bias;
+  static const int hot = getenv("NT_HOT") ? atoi(getenv("NT_HOT")) : 0;    // timing only (wrong numbers): 1: every A row aliases row 0, 2: B too, so the
+  if (hot >= 1) d.lda = 0;                                                   // LDS-DMA stream hits L1 / L2 -- the K loop without memory-side latency
+  if (hot >= 2) d.ldb = 0;
   switch (c.epi) {
     case 0: break;
     case 1: d.c_f32 = 1; d.res_f32 = b.res; break;
