@@ -79,6 +79,13 @@ enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32, F
 // DT: operand / output element type.  0 = bf16 operands, C bf16 | f32 (every product of the vision stream and of the backward pass);
 // 1 = fp16 operands (v_mfma_f32_32x32x16_f16: same rate, 11-bit significands), C bf16 | f32; 2 = fp16 operands AND C in fp16 (the GELU output that
 // is the next product's A operand), with C2 as its bf16 copy for the backward pass.  The 16-bit lanes move through LDS untyped.
+// cache-policy bits of the 8-phase loop's LDS-DMA (gfx940+: 1 = sc0, 2 = nt, 16 = sc1); experiments: -DGLDS_AUX_A=.. -DGLDS_AUX_B=..
+#ifndef GLDS_AUX_A
+#define GLDS_AUX_A 0
+#endif
+#ifndef GLDS_AUX_B
+#define GLDS_AUX_B 0
+#endif
 template <int DT> __device__ __forceinline__ f32x16 mm(bf16x8 a, bf16x8 b, f32x16 c) {
   if constexpr (DT == 0) return mfma32(a, b, c); else return mfma32h(a, b, c);
 }
@@ -306,13 +313,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
       constexpr int hf = decltype(HALF)::value;
       char* sA = smem + (t & 1) * STAGE;
 #pragma unroll
-      for (int r = 2 * hf; r < 2 * hf + 2; ++r) glds16(Ap + offA[r], sA + (r * NT + wave * 64) * 16);
+      for (int r = 2 * hf; r < 2 * hf + 2; ++r) __builtin_amdgcn_global_load_lds(GLB_PTR(Ap + offA[r]), LDS_PTR(sA + (r * NT + wave * 64) * 16), 16, 0, GLDS_AUX_A);
     };
     auto issueB = [&](const bf16* Bp, int t, auto HALF) {
       constexpr int hf = decltype(HALF)::value;
       char* sB = smem + (t & 1) * STAGE + A_BYTES;
 #pragma unroll
-      for (int r = 2 * hf; r < 2 * hf + 2; ++r) glds16(Bp + offB[r], sB + (r * NT + wave * 64) * 16);
+      for (int r = 2 * hf; r < 2 * hf + 2; ++r) __builtin_amdgcn_global_load_lds(GLB_PTR(Bp + offB[r]), LDS_PTR(sB + (r * NT + wave * 64) * 16), 16, 0, GLDS_AUX_B);
     };
     auto readA = [&](const char* sA_, auto IH) {
       constexpr int ih = decltype(IH)::value;
