@@ -5,7 +5,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 TAG=${1:-r04}
 mkdir -p gpurun_out
-timeout 600 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json
 for mode in serial overlap; do
   if [ $mode = serial ]; then export MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0; else export MART_OVERLAP_WGRAD=1 MART_TWO_STREAM=1; fi
   rm -rf gpurun_out/prof_tmp
@@ -22,6 +21,9 @@ bash tools/pmc.sh "gemm_nt_kernel<256" gpurun_out/${TAG}_pmc_gemm_nt.txt -- $CMD
 python tools/pmc_to_json.py gpurun_out/${TAG}_pmc_gemm_nt.txt gpurun_out/${TAG}_pmc_gemm_nt.json "MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0 rocprofv3 --pmc <group> -- $CMD (one pass per counter group: tools/pmc.sh)" | cut -c1-300
 bash tools/pmc.sh "gemm_tn8" gpurun_out/${TAG}_pmc_gemm_tn.txt -- $CMD > /dev/null 2>&1
 unset MART_OVERLAP_WGRAD MART_TWO_STREAM
+# the bench line last of the three, so that its roofline.traffic is THIS run's PMC file (bench.py reads profiles/<TAG>_pmc_gemm_nt.json and checks the source hash)
+cp gpurun_out/${TAG}_pmc_gemm_nt.json profiles/${TAG}_pmc_gemm_nt.json
+timeout 600 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json
 run() { # tag, bench args...
   tag=$1; shift
   timeout 600 python bench.py "$@" --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_$tag.json
