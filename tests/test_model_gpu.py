@@ -470,3 +470,25 @@ def test_fused_fusion_kernels_equal_the_general_path_in_the_model():
     assert float((aw1 - aw0).norm() / aw0.norm()) < 0.15
     assert compared > 400 and worst > 0.0                        # all gradient tensors took part, and the two paths really are different code
     print(f"worst relative gradient difference fused vs general: {worst:.3e} over {compared} tensors")
+
+
+def test_async_step_boundary_equals_in_order():
+    """optim.FusedAdamW.async_step (MART_ASYNC_STEP=1): the gradient zero-fill and the W^T refresh on the optimizer stream, joined by the model's
+    forward / FlatStore.g() / wt().  Three training steps (eval-mode arithmetic: no dropout) end in bit-identical weights, moments and shadows."""
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.trainer import Trainer
+    gb = D.make_batch(8, 64, seed=21, device="cuda")
+    res = []
+    for mode in (False, True):
+        model, lit, cfg, vc = _product(32, seed=5)
+        tr = Trainer(max_epochs=1, max_steps=40)
+        tr._setup(lit, [gb] * 40)
+        tr.optimizer.async_step = mode
+        model.engine.p_hidden = model.engine.p_attn = 0.0          # same arithmetic in both runs
+        for i in range(3):
+            tr.train_step(lit, gb, i)
+        torch.cuda.synchronize()
+        st = model.store
+        res.append((st.master.clone(), st.shadow.clone(), st.shadow_t.clone(), tr.optimizer.m.clone(), tr.optimizer.v.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

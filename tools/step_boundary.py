@@ -7,7 +7,7 @@ that the un-profiled run does not have).
     fwd_k1    after the first forward kernel of the next step (patchify_k)
     fwd_emb   after the vision pre-LayerNorm (patch GEMM, assemble, LN: the first ~0.5 ms of forward work)
 
-usage: python tools/step_boundary.py [steps] ; MART_ASYNC_STEP=0 for the in-order zero-fill / W^T refresh"""
+usage: python tools/step_boundary.py [steps] ; MART_ASYNC_STEP=1 for the off-stream zero-fill / W^T refresh"""
 import os
 import sys
 
@@ -73,7 +73,7 @@ for a, b in zip(marks[:-1], marks[1:]):
                  a["start"].elapsed_time(b["start"])))
 n = len(rows)
 avg = [sum(r[j] for r in rows) / n for j in range(4)]
-print(f"MART_ASYNC_STEP={os.environ.get('MART_ASYNC_STEP', '1')}  {n} step boundaries, ms on the compute stream (mean / max):")
+print(f"MART_ASYNC_STEP={os.environ.get('MART_ASYNC_STEP', '0')}  {n} step boundaries, ms on the compute stream (mean / max):")
 for j, name in enumerate(("bwd_end -> step_end   (exposed AdamW tail + joins; in-order: + W^T refresh)", "step_end -> fwd_k1    (in-order: zero-fill; + patchify_k ~0.12 ms)",
                           "fwd_k1 -> fwd_emb     (patch GEMM, assemble, pre-LN)", "step period")):
     print(f"   {name:78s} {avg[j]:8.3f} / {max(r[j] for r in rows):8.3f}")
