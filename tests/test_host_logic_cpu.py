@@ -296,3 +296,25 @@ def test_seeded_weights_equal_the_golden_generators_recipe(model, cond):
     assert list(got) == list(ref)
     for n in ref:
         assert torch.equal(got[n], ref[n]), n
+
+
+def test_scored_ids_uniqueness_check_is_per_tensor_object_not_per_address():
+    """functional._require_unique (round-3 advisor finding): the cache must never answer for a DIFFERENT id tensor that happens to live at the
+    address of an earlier one (the caching allocator recycles addresses): keyed on the tensor object and its in-place version."""
+    from mkg_analogy_amd import functional as Fn
+    good = torch.tensor([3, 1, 2], dtype=torch.int32)
+    Fn._require_unique(good)
+    Fn._require_unique(good)                                  # cached: same object, same version
+    good[0] = 1                                               # in-place edit bumps _version -> checked again
+    with pytest.raises(ValueError):
+        Fn._require_unique(good)
+    for _ in range(200):                                      # fresh objects (recycled ids / addresses included) are always checked
+        bad = torch.tensor([5, 5, 7], dtype=torch.int32)
+        with pytest.raises(ValueError):
+            Fn._require_unique(bad)
+        ok = torch.tensor([5, 6, 7], dtype=torch.int32)
+        Fn._require_unique(ok)
+    rng = torch.arange(0, 10, dtype=torch.int32)
+    rng._mart_unique = True                                   # LazyRows marks ranges: no check, no device sync
+    Fn._require_unique(rng)
+    assert len(Fn._UNIQUE_OK) <= 66
