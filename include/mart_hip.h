@@ -329,6 +329,8 @@ typedef struct {
   float scale;
   const int64_t* attn_mask; const int64_t* sep; int sep_stride; const float* w0; const float* w1; int rw_skip_row0;
   float* ctx; long long ldctx;
+  int fast;                                                        /* 1 (evaluation passes): unmasked head-dim-64 calls may run on two-term bf16 operand splits
+                                                                      (three products, 2^-16 relative: the arithmetic of the path's GEMMs) instead of exact f32 */
 } mart_attn_f32_desc;
 int mart_attn_fwd_f32(const mart_attn_f32_desc* d, void* stream);
 

@@ -1223,6 +1223,149 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
   }
 }
 
+// =========================================================================== fp32-accurate forward on the bf16 matrix pipe (evaluation path)
+// The multi-head attentions of the fp32-accurate EVALUATION pass (engine_precise, no_grad) without masks / reweighting -- the vision tower incl. its
+// text K / V prefix, 24 % of that pass on the f32 matrix pipe (attn_f32_mfma_k: 2.0 ms per layer at the bench shape, the f32 MFMA runs at 1/16 of the
+// bf16 rate).  Here both contractions run on TWO-TERM bf16 splits of their f32 operands, three products each (hi*hi + hi*lo + lo*hi, f32 accumulate:
+// 2^-16 relative, the same arithmetic as the path's GEMMs, mart_split_bf16x3): S^T = K q^T with K and Q split, O^T = V^T P^T with V and the
+// probabilities split; softmax statistics in f32.  Skeleton of attn_fwd_k<vision>: a wave owns 32 queries (lane = query), K / V stream in 64-key
+// tiles -- f32 rows are fetched into registers one tile ahead, split, and written as four swizzled bf16 images (K hi / lo, V hi / lo: 32 KB per
+// workgroup) that the same fragment readers as the bf16 kernel consume.  48 MFMAs per tile and wave against 16 in the bf16 kernel.
+constexpr int SP_IMG = 64 * 128;                  // one 64 x 64 bf16 image
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (bf16)a[e]; lo[e] = (bf16)(a[e] - (float)hi[e]);
+    hi[4 + e] = (bf16)b[e]; lo[4 + e] = (bf16)(b[e] - (float)hi[4 + e]);
+  }
+}
+__global__ __launch_bounds__(NTH, 2) void attn_split_fwd_k(mart_attn_f32_desc p) {
+  __shared__ __attribute__((aligned(16))) char sm[4 * SP_IMG];
+  char* sKh = sm; char* sKl = sm + SP_IMG; char* sVh = sm + 2 * SP_IMG; char* sVl = sm + 3 * SP_IMG;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y;
+  const long long b = blockIdx.z;
+  const int Stot = p.Lp + p.Sk;
+  const LaneOffs lo = make_offs(lane);
+  const int q0 = blockIdx.x * 128 + wave * 32, qi = q0 + l31;
+  const bool active = q0 < p.Sq;                       // wave-uniform
+  bf16x8 qh[4], ql[4];
+  {
+    const float* qp = p.q + (b * p.Sq + min(qi, p.Sq - 1)) * p.ldq + h * 64 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) split8(*(const f32x4*)(qp + ks * 16), *(const f32x4*)(qp + ks * 16 + 4), qh[ks], ql[ks]);
+  }
+  f32x16 ot[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
+  float m_run = -1.0e30f, l_run = 0.f;
+  const float c2 = p.scale * LOG2E;
+  // staging: thread -> key row tid >> 2, 16 consecutive dims (tid & 3) * 16 of K and of V (four float4 each), kept in registers one tile ahead
+  const int srow = tid >> 2, sc16 = (tid & 3) * 16;
+  f32x4 kp[4], vp[4];
+  auto fetch = [&](int t) {
+    const int j = min(t * 64 + srow, Stot - 1);                       // rows past the last key: clamped copies (masked below)
+    const float* kr = j < p.Lp ? p.pk + (b * p.Lp + j) * p.ldp + h * 64 : p.k + (b * p.Sk + (j - p.Lp)) * p.ldk + h * 64;
+    const float* vr = j < p.Lp ? p.pv + (b * p.Lp + j) * p.ldp + h * 64 : p.v + (b * p.Sk + (j - p.Lp)) * p.ldv + h * 64;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { kp[u] = *(const f32x4*)(kr + sc16 + 4 * u); vp[u] = *(const f32x4*)(vr + sc16 + 4 * u); }
+  };
+  auto stash = [&]() {
+    const int key = swz_key(srow);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                                      // two 16-byte chunks of 8 dims each
+      const int off = srow * 128 + ((((sc16 >> 3) + u) ^ key) << 4);
+      bf16x8 a, c;
+      split8(kp[2 * u], kp[2 * u + 1], a, c);
+      *(bf16x8*)(sKh + off) = a; *(bf16x8*)(sKl + off) = c;
+      split8(vp[2 * u], vp[2 * u + 1], a, c);
+      *(bf16x8*)(sVh + off) = a; *(bf16x8*)(sVl + off) = c;
+    }
+  };
+  const int ntiles = (Stot + 63) / 64;
+  fetch(0);
+  stash();
+  __syncthreads();
+  for (int kt = 0; kt < ntiles; ++kt) {
+    if (kt + 1 < ntiles) fetch(kt + 1);
+    if (active) {
+      f32x16 st[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kh = tile_frag(sKh, t, ks, lo), kl = tile_frag(sKl, t, ks, lo);
+          st[t] = mfma32(kl, qh[ks], st[t]);                           // small terms first
+          st[t] = mfma32(kh, ql[ks], st[t]);
+          st[t] = mfma32(kh, qh[ks], st[t]);
+        }
+      }
+      if (kt * 64 + 64 > Stot) {
+        const int lim = Stot - kt * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (t * 32 + mfma_row(r, hh) >= lim) st[t][r] = -1.0e30f;
+      }
+      float mx = st[0][0];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float rs = 0.f;
+      float pv[2][16];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], c2, -m_new));
+          rs += e;
+          pv[t][r] = e;
+        }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+      if (!__all(alpha == 1.f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          bf16x8 ph, pl;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float x = pv[t][8 * a + e]; ph[e] = (bf16)x; pl[e] = (bf16)(x - (float)ph[e]); }
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vh = tile_frag_tr(sVh, t * 32 + 16 * a, dt, lo), vl = tile_frag_tr(sVl, t * 32 + 16 * a, dt, lo);
+            ot[dt] = mfma32(vl, ph, ot[dt]);
+            ot[dt] = mfma32(vh, pl, ot[dt]);
+            ot[dt] = mfma32(vh, ph, ot[dt]);
+          }
+        }
+    }
+    __syncthreads();                                                   // every wave is through tile kt
+    if (kt + 1 < ntiles) { stash(); __syncthreads(); }
+  }
+  if (qi < p.Sq) {
+    const float inv = 1.f / l_run;
+    float* op = p.ctx + (b * p.Sq + qi) * p.ldctx + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(f32x4*)(op + dt * 32 + 8 * g + 4 * hh) = f32x4{ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv, ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv};
+  }
+}
+
 int check_fwd(const mart_attn_fwd_desc* d) {
   MART_CHECK(d && d->q && d->k && d->v && d->ctx, "attn: null pointer");
   MART_CHECK(d->B > 0 && d->nh > 0 && d->Sq > 0 && d->Sk > 0 && d->Lp >= 0, "attn: bad shape");
@@ -1554,6 +1697,13 @@ int set_attrs() {
   return 0;
 }
 }  // namespace
+
+// internal launcher for csrc/precise.hip (mart_attn_fwd_f32 routes its unmasked head-dim-64 calls of evaluation passes here)
+int mart_attn_split_launch(const mart_attn_f32_desc* d, void* stream) {
+  hipLaunchKernelGGL(attn_split_fwd_k, dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), 0, (hipStream_t)stream, *d);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream) {
   if (int rc = check_fwd(d)) return rc;

@@ -121,7 +121,7 @@ class PreciseUnimoForward(_PreciseBase):
             pre = t_qkv_prev if l >= self.fuse_from else None
             ops.attn_fwd_f32(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, B=B, nh=nh, D=64, Sq=Nv, Sk=Nv, scale=0.125,
                              pk=pre[:, H:2 * H] if pre is not None else None, pv=pre[:, 2 * H:] if pre is not None else None,
-                             Lp=Lq if pre is not None else 0)
+                             Lp=Lq if pre is not None else 0, fast=True)          # evaluation pass: two-term splits on the bf16 matrix pipe
             ctx = self._rb(ctx, "vis_attn")
             x1 = self.lin(ctx, [v + "self_attn.out_proj.weight"], [v + "self_attn.out_proj.bias"], H, tag="vis_lin", res_f32=xv)
             h2 = self._ln(x1, v + "layer_norm2.weight", v + "layer_norm2.bias", self.eps_v)
@@ -467,7 +467,7 @@ class PreciseFlavaForward(_PreciseBase):
         h1 = self._ln(x, p + "layernorm_before.weight", p + "layernorm_before.bias", self.eps)
         qkv = self.lin(h1, [a + f"{n}.weight" for n in ("query", "key", "value")], [a + f"{n}.bias" for n in ("query", "key", "value")], 3 * H)
         ctx = _e((x.shape[0], H), F32, x.device)
-        ops.attn_fwd_f32(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, B=B, nh=self.nh, D=64, Sq=S, Sk=S, scale=0.125, **attn)
+        ops.attn_fwd_f32(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, B=B, nh=self.nh, D=64, Sq=S, Sk=S, scale=0.125, fast=True, **attn)
         x1 = self.lin(ctx, [p + "attention.output.dense.weight"], [p + "attention.output.dense.bias"], H, res_f32=x)
         h2 = self._ln(x1, p + "layernorm_after.weight", p + "layernorm_after.bias", self.eps)
         f = self.lin(h2, [p + "intermediate.dense.weight"], [p + "intermediate.dense.bias"], I, act=ops.ACT_GELU)

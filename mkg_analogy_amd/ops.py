@@ -255,8 +255,10 @@ def vision_assemble_f32(patch, cls, pos, s, B, P, H, tail_shift=0):
 
 
 def attn_fwd_f32(*, q, k, v, ctx, B, nh, D, Sq, Sk, scale, pk=None, pv=None, Lp=0, attn_mask=None, sep=None, sep_stride=0,
-                 w0=None, w1=None, rw_skip_row0=False):
+                 w0=None, w1=None, rw_skip_row0=False, fast=False):
+    """``fast`` (evaluation passes): unmasked head-dim-64 calls may run on two-term bf16 operand splits (csrc/attention.hip attn_split_fwd_k)."""
     d = L.AttnF32()
+    d.fast = int(bool(fast))
     d.q, d.k, d.v, d.ldq, d.ldk, d.ldv = _p(q), _p(k), _p(v), _rows2d(q), _rows2d(k), _rows2d(v)
     d.pk, d.pv, d.ldp, d.Lp = _p(pk), _p(pv), (_rows2d(pk) if pk is not None else 0), Lp
     d.B, d.nh, d.D, d.Sq, d.Sk, d.scale = B, nh, D, Sq, Sk, scale

@@ -120,6 +120,28 @@ def test_attn_f32_mfma_kernels_at_real_shapes():
     assert e1 < 2e-5 and e3 < 2e-4
 
 
+@pytest.mark.parametrize("Lp", [0, 64])
+def test_attn_split_kernel_vs_f64_and_exact_f32(Lp):
+    """mart_attn_fwd_f32 with ``fast`` (evaluation passes): the unmasked head-dim-64 attention on two-term bf16 operand splits (attn_split_fwd_k) at the
+    bench shape (393 queries, 393 / 64 + 393 keys, ragged last tile), against float64 and against the exact f32 matrix-pipe kernel."""
+    from mkg_analogy_amd import ops
+    g = torch.Generator().manual_seed(7 + Lp)
+    B, nh, H, Nv, L = 3, 12, 768, 393, 64
+    qkv, pre = 1.5 * torch.randn(B * Nv, 3 * H, generator=g), 1.5 * torch.randn(B * L, 3 * H, generator=g)
+    dq, dp = qkv.to(DEV), pre.to(DEV)
+    kw = dict(q=dq[:, :H], k=dq[:, H:2 * H], v=dq[:, 2 * H:], B=B, nh=nh, D=64, Sq=Nv, Sk=Nv, scale=0.125,
+              pk=dp[:, H:2 * H] if Lp else None, pv=dp[:, 2 * H:] if Lp else None, Lp=Lp)
+    fast, exact = torch.full((B * Nv, H), float("nan"), device=DEV), torch.empty(B * Nv, H, device=DEV)
+    ops.attn_fwd_f32(ctx=fast, fast=True, **kw)
+    ops.attn_fwd_f32(ctx=exact, **kw)
+    ref = _ref_attn(qkv[:, :H].reshape(B, Nv, H), qkv[:, H:2 * H].reshape(B, Nv, H), qkv[:, 2 * H:].reshape(B, Nv, H), nh, 0.125,
+                    pre[:, H:2 * H].reshape(B, L, H) if Lp else None, pre[:, 2 * H:].reshape(B, L, H) if Lp else None)
+    ef = (fast.cpu().double().view(B, Nv, H) - ref).abs().max().item()
+    ee = (exact.cpu().double().view(B, Nv, H) - ref).abs().max().item()
+    print(f"\nattention 393 x {Lp + Nv} keys, |out| max {ref.abs().max():.2f}: two-term splits max|err| {ef:.2e}, exact f32 kernel {ee:.2e}")
+    assert bool(torch.isfinite(fast).all()) and ef < 2.5e-5 * float(ref.abs().max()) and ee < 2e-5      # 2^-16 relative for the two-term splits
+
+
 def _setup(patch, seed, conditioned):
     from tests.test_model_gpu import _product, _oracle_sd
     model, lit, cfg, vc = _product(patch, seed=seed, conditioned=conditioned)
