@@ -107,6 +107,8 @@ typedef struct {
   void* out_f16;                                                  /* optional: the normalised output as IEEE fp16 (A operand of the text stream's fp16 forward products) */
   const int32_t* x_rows;                                          /* optional row gather of the residual input: row m reads x_f32[x_rows[m]] (last text layer, computed
                                                                      only on the rows the loss reads); y_*, s_out, outputs, mean / rstd and the dropout index stay compact */
+  void* out_split3;                                               /* optional bf16 [M, 3H]: the output as the two-term split [hi | lo | hi] (mart_split_bf16x3 role 0),
+                                                                     the A operand of the fp32-accurate path's GEMMs -- written here instead of by a separate pass */
 } mart_ln_fwd_desc;
 int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream);
 
@@ -331,6 +333,8 @@ typedef struct {
   float* ctx; long long ldctx;
   int fast;                                                        /* 1 (evaluation passes): unmasked head-dim-64 calls may run on two-term bf16 operand splits
                                                                       (three products, 2^-16 relative: the arithmetic of the path's GEMMs) instead of exact f32 */
+  void* ctx_split3; long long ldctx3;                              /* optional, fast path only: the context ALSO as [hi | lo | hi] bf16 rows of 3 * nh * D columns
+                                                                      (row stride ldctx3 elements): the A operand of the output projection, no separate split pass */
 } mart_attn_f32_desc;
 int mart_attn_fwd_f32(const mart_attn_f32_desc* d, void* stream);
 

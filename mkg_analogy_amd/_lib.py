@@ -38,7 +38,7 @@ class GemmTN(C.Structure):
 class LnFwd(C.Structure):
     _fields_ = [("x_f32", vp), ("y_bf16", vp), ("p_drop", f32), ("seed", u64), ("gamma", vp), ("beta", vp), ("eps", f32),
                 ("M", i32), ("H", i32), ("s_out", vp), ("out_f32", vp), ("out_bf16", vp), ("mean", vp), ("rstd", vp), ("y_f32", vp),
-                ("out_f16", vp), ("x_rows", vp)]
+                ("out_f16", vp), ("x_rows", vp), ("out_split3", vp)]
 
 
 class LnBwd(C.Structure):
@@ -66,7 +66,7 @@ class AttnF32(C.Structure):
                 ("pk", vp), ("pv", vp), ("ldp", i64), ("Lp", i32),
                 ("B", i32), ("nh", i32), ("D", i32), ("Sq", i32), ("Sk", i32), ("scale", f32),
                 ("attn_mask", vp), ("sep", vp), ("sep_stride", i32), ("w0", vp), ("w1", vp), ("rw_skip_row0", i32),
-                ("ctx", vp), ("ldctx", i64), ("fast", i32)]
+                ("ctx", vp), ("ldctx", i64), ("fast", i32), ("ctx_split3", vp), ("ldctx3", i64)]
 
 
 class AttnBwdF32(C.Structure):
@@ -161,7 +161,7 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
-EXPECTED_ABI = 6            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
+EXPECTED_ABI = 7            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
 _lib = None
 
 

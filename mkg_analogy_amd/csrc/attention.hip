@@ -1362,7 +1362,17 @@ __global__ __launch_bounds__(NTH, 2) void attn_split_fwd_k(mart_attn_f32_desc p)
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *(f32x4*)(op + dt * 32 + 8 * g + 4 * hh) = f32x4{ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv, ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv};
+      {
+        const f32x4 y = {ot[dt][4 * g] * inv, ot[dt][4 * g + 1] * inv, ot[dt][4 * g + 2] * inv, ot[dt][4 * g + 3] * inv};
+        const int col = h * 64 + dt * 32 + 8 * g + 4 * hh;
+        if (p.ctx) *(f32x4*)(op + dt * 32 + 8 * g + 4 * hh) = y;
+        if (p.ctx_split3) {                                            // [hi | lo | hi] operand rows for the output projection
+          const int HD = p.nh * 64;
+          const bf16x4 hi = f4_to_bf4(y), lw = f4_to_bf4(y - bf4_to_f4(hi));
+          bf16* d3 = (bf16*)p.ctx_split3 + (b * p.Sq + qi) * p.ldctx3 + col;
+          *(bf16x4*)d3 = hi; *(bf16x4*)(d3 + HD) = lw; *(bf16x4*)(d3 + 2 * HD) = hi;
+        }
+      }
   }
 }
 

@@ -94,6 +94,12 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
         if (p.out_f32) stx((f32x4*)(p.out_f32 + o), y, (LN_NT & 2) != 0);
         if (p.out_bf16) stx((bf16x4*)((bf16*)p.out_bf16 + o), f4_to_bf4(y), (LN_NT & 4) != 0);
         if (p.out_f16) stx((bf16x4*)((bf16*)p.out_f16 + o), f4_to_h4raw(y), (LN_NT & 4) != 0);
+        if (p.out_split3) {                                   // [hi | lo | hi]: the A operand of the fp32-accurate path's split GEMMs (mart_split_bf16x3, role 0)
+          const bf16x4 hi = f4_to_bf4(y);
+          const bf16x4 lo = f4_to_bf4(y - bf4_to_f4(hi));
+          bf16* d3 = (bf16*)p.out_split3 + (long long)m * 3 * p.H + c;
+          *(bf16x4*)d3 = hi; *(bf16x4*)(d3 + p.H) = lo; *(bf16x4*)(d3 + 2 * p.H) = hi;
+        }
       }
   }
 }
@@ -775,12 +781,12 @@ extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
   MART_CHECK(d && (d->x_f32 || d->y_bf16 || d->y_f32), "ln_fwd: need x_f32, y_bf16 or y_f32");
   MART_CHECK(!(d->y_bf16 && d->y_f32), "ln_fwd: y_bf16 and y_f32 are alternatives");
   MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_fwd: H must be a multiple of 256 and <= 1024");
-  MART_CHECK(d->gamma && d->beta && d->mean && d->rstd && (d->out_f32 || d->out_bf16 || d->out_f16), "ln_fwd: null pointer");
+  MART_CHECK(d->gamma && d->beta && d->mean && d->rstd && (d->out_f32 || d->out_bf16 || d->out_f16 || d->out_split3), "ln_fwd: null pointer");
   MART_CHECK(!d->x_rows || d->x_f32, "ln_fwd: x_rows gathers x_f32");
   MART_CHECK(d->p_drop >= 0.f && d->p_drop < 1.f, "ln_fwd: bad dropout p");
   static const int fast = getenv("MART_LN_FAST") ? atoi(getenv("MART_LN_FAST")) : 1;
   static const int fcap = getenv("MART_LN_FWD_GRID") ? atoi(getenv("MART_LN_FWD_GRID")) : 512;   // 6.15 TB/s (768 / 1024 / 2048: 5.8-5.95)
-  if (fast && d->x_f32 && !d->x_rows && !d->y_bf16 && !d->y_f32 && !d->s_out && !d->out_f32 && (d->out_bf16 || d->out_f16) && d->p_drop == 0.f && (d->H == 768 || d->H == 1024) && d->M >= 4096) {
+  if (fast && d->x_f32 && !d->x_rows && !d->y_bf16 && !d->y_f32 && !d->s_out && !d->out_f32 && !d->out_split3 && (d->out_bf16 || d->out_f16) && d->p_drop == 0.f && (d->H == 768 || d->H == 1024) && d->M >= 4096) {
     int g = (d->M + WPB - 1) / WPB;
     if (g > fcap) g = fcap;
     const int gmin = (d->M + WPB * 64 - 1) / (WPB * 64);          // at most 64 rows per wave (their statistics live in one register across the lanes)

@@ -37,6 +37,12 @@ class _PreciseBase:
         # fusion, head_t, head_s.  Empty in normal use.
         self.degrade: set = set()
         self.terms = 2                                   # bf16 terms per operand split: 2 (three products) everywhere but the verification-mode training step
+        # evaluation passes: LayerNorm and the unmasked attention write the [hi | lo | hi] A operand of the GEMM that follows them directly (no
+        # separate split pass over an f32 copy), and that attention runs on two-term splits itself (csrc/attention.hip attn_split_fwd_k)
+        self.fused_split = os.environ.get("MART_PRECISE_FUSED_SPLIT", "1") == "1" and os.environ.get("MART_ATTN_F32_SPLIT", "1") == "1"
+
+    def _pre(self) -> bool:
+        return self.fused_split and self.terms == 2 and not self.degrade
 
     def _rb(self, x: torch.Tensor, tag: Optional[str]) -> torch.Tensor:
         return x.to(BF).to(F32) if tag is not None and tag in self.degrade else x
@@ -73,13 +79,17 @@ class PreciseUnimoForward(_PreciseBase):
         out = _e((x.shape[0], N), F32, x.device)
         bias = self.st.fused(list(bnames), self.st.master) if bnames else None
         deg = tag is not None and tag in self.degrade
-        ops.gemm_nt(ops.split_bf16x3(self._rb(x, tag), 0, terms=self.terms), self.w3(wnames, rounded=deg), out, bias=bias, **epi)
+        a3 = x if x.dtype == BF else ops.split_bf16x3(self._rb(x, tag), 0, terms=self.terms)      # bf16 input: already the [hi | lo | hi] operand
+        ops.gemm_nt(a3, self.w3(wnames, rounded=deg), out, bias=bias, **epi)
         return out
 
-    def _ln(self, x, wname, bname, eps):
+    def _ln(self, x, wname, bname, eps, split3: bool = False):
+        """fp32 LayerNorm; ``split3``: return the bf16 [M, 3H] A operand of the GEMM that consumes it instead of the f32 tensor."""
         M, H = x.shape
-        y, mean, rstd = _e((M, H), F32, x.device), _e((M,), F32, x.device), _e((M,), F32, x.device)
-        ops.ln_fwd(x_f32=x, gamma=self.st.m(wname), beta=self.st.m(bname), eps=eps, M=M, H=H, mean=mean, rstd=rstd, out_f32=y)
+        mean, rstd = _e((M,), F32, x.device), _e((M,), F32, x.device)
+        y = _e((M, 3 * H), BF, x.device) if split3 else _e((M, H), F32, x.device)
+        ops.ln_fwd(x_f32=x, gamma=self.st.m(wname), beta=self.st.m(bname), eps=eps, M=M, H=H, mean=mean, rstd=rstd,
+                   out_f32=None if split3 else y, out_split3=y if split3 else None)
         return y
 
     # ------------------------------------------------------------------ forward
@@ -114,17 +124,19 @@ class PreciseUnimoForward(_PreciseBase):
         for l in range(self.n_layers):
             # ---- vision layer l (CLIPEncoderLayer.forward :490-527)
             v = f"unimo.encoder.vision_layers.{l}."
-            h1 = self._ln(xv, v + "layer_norm1.weight", v + "layer_norm1.bias", self.eps_v)
+            pre3 = self._pre()
+            h1 = self._ln(xv, v + "layer_norm1.weight", v + "layer_norm1.bias", self.eps_v, split3=pre3)
             names = [v + f"self_attn.{n}" for n in ("q_proj", "k_proj", "v_proj")]
             qkv = self._rb(self.lin(h1, [n + ".weight" for n in names], [n + ".bias" for n in names], 3 * H, tag="vis_lin"), "vis_attn")
-            ctx = _e((Mv, H), F32, dev)
+            ctx = _e((Mv, 3 * H), BF, dev) if pre3 else _e((Mv, H), F32, dev)
             pre = t_qkv_prev if l >= self.fuse_from else None
-            ops.attn_fwd_f32(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, B=B, nh=nh, D=64, Sq=Nv, Sk=Nv, scale=0.125,
+            ops.attn_fwd_f32(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=None if pre3 else ctx, ctx_split3=ctx if pre3 else None,
+                             B=B, nh=nh, D=64, Sq=Nv, Sk=Nv, scale=0.125,
                              pk=pre[:, H:2 * H] if pre is not None else None, pv=pre[:, 2 * H:] if pre is not None else None,
                              Lp=Lq if pre is not None else 0, fast=True)          # evaluation pass: two-term splits on the bf16 matrix pipe
             ctx = self._rb(ctx, "vis_attn")
             x1 = self.lin(ctx, [v + "self_attn.out_proj.weight"], [v + "self_attn.out_proj.bias"], H, tag="vis_lin", res_f32=xv)
-            h2 = self._ln(x1, v + "layer_norm2.weight", v + "layer_norm2.bias", self.eps_v)
+            h2 = self._ln(x1, v + "layer_norm2.weight", v + "layer_norm2.bias", self.eps_v, split3=pre3)
             f = self.lin(h2, [v + "mlp.fc1.weight"], [v + "mlp.fc1.bias"], I, tag="vis_lin", act=ops.ACT_QGELU)
             xv = self.lin(f, [v + "mlp.fc2.weight"], [v + "mlp.fc2.bias"], H, tag="vis_lin", res_f32=x1)
             # ---- text layer l (BertLayer.forward :540-577)
@@ -464,12 +476,15 @@ class PreciseFlavaForward(_PreciseBase):
         """FlavaLayer.forward (:635-665): x + Attn(LN x); x + MLP(LN x)."""
         H, I = self.H, self.I
         a = p + "attention.attention."
-        h1 = self._ln(x, p + "layernorm_before.weight", p + "layernorm_before.bias", self.eps)
+        pre3 = self._pre()
+        c3 = pre3 and not attn                          # unmasked stack (image): the attention writes the output projection's operand itself
+        h1 = self._ln(x, p + "layernorm_before.weight", p + "layernorm_before.bias", self.eps, split3=pre3)
         qkv = self.lin(h1, [a + f"{n}.weight" for n in ("query", "key", "value")], [a + f"{n}.bias" for n in ("query", "key", "value")], 3 * H)
-        ctx = _e((x.shape[0], H), F32, x.device)
-        ops.attn_fwd_f32(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=ctx, B=B, nh=self.nh, D=64, Sq=S, Sk=S, scale=0.125, fast=True, **attn)
+        ctx = _e((x.shape[0], 3 * H), BF, x.device) if c3 else _e((x.shape[0], H), F32, x.device)
+        ops.attn_fwd_f32(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], ctx=None if c3 else ctx, ctx_split3=ctx if c3 else None,
+                         B=B, nh=self.nh, D=64, Sq=S, Sk=S, scale=0.125, fast=True, **attn)
         x1 = self.lin(ctx, [p + "attention.output.dense.weight"], [p + "attention.output.dense.bias"], H, res_f32=x)
-        h2 = self._ln(x1, p + "layernorm_after.weight", p + "layernorm_after.bias", self.eps)
+        h2 = self._ln(x1, p + "layernorm_after.weight", p + "layernorm_after.bias", self.eps, split3=pre3)
         f = self.lin(h2, [p + "intermediate.dense.weight"], [p + "intermediate.dense.bias"], I, act=ops.ACT_GELU)
         return self.lin(f, [p + "output.dense.weight"], [p + "output.dense.bias"], H, res_f32=x1)
 

@@ -103,9 +103,9 @@ def gemm_tn(X, Y, out, *, M=None, NX=None, NY=None, out_rows=None, colsum=None, 
 
 
 def ln_fwd(*, x_f32=None, y_bf16=None, y_f32=None, gamma, beta, eps, M, H, mean, rstd, s_out=None, out_f32=None, out_bf16=None,
-           p_drop=0.0, seed=0, out_f16=None, x_rows=None):
+           p_drop=0.0, seed=0, out_f16=None, x_rows=None, out_split3=None):
     d = L.LnFwd()
-    d.out_f16, d.x_rows = _p(out_f16), _p(x_rows)
+    d.out_f16, d.x_rows, d.out_split3 = _p(out_f16), _p(x_rows), _p(out_split3)
     d.x_f32, d.y_bf16, d.p_drop, d.seed = _p(x_f32), _p(y_bf16), p_drop, seed
     d.y_f32 = _p(y_f32)
     d.gamma, d.beta, d.eps, d.M, d.H = _p(gamma), _p(beta), eps, M, H
@@ -255,15 +255,17 @@ def vision_assemble_f32(patch, cls, pos, s, B, P, H, tail_shift=0):
 
 
 def attn_fwd_f32(*, q, k, v, ctx, B, nh, D, Sq, Sk, scale, pk=None, pv=None, Lp=0, attn_mask=None, sep=None, sep_stride=0,
-                 w0=None, w1=None, rw_skip_row0=False, fast=False):
-    """``fast`` (evaluation passes): unmasked head-dim-64 calls may run on two-term bf16 operand splits (csrc/attention.hip attn_split_fwd_k)."""
+                 w0=None, w1=None, rw_skip_row0=False, fast=False, ctx_split3=None):
+    """``fast`` (evaluation passes): unmasked head-dim-64 calls may run on two-term bf16 operand splits (csrc/attention.hip attn_split_fwd_k);
+    ``ctx_split3`` (fast path only, bf16 [rows, 3 * nh * D]): the context as the [hi | lo | hi] operand of the output projection (``ctx`` may be None)."""
     d = L.AttnF32()
     d.fast = int(bool(fast))
+    d.ctx_split3, d.ldctx3 = _p(ctx_split3), (_rows2d(ctx_split3) if ctx_split3 is not None else 0)
     d.q, d.k, d.v, d.ldq, d.ldk, d.ldv = _p(q), _p(k), _p(v), _rows2d(q), _rows2d(k), _rows2d(v)
     d.pk, d.pv, d.ldp, d.Lp = _p(pk), _p(pv), (_rows2d(pk) if pk is not None else 0), Lp
     d.B, d.nh, d.D, d.Sq, d.Sk, d.scale = B, nh, D, Sq, Sk, scale
     d.attn_mask, d.sep, d.sep_stride, d.w0, d.w1, d.rw_skip_row0 = _p(attn_mask), _p(sep), sep_stride, _p(w0), _p(w1), int(rw_skip_row0)
-    d.ctx, d.ldctx = _p(ctx), _rows2d(ctx)
+    d.ctx, d.ldctx = _p(ctx), (_rows2d(ctx) if ctx is not None else 0)
     L.check(L.lib().mart_attn_fwd_f32(C.byref(d), _stream()), "mart_attn_fwd_f32")
 
 

@@ -205,3 +205,27 @@ def test_fp32_path_with_image_table():
     _, t2 = model(pixel_values=pix, **kw)
     assert torch.equal(t1, t2)
     model.set_precision("bf16")
+
+
+def test_fused_split_outputs_equal_the_split_pass():
+    """mart_ln_fwd.out_split3 and mart_attn_fwd_f32.ctx_split3 (evaluation passes): the [hi | lo | hi] A operand written by the producer is
+    bit-identical to mart_split_bf16x3 of the producer's f32 output."""
+    from mkg_analogy_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, H = 1000, 768
+    x = (2.0 * torch.randn(M, H, generator=g)).to(DEV)
+    gam, bet = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV), (0.1 * torch.randn(H, generator=g)).to(DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    y, y3 = torch.empty(M, H, device=DEV), torch.empty(M, 3 * H, device=DEV, dtype=torch.bfloat16)
+    ops.ln_fwd(x_f32=x, gamma=gam, beta=bet, eps=1e-5, M=M, H=H, mean=mean, rstd=rstd, out_f32=y)
+    ops.ln_fwd(x_f32=x, gamma=gam, beta=bet, eps=1e-5, M=M, H=H, mean=mean, rstd=rstd, out_split3=y3)
+    assert torch.equal(y3, ops.split_bf16x3(y, 0, terms=2))
+    B, nh, Nv = 2, 12, 393
+    qkv = torch.randn(B * Nv, 3 * H, generator=g).to(DEV)
+    kw = dict(q=qkv[:, :H], k=qkv[:, H:2 * H], v=qkv[:, 2 * H:], B=B, nh=nh, D=64, Sq=Nv, Sk=Nv, scale=0.125, fast=True)
+    c, c3 = torch.empty(B * Nv, H, device=DEV), torch.empty(B * Nv, 3 * H, device=DEV, dtype=torch.bfloat16)
+    ops.attn_fwd_f32(ctx=c, **kw)
+    ops.attn_fwd_f32(ctx=None, ctx_split3=c3, **kw)
+    assert torch.equal(c3, ops.split_bf16x3(c, 0, terms=2))
+    with pytest.raises(Exception):                       # the exact kernels do not write the operand form
+        ops.attn_fwd_f32(ctx=None, ctx_split3=c3, **{**kw, "fast": False})
