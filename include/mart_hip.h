@@ -67,6 +67,9 @@ typedef struct {
   int in_f16, c_f16;                                              /* in_f16: A, B (A2, B2) hold IEEE fp16 instead of bf16 (v_mfma_f32_32x32x16_f16, same rate, 11-bit
                                                                      significands): the forward linear layers of the text stream.  c_f16 (needs in_f16, 16-bit C): C is
                                                                      written as fp16 and C2, when given, is its bf16 copy (what the backward pass reads).  preact stays bf16. */
+  int c_split3;                                                   /* C is bf16 [M, >= 3N]: the f32 result (after bias / activation) as the two-term split [hi | lo | hi]
+                                                                     (mart_split_bf16x3 role 0) -- the A operand of the next GEMM of the fp32-accurate path, written by
+                                                                     the epilogue instead of an f32 C plus a split pass.  256 x 256 tiles, N % 256 == 0, no other outputs */
 } mart_gemm_nt_desc;
 int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream);
 

@@ -25,7 +25,7 @@ class GemmNT(C.Structure):
                 ("bias", vp), ("bias2", vp), ("bias_by_brow", i32), ("act", i32), ("preact", vp),
                 ("mulz", vp), ("mul_act", i32), ("res_f32", vp), ("res_bf16", vp), ("ldres", i32),
                 ("alpha", f32), ("C", vp), ("ldc", i32), ("c_f32", i32), ("C2", vp), ("ldc2", i32), ("tile_cfg", i32), ("preact_grad", i32), ("b_blocked", i32), ("a_src_rows", i32), ("b_src_rows", i32),
-                ("in_f16", i32), ("c_f16", i32)]
+                ("in_f16", i32), ("c_f16", i32), ("c_split3", i32)]
 
 
 class GemmTN(C.Structure):
@@ -161,7 +161,7 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
-EXPECTED_ABI = 7            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
+EXPECTED_ABI = 8            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
 _lib = None
 
 

@@ -72,7 +72,8 @@ struct Args {
 // Epilogue feature mask of the specialised ("fast") instantiations.  EPI < 0 = the general epilogue (tails, gathers,
 // bf16 residual, unaligned rows).  Every large product of the step maps to one of the fast masks; their epilogues are a few
 // hundred bytes of straight-line vector code (the general one made the kernel 200 KB and instruction-fetch bound).
-enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32, F_PGRAD = 64 };   // F_PGRAD: preact holds act'(z)
+enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32, F_PGRAD = 64, F_SPLIT3 = 128 };   // F_PGRAD: preact holds act'(z)
+// F_SPLIT3 (with F_PREACT | F_C2, bf16): the three 16-bit outputs are the two-term split [hi | lo | hi] of the f32 result (mart_gemm_nt_desc.c_split3)
 
 // PERSIST: one workgroup per CU slot walks over its tiles; the first K-tile of the NEXT tile is put in flight before the
 // epilogue of the current one, so the ~2-3 us of launch + first-DMA latency per tile hide behind the epilogue.
@@ -96,7 +97,7 @@ template <int DT> __device__ __forceinline__ bf16x4 cvt_c2(f32x2 lo, f32x2 hi) {
   if constexpr (DT == 2) return f2x2_to_h4raw(lo, hi); else return f2x2_to_bf4(lo, hi);
 }
 constexpr bool epi_packed(int EPI, int DT) {     // 16-bit outputs only, no streamed operands: staged through LDS as packed 16-bit rows
-  return EPI >= 0 && (EPI & (1 | 2 | 16)) == 0 && (DT == 2 || (EPI & 32) == 0);
+  return EPI >= 0 && (EPI & (1 | 2 | 16)) == 0 && (DT == 2 || (EPI & 32) == 0 || (EPI & 128) != 0);
 }
 constexpr int epi_outputs(int EPI) { return 1 + ((EPI & 4) != 0 ? 1 : 0) + ((EPI & 32) != 0 ? 1 : 0); }
 
@@ -527,7 +528,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
 
   static_assert(EPI < 0 || (EPI & F_PGRAD) == 0 || (EPI & (F_PREACT | F_ACT | F_RES | F_MULZ | F_CF32)) == (F_PREACT | F_ACT),
                 "act'(z) output is a fast-lane option of the 16-bit pre-activation + activation epilogue only");
-  static_assert(EPI < 0 || (EPI & F_C2) == 0 || DT == 2 || (EPI & F_CF32) != 0, "C2 is the bf16 copy of an f32 C, or of an fp16 C (DT 2)");
+  static_assert(EPI < 0 || (EPI & F_C2) == 0 || DT == 2 || (EPI & F_CF32) != 0 || (EPI & F_SPLIT3) != 0, "C2 is the bf16 copy of an f32 C, or of an fp16 C (DT 2)");
+  static_assert(EPI < 0 || (EPI & F_SPLIT3) == 0 || ((EPI & (F_PREACT | F_C2 | F_PGRAD | F_RES | F_MULZ | F_CF32)) == (F_PREACT | F_C2) && DT == 0),
+                "the split output is the three-output 16-bit epilogue on bf16 operands");
   if constexpr (epi_packed(EPI, DT)) {
     // ---- bf16-only outputs without streamed operands (plain / bias, and fc1's pre-activation + activation): bias and
     // activation are applied in MFMA layout, the results go through LDS as packed bf16 (half the staging traffic of the
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
             if constexpr ((EPI & F_C2) != 0) *(bf16x4*)(dst + S2 * 32 * RS) = f2x2_to_bf4(a0, a1);
             continue;
           } else {
-            if constexpr ((EPI & F_PREACT) != 0) *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(v);
+            if constexpr ((EPI & F_PREACT) != 0 && (EPI & F_SPLIT3) == 0) *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(v);
             if constexpr ((EPI & F_ACT) != 0) {
               // bf16 outputs: the same packed fast forms as the act + act' epilogue (bit-identical activations whether or
               // not the derivative is kept); the f32-output lanes keep the accurate erff / division forms
@@ -590,6 +593,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
               act_fwd_grad2(f32x2{v[2], v[3]}, ACTK, a1, g1);
               v = f32x4{a0[0], a0[1], a1[0], a1[1]};
             }
+          }
+          if constexpr ((EPI & F_SPLIT3) != 0) {                  // [hi | lo | hi] of the f32 result: the A operand of the next split GEMM
+            const bf16x4 hi = f4_to_bf4(v);
+            *(bf16x4*)(dst + 32 * RS) = f4_to_bf4(v - bf4_to_f4(hi));
+            *(bf16x4*)dst = hi;
+            *(bf16x4*)(dst + S2 * 32 * RS) = hi;
+            continue;
           }
           *(bf16x4*)dst = cvt_c<DT>(v);
           if constexpr ((EPI & F_C2) != 0) *(bf16x4*)(dst + S2 * 32 * RS) = f4_to_bf4(v);
@@ -951,6 +961,16 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
                        ((uintptr_t)d->bias2 % 16 == 0) && (d->stride_c % 4 == 0) && (d->stride_aux % 4 == 0);
   const int dt = d->in_f16 ? (d->c_f16 ? 2 : 1) : 0;
   const bool two_acts = d->mulz && d->act != ACT_NONE;               // not a fast combination
+  if (d->c_split3) {
+    // C is bf16 [M, 3N]: hi at column n, lo at N + n, hi again at 2N + n -- the three 16-bit outputs of the packed epilogue
+    MART_CHECK(!d->c_f32 && !d->preact && !d->C2 && !d->res_f32 && !d->res_bf16 && !d->mulz && !d->in_f16 && batch == 1 && aligned && cfg == 256 && d->ldc >= 3 * d->N && d->N % 8 == 0,
+               "gemm_nt: c_split3 needs a bf16 C of >= 3N columns, N a multiple of the tile, 16-byte aligned rows and none of c_f32 / preact / C2 / residual / mulz / fp16 operands");
+    a.preact = (bf16*)d->C + d->N; a.C2 = (bf16*)d->C + 2 * d->N; a.ldc2 = d->ldc;
+    const int m3 = F_PREACT | F_C2 | F_SPLIT3 | (d->act != ACT_NONE ? F_ACT : 0);
+    if (m3 == (F_PREACT | F_C2 | F_SPLIT3 | F_ACT) && d->act == ACT_QGELU) return launch<256, 256, 2, 4, 2, F_PREACT | F_C2 | F_SPLIT3 | F_ACT, ACT_QGELU>(a, batch, st);
+    if (m3 == (F_PREACT | F_C2 | F_SPLIT3 | F_ACT) && d->act == ACT_GELU) return launch<256, 256, 2, 4, 2, F_PREACT | F_C2 | F_SPLIT3 | F_ACT, ACT_GELU>(a, batch, st);
+    return launch<256, 256, 2, 4, 2, F_PREACT | F_C2 | F_SPLIT3, ACT_NONE>(a, batch, st);
+  }
   const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->preact_grad ? F_PGRAD : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
                    (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
   // Start stagger for the f32-residual epilogues (out-proj, fc2: 512 KB of HBM traffic per tile against a 12-48 K-tile loop):

@@ -74,9 +74,14 @@ class PreciseUnimoForward(_PreciseBase):
         self._w3[key] = (ver, out)
         return out
 
-    def lin(self, x: torch.Tensor, wnames: Sequence[str], bnames: Optional[Sequence[str]], N: int, tag: Optional[str] = None, **epi) -> torch.Tensor:
-        """f32 [M, N] = epilogue(x @ W^T + b) with x f32 [M, K]."""
-        out = _e((x.shape[0], N), F32, x.device)
+    def lin(self, x: torch.Tensor, wnames: Sequence[str], bnames: Optional[Sequence[str]], N: int, tag: Optional[str] = None, split3: bool = False,
+            **epi) -> torch.Tensor:
+        """f32 [M, N] = epilogue(x @ W^T + b) with x f32 [M, K] (or bf16 [M, 3K]: already the split operand).  ``split3``: the result as the bf16
+        [M, 3N] operand of the next GEMM, written by the epilogue (256-wide tiles: N % 256 == 0 and at least half a round of them)."""
+        split3 = split3 and N % 256 == 0 and x.shape[0] * N >= 128 * 256 * 256 and x.shape[0] > 128
+        out = _e((x.shape[0], 3 * N), BF, x.device) if split3 else _e((x.shape[0], N), F32, x.device)
+        if split3:
+            epi = dict(epi, c_split3=True, tile_cfg=256)
         bias = self.st.fused(list(bnames), self.st.master) if bnames else None
         deg = tag is not None and tag in self.degrade
         a3 = x if x.dtype == BF else ops.split_bf16x3(self._rb(x, tag), 0, terms=self.terms)      # bf16 input: already the [hi | lo | hi] operand
@@ -137,7 +142,7 @@ class PreciseUnimoForward(_PreciseBase):
             ctx = self._rb(ctx, "vis_attn")
             x1 = self.lin(ctx, [v + "self_attn.out_proj.weight"], [v + "self_attn.out_proj.bias"], H, tag="vis_lin", res_f32=xv)
             h2 = self._ln(x1, v + "layer_norm2.weight", v + "layer_norm2.bias", self.eps_v, split3=pre3)
-            f = self.lin(h2, [v + "mlp.fc1.weight"], [v + "mlp.fc1.bias"], I, tag="vis_lin", act=ops.ACT_QGELU)
+            f = self.lin(h2, [v + "mlp.fc1.weight"], [v + "mlp.fc1.bias"], I, tag="vis_lin", act=ops.ACT_QGELU, split3=pre3)
             xv = self.lin(f, [v + "mlp.fc2.weight"], [v + "mlp.fc2.bias"], H, tag="vis_lin", res_f32=x1)
             # ---- text layer l (BertLayer.forward :540-577)
             t = f"unimo.encoder.text_layer.{l}."
@@ -485,7 +490,7 @@ class PreciseFlavaForward(_PreciseBase):
                          B=B, nh=self.nh, D=64, Sq=S, Sk=S, scale=0.125, fast=True, **attn)
         x1 = self.lin(ctx, [p + "attention.output.dense.weight"], [p + "attention.output.dense.bias"], H, res_f32=x)
         h2 = self._ln(x1, p + "layernorm_after.weight", p + "layernorm_after.bias", self.eps, split3=pre3)
-        f = self.lin(h2, [p + "intermediate.dense.weight"], [p + "intermediate.dense.bias"], I, act=ops.ACT_GELU)
+        f = self.lin(h2, [p + "intermediate.dense.weight"], [p + "intermediate.dense.bias"], I, act=ops.ACT_GELU, split3=pre3)
         return self.lin(f, [p + "output.dense.weight"], [p + "output.dense.bias"], H, res_f32=x1)
 
     @torch.no_grad()

@@ -40,10 +40,12 @@ def _rows2d(t: torch.Tensor):
 def gemm_nt(A, B, out, *, A2=None, B2=None, a_rows=None, b_rows=None, M=None, N=None, bias=None, bias2=None,
             bias_by_brow=False, act=ACT_NONE, preact=None, mulz=None, mul_act=ACT_NONE, res_f32=None, res_bf16=None,
             C2=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_aux=0, tile_cfg=0, b_blocked=False,
-            preact_grad=False):
+            preact_grad=False, c_split3=False):
     """out[M,N] = epi(A[M,K] @ B[N,K]^T (+ A2 @ B2^T)).  A/B are 2-D (row stride = ld) bf16 -- or fp16, all of them (the forward
-    products of the text stream); out bf16 or f32, or fp16 with fp16 operands (C2 is then its bf16 copy)."""
+    products of the text stream); out bf16 or f32, or fp16 with fp16 operands (C2 is then its bf16 copy).  ``c_split3``: out is bf16
+    [M, 3N] and receives the f32 result as the two-term split [hi | lo | hi] (the A operand of the next GEMM of the fp32-accurate path)."""
     d = L.GemmNT()
+    d.c_split3 = int(bool(c_split3))
     K = A.shape[-1]
     d.in_f16 = int(A.dtype == F16)
     assert B.dtype == A.dtype and (A2 is None or (A2.dtype == A.dtype and B2.dtype == A.dtype)), "gemm_nt operands must share one 16-bit type"

@@ -229,3 +229,28 @@ def test_fused_split_outputs_equal_the_split_pass():
     assert torch.equal(c3, ops.split_bf16x3(c, 0, terms=2))
     with pytest.raises(Exception):                       # the exact kernels do not write the operand form
         ops.attn_fwd_f32(ctx=None, ctx_split3=c3, **{**kw, "fast": False})
+
+
+@pytest.mark.parametrize("act", ["none", "qgelu", "gelu"])
+def test_gemm_nt_split3_output(act):
+    """mart_gemm_nt_desc.c_split3: the epilogue writes the f32 result as the [hi | lo | hi] operand of the next split GEMM.  Without an activation it is
+    bit-identical to mart_split_bf16x3 of the f32-output GEMM; with one, hi + lo reproduces the f32-output result to the activation's fast-form accuracy
+    (rcp / exp / erf approximations of the 16-bit epilogue lanes: 1e-6 relative)."""
+    from mkg_analogy_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 1000, 768, 768
+    a = ops.split_bf16x3(torch.randn(M, K, generator=g).to(DEV), 0, terms=2)
+    w = ops.split_bf16x3((0.05 * torch.randn(N, K, generator=g)).to(DEV), 1, terms=2)
+    bias = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    kind = dict(none=ops.ACT_NONE, qgelu=ops.ACT_QGELU, gelu=ops.ACT_GELU)[act]
+    ref = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(a, w, ref, bias=bias, act=kind, tile_cfg=256)
+    out = torch.full((M, 3 * N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(a, w, out, bias=bias, act=kind, tile_cfg=256, c_split3=True)
+    assert bool(torch.isfinite(out.float()).all()) and torch.equal(out[:, :N], out[:, 2 * N:])
+    if act == "none":
+        assert torch.equal(out, ops.split_bf16x3(ref, 0, terms=2))
+    rec = out[:, :N].float() + out[:, N:2 * N].float()
+    err = float((rec - ref).abs().max()) / float(ref.abs().max())
+    print(f"\nsplit3 epilogue ({act}): hi + lo vs the f32-output GEMM, max rel err {err:.2e}")
+    assert err < 2e-5          # the two-term split itself carries 2^-16
