@@ -1239,7 +1239,8 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
     hi[4 + e] = (bf16)b[e]; lo[4 + e] = (bf16)(b[e] - (float)hi[4 + e]);
   }
 }
-__global__ __launch_bounds__(NTH, 2) void attn_split_fwd_k(mart_attn_f32_desc p) {
+template <int NW>      // waves per workgroup: 4 (128 queries) or 8 (256 queries: the K / V of a head are fetched and split half as often)
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_split_fwd_k(mart_attn_f32_desc p) {
   __shared__ __attribute__((aligned(16))) char sm[4 * SP_IMG];
   char* sKh = sm; char* sKl = sm + SP_IMG; char* sVh = sm + 2 * SP_IMG; char* sVl = sm + 3 * SP_IMG;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -1248,7 +1249,7 @@ __global__ __launch_bounds__(NTH, 2) void attn_split_fwd_k(mart_attn_f32_desc p)
   const long long b = blockIdx.z;
   const int Stot = p.Lp + p.Sk;
   const LaneOffs lo = make_offs(lane);
-  const int q0 = blockIdx.x * 128 + wave * 32, qi = q0 + l31;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32, qi = q0 + l31;
   const bool active = q0 < p.Sq;                       // wave-uniform
   bf16x8 qh[4], ql[4];
   {
@@ -1261,21 +1262,22 @@ __global__ __launch_bounds__(NTH, 2) void attn_split_fwd_k(mart_attn_f32_desc p)
   for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
   float m_run = -1.0e30f, l_run = 0.f;
   const float c2 = p.scale * LOG2E;
-  // staging: thread -> key row tid >> 2, 16 consecutive dims (tid & 3) * 16 of K and of V (four float4 each), kept in registers one tile ahead
-  const int srow = tid >> 2, sc16 = (tid & 3) * 16;
-  f32x4 kp[4], vp[4];
+  // staging: thread -> key row, NC 16-byte bf16 chunks (8 dims each) of K and of V: f32 rows kept in registers one tile ahead
+  constexpr int NC = 8 / NW;                                           // chunks per thread: 64 rows x 8 chunks over 64 * NW threads
+  const int srow = tid / (8 / NC), sc8 = (tid % (8 / NC)) * NC;        // first chunk
+  f32x4 kp[2 * NC], vp[2 * NC];
   auto fetch = [&](int t) {
     const int j = min(t * 64 + srow, Stot - 1);                       // rows past the last key: clamped copies (masked below)
     const float* kr = j < p.Lp ? p.pk + (b * p.Lp + j) * p.ldp + h * 64 : p.k + (b * p.Sk + (j - p.Lp)) * p.ldk + h * 64;
     const float* vr = j < p.Lp ? p.pv + (b * p.Lp + j) * p.ldp + h * 64 : p.v + (b * p.Sk + (j - p.Lp)) * p.ldv + h * 64;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { kp[u] = *(const f32x4*)(kr + sc16 + 4 * u); vp[u] = *(const f32x4*)(vr + sc16 + 4 * u); }
+    for (int u = 0; u < 2 * NC; ++u) { kp[u] = *(const f32x4*)(kr + sc8 * 8 + 4 * u); vp[u] = *(const f32x4*)(vr + sc8 * 8 + 4 * u); }
   };
   auto stash = [&]() {
     const int key = swz_key(srow);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {                                      // two 16-byte chunks of 8 dims each
-      const int off = srow * 128 + ((((sc16 >> 3) + u) ^ key) << 4);
+    for (int u = 0; u < NC; ++u) {
+      const int off = srow * 128 + (((sc8 + u) ^ key) << 4);
       bf16x8 a, c;
       split8(kp[2 * u], kp[2 * u + 1], a, c);
       *(bf16x8*)(sKh + off) = a; *(bf16x8*)(sKl + off) = c;
@@ -1710,7 +1712,9 @@ int set_attrs() {
 
 // internal launcher for csrc/precise.hip (mart_attn_fwd_f32 routes its unmasked head-dim-64 calls of evaluation passes here)
 int mart_attn_split_launch(const mart_attn_f32_desc* d, void* stream) {
-  hipLaunchKernelGGL(attn_split_fwd_k, dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), 0, (hipStream_t)stream, *d);
+  static const int nw = getenv("MART_ATTN_SPLIT_WAVES") ? atoi(getenv("MART_ATTN_SPLIT_WAVES")) : 8;   // 0.858 vs 0.910 ms at the bench shape
+  if (nw == 8 && d->Sq > 128) hipLaunchKernelGGL(attn_split_fwd_k<8>, dim3((d->Sq + 255) / 256, d->nh, d->B), dim3(512), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(attn_split_fwd_k<4>, dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(256), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
   return 0;
 }
