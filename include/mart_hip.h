@@ -334,7 +334,7 @@ typedef struct {
   float scale;
   const int64_t* attn_mask; const int64_t* sep; int sep_stride; const float* w0; const float* w1; int rw_skip_row0;
   float* ctx; long long ldctx;
-  int fast;                                                        /* 1 (evaluation passes): unmasked head-dim-64 calls may run on two-term bf16 operand splits
+  int fast;                                                        /* 1 (evaluation passes): head-dim-64 calls may run on two-term bf16 operand splits
                                                                       (three products, 2^-16 relative: the arithmetic of the path's GEMMs) instead of exact f32 */
   void* ctx_split3; long long ldctx3;                              /* optional, fast path only: the context ALSO as [hi | lo | hi] bf16 rows of 3 * nh * D columns
                                                                       (row stride ldctx3 elements): the A operand of the output projection, no separate split pass */

@@ -1224,8 +1224,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
 }
 
 // =========================================================================== fp32-accurate forward on the bf16 matrix pipe (evaluation path)
-// The multi-head attentions of the fp32-accurate EVALUATION pass (engine_precise, no_grad) without masks / reweighting -- the vision tower incl. its
-// text K / V prefix, 24 % of that pass on the f32 matrix pipe (attn_f32_mfma_k: 2.0 ms per layer at the bench shape, the f32 MFMA runs at 1/16 of the
+// The multi-head attentions of the fp32-accurate EVALUATION pass (engine_precise, no_grad) -- the vision tower incl. its text K / V prefix (24 % of
+// that pass on the f32 matrix pipe) and, with the text options of attn_f32_mfma_k, the text / multimodal stacks (attn_f32_mfma_k: 2.0 ms per layer at the bench shape, the f32 MFMA runs at 1/16 of the
 // bf16 rate).  Here both contractions run on TWO-TERM bf16 splits of their f32 operands, three products each (hi*hi + hi*lo + lo*hi, f32 accumulate:
 // 2^-16 relative, the same arithmetic as the path's GEMMs, mart_split_bf16x3): S^T = K q^T with K and Q split, O^T = V^T P^T with V and the
 // probabilities split; softmax statistics in f32.  Skeleton of attn_fwd_k<vision>: a wave owns 32 queries (lane = query), K / V stream in 64-key
@@ -1262,6 +1262,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_split_fwd_k(mar
   for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
   float m_run = -1.0e30f, l_run = 0.f;
   const float c2 = p.scale * LOG2E;
+  // text options (BertSelfAttention / the FLAVA variant), exactly as attn_f32_mfma_k: scale, adaptive reweight of the keys >= sep, additive key mask
+  const bool textopt = p.sep != nullptr || p.attn_mask != nullptr;
+  int sp = 0x7fffffff; float rw = 1.f;
+  if (p.sep) {
+    sp = (int)p.sep[b * p.sep_stride];
+    const float w0 = fminf(fmaxf(*p.w0, 0.f), 0.5f), w1 = fminf(fmaxf(*p.w1, 0.5f), 1.f);
+    rw = (p.rw_skip_row0 && qi == 0) ? 1.f : (qi < sp ? w0 : w1);
+  }
   // staging: thread -> key row, NC 16-byte bf16 chunks (8 dims each) of K and of V: f32 rows kept in registers one tile ahead
   constexpr int NC = 8 / NW;                                           // chunks per thread: 64 rows x 8 chunks over 64 * NW threads
   const int srow = tid / (8 / NC), sc8 = (tid % (8 / NC)) * NC;        // first chunk
@@ -1305,20 +1313,30 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_split_fwd_k(mar
           st[t] = mfma32(kh, qh[ks], st[t]);
         }
       }
-      if (kt * 64 + 64 > Stot) {
-        const int lim = Stot - kt * 64;
+      // scores in the log2 domain: st <- log2(e) * (scale * s [* reweight] [+ mask]); keys past the end: -1e30
+      if (!textopt && kt * 64 + 64 <= Stot) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (t * 32 + mfma_row(r, hh) >= lim) st[t][r] = -1.0e30f;
+          for (int r = 0; r < 16; ++r) st[t][r] *= c2;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = kt * 64 + t * 32 + mfma_row(r, hh);
+            float v = st[t][r] * p.scale;
+            if (j >= sp) v *= rw;
+            if (p.attn_mask) v += (p.attn_mask[b * p.Sk + min(j, Stot - 1)] == 0) ? -10000.0f : 0.f;
+            st[t][r] = j >= Stot ? -1.0e30f : v * LOG2E;
+          }
       }
       float mx = st[0][0];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float rs = 0.f;
@@ -1327,7 +1345,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attn_split_fwd_k(mar
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], c2, -m_new));
+          const float e = __builtin_amdgcn_exp2f(st[t][r] - m_new);
           rs += e;
           pv[t][r] = e;
         }

@@ -756,10 +756,10 @@ extern "C" int mart_attn_fwd_f32(const mart_attn_f32_desc* d, void* stream) {
   MART_CHECK(!d->attn_mask || d->Lp == 0, "attn_f32: mask with prefix unsupported");
   static const int scalar = getenv("MART_ATTN_F32_SCALAR") ? atoi(getenv("MART_ATTN_F32_SCALAR")) : 0;   // 1: the FMA-loop kernel (A/B, tests)
   static const int split_ok = getenv("MART_ATTN_F32_SPLIT") ? atoi(getenv("MART_ATTN_F32_SPLIT")) : 1;   // 0: exact f32 for evaluation passes too
-  if (d->fast && split_ok && !scalar && d->D == 64 && !d->attn_mask && !d->sep && d->ldctx % 4 == 0 && d->ldctx3 % 4 == 0 &&
+  if (d->fast && split_ok && !scalar && d->D == 64 && d->ldctx % 4 == 0 && d->ldctx3 % 4 == 0 &&
       (((uintptr_t)d->ctx | (uintptr_t)d->ctx_split3 | (uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->pk | (uintptr_t)d->pv) & 15) == 0)
     return mart_attn_split_launch(d, stream);          // csrc/attention.hip: attn_split_fwd_k
-  MART_CHECK(!d->ctx_split3 || d->ctx, "attn_f32: ctx_split3 without ctx needs the fast path (fast = 1, D = 64, no mask / reweight, 16-byte aligned operands)");
+  MART_CHECK(!d->ctx_split3 || d->ctx, "attn_f32: ctx_split3 without ctx needs the fast path (fast = 1, D = 64, 16-byte aligned operands)");
   MART_CHECK(!d->ctx_split3, "attn_f32: ctx_split3 is an output of the fast path only");
   if (d->D == 64 && !scalar && d->ldctx % 4 == 0 && ((uintptr_t)d->ctx & 15) == 0 && ((uintptr_t)d->k & 15) == 0 && ((uintptr_t)d->v & 15) == 0 &&
       (!d->pk || (((uintptr_t)d->pk & 15) == 0 && ((uintptr_t)d->pv & 15) == 0))) {

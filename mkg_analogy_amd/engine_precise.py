@@ -149,20 +149,22 @@ class PreciseUnimoForward(_PreciseBase):
             names = [t + f"attention.self.{n}" for n in ("query", "key", "value")]
             tl = "txt_lin_hi" if l >= self.fuse_from else "txt_lin_lo"
             tqkv = self._rb(self.lin(xt, [n + ".weight" for n in names], [n + ".bias" for n in names], 3 * H, tag=tl), "txt_attn")
-            tctx = _e((Mt, H), F32, dev)
+            tctx = _e((Mt, H), F32, dev) if (not pre3 or l >= self.fuse_from) else None     # the fusion op reads the f32 context
+            tctx3 = _e((Mt, 3 * H), BF, dev) if pre3 else None                            # the output projection its split operand
             on = sep_idx is not None
-            ops.attn_fwd_f32(q=tqkv[:, :H], k=tqkv[:, H:2 * H], v=tqkv[:, 2 * H:], ctx=tctx, B=B, nh=nh, D=64, Sq=Lq, Sk=Lq, scale=0.125,
+            ops.attn_fwd_f32(q=tqkv[:, :H], k=tqkv[:, H:2 * H], v=tqkv[:, 2 * H:], ctx=tctx, ctx_split3=tctx3, B=B, nh=nh, D=64, Sq=Lq, Sk=Lq, scale=0.125,
                              attn_mask=attention_mask, sep=sep_idx[:, 2:] if on else None, sep_stride=sep_idx.shape[1] if on else 0,
                              w0=st.m(t + "attention.self.adaptive_weight.0") if on else None,
-                             w1=st.m(t + "attention.self.adaptive_weight.1") if on else None)
-            tctx = self._rb(tctx, "txt_attn")
+                             w1=st.m(t + "attention.self.adaptive_weight.1") if on else None, fast=True)
+            if tctx is not None:
+                tctx = self._rb(tctx, "txt_attn")
             fus = None
             if l >= self.fuse_from:                                  # BertFusion.forward :400-414 (unscaled, unmasked, one "head" of 768)
                 fus = _e((Mt, H), F32, dev)
                 xvf = self._rb(xv, "fusion")
                 ops.attn_fwd_f32(q=self._rb(tctx, "fusion"), k=xvf, v=xvf, ctx=fus, B=B, nh=1, D=H, Sq=Lq, Sk=Nv, scale=1.0)
                 fus = self._rb(fus, "fusion")
-            s1 = self.lin(tctx, [t + "attention.output.dense.weight"], [t + "attention.output.dense.bias"], H, tag=tl, res_f32=xt)
+            s1 = self.lin(tctx3 if pre3 else tctx, [t + "attention.output.dense.weight"], [t + "attention.output.dense.bias"], H, tag=tl, res_f32=xt)
             a = self._ln(s1, t + "attention.output.LayerNorm.weight", t + "attention.output.LayerNorm.bias", self.eps_t)
             ht = _e((Mt, I), F32, dev)
             deg = tl in self.degrade
@@ -482,7 +484,7 @@ class PreciseFlavaForward(_PreciseBase):
         H, I = self.H, self.I
         a = p + "attention.attention."
         pre3 = self._pre()
-        c3 = pre3 and not attn                          # unmasked stack (image): the attention writes the output projection's operand itself
+        c3 = pre3                                        # the attention writes the output projection's operand itself
         h1 = self._ln(x, p + "layernorm_before.weight", p + "layernorm_before.bias", self.eps, split3=pre3)
         qkv = self.lin(h1, [a + f"{n}.weight" for n in ("query", "key", "value")], [a + f"{n}.bias" for n in ("query", "key", "value")], 3 * H)
         ctx = _e((x.shape[0], 3 * H), BF, x.device) if c3 else _e((x.shape[0], H), F32, x.device)

@@ -254,3 +254,30 @@ def test_gemm_nt_split3_output(act):
     err = float((rec - ref).abs().max()) / float(ref.abs().max())
     print(f"\nsplit3 epilogue ({act}): hi + lo vs the f32-output GEMM, max rel err {err:.2e}")
     assert err < 2e-5          # the two-term split itself carries 2^-16
+
+
+@pytest.mark.parametrize("skip0", [False, True])
+def test_attn_split_kernel_text_options(skip0):
+    """attn_split_fwd_k with the text options (scale, adaptive reweight incl. the FLAVA row-0 variant, additive key mask), L = 64 and a ragged L = 40,
+    against float64; the context written both as f32 and as the split operand."""
+    from mkg_analogy_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, nh, H = 3, 12, 768
+    for L in (64, 40):
+        tq = torch.randn(B * L, 3 * H, generator=g)
+        mask = torch.ones(B, L, dtype=torch.int64); mask[0, 33:] = 0; mask[2, 20:] = 0
+        sep = torch.tensor([[3, 5, 17, 20, 25, 30], [2, 4, 9, 12, 14, 16], [1, 2, 11, 13, 15, 19]])
+        w0, w1 = torch.tensor([0.31]), torch.tensor([0.77])
+        dt = tq.to(DEV)
+        c, c3 = torch.full((B * L, H), float("nan"), device=DEV), torch.empty(B * L, 3 * H, device=DEV, dtype=torch.bfloat16)
+        ops.attn_fwd_f32(q=dt[:, :H], k=dt[:, H:2 * H], v=dt[:, 2 * H:], ctx=c, ctx_split3=c3, B=B, nh=nh, D=64, Sq=L, Sk=L, scale=0.125,
+                         attn_mask=mask.to(DEV), sep=sep.to(DEV)[:, 2:], sep_stride=6, w0=w0.to(DEV), w1=w1.to(DEV), rw_skip_row0=skip0, fast=True)
+        ref = _ref_attn(tq[:, :H].reshape(B, L, H), tq[:, H:2 * H].reshape(B, L, H), tq[:, 2 * H:].reshape(B, L, H), nh, 0.125,
+                        mask=mask, sep=sep[:, 2], w0=w0, w1=w1)
+        if skip0:                                             # FLAVA: query row 0 keeps factor 1 (flava_oracle / modeling_flava.py reweight variant)
+            ref0 = _ref_attn(tq[:, :H].reshape(B, L, H), tq[:, H:2 * H].reshape(B, L, H), tq[:, 2 * H:].reshape(B, L, H), nh, 0.125, mask=mask)
+            ref[:, 0] = ref0[:, 0]
+        e = (c.cpu().double().view(B, L, H) - ref).abs().max().item()
+        print(f"\nsplit attention, text options, L = {L}, skip_row0 = {skip0}: max|err| {e:.2e} (|out| max {ref.abs().max():.2f})")
+        assert e < 2.5e-5 * max(1.0, float(ref.abs().max()))
+        assert torch.equal(c3, ops.split_bf16x3(c, 0, terms=2))
