@@ -166,15 +166,17 @@ class PreciseUnimoForward(_PreciseBase):
                 fus = self._rb(fus, "fusion")
             s1 = self.lin(tctx3 if pre3 else tctx, [t + "attention.output.dense.weight"], [t + "attention.output.dense.bias"], H, tag=tl, res_f32=xt)
             a = self._ln(s1, t + "attention.output.LayerNorm.weight", t + "attention.output.LayerNorm.bias", self.eps_t)
-            ht = _e((Mt, I), F32, dev)
+            h3 = pre3 and Mt > 128 and Mt * I >= 128 * 256 * 256                 # the GELU epilogue writes output.dense's split operand (256-wide tiles)
+            ht = _e((Mt, 3 * I), BF, dev) if h3 else _e((Mt, I), F32, dev)
+            hkw = dict(c_split3=True, tile_cfg=256) if h3 else {}
             deg = tl in self.degrade
             a3 = ops.split_bf16x3(self._rb(a, tl), 0, terms=self.terms)
             if fus is not None:
                 ops.gemm_nt(a3, self.w3([t + "intermediate.dense.weight"], rounded=deg), ht, A2=ops.split_bf16x3(self._rb(fus, tl), 0, terms=self.terms),
                             B2=self.w3([t + "intermediate.fusion_dense.weight"], rounded=deg), bias=st.m(t + "intermediate.dense.bias"),
-                            bias2=st.m(t + "intermediate.fusion_dense.bias"), act=ops.ACT_GELU)
+                            bias2=st.m(t + "intermediate.fusion_dense.bias"), act=ops.ACT_GELU, **hkw)
             else:
-                ops.gemm_nt(a3, self.w3([t + "intermediate.dense.weight"], rounded=deg), ht, bias=st.m(t + "intermediate.dense.bias"), act=ops.ACT_GELU)
+                ops.gemm_nt(a3, self.w3([t + "intermediate.dense.weight"], rounded=deg), ht, bias=st.m(t + "intermediate.dense.bias"), act=ops.ACT_GELU, **hkw)
             s2 = self.lin(ht, [t + "output.dense.weight"], [t + "output.dense.bias"], H, tag=tl, res_f32=a)
             xt = self._ln(s2, t + "output.LayerNorm.weight", t + "output.LayerNorm.bias", self.eps_t)
             t_qkv_prev = tqkv if l >= self.export_from else None
