@@ -90,6 +90,17 @@ enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32, F
 template <int DT> __device__ __forceinline__ f32x16 mm(bf16x8 a, bf16x8 b, f32x16 c) {
   if constexpr (DT == 0) return mfma32(a, b, c); else return mfma32h(a, b, c);
 }
+// v_mfma_f32_16x16x32: D[i][j] += sum_k A[i][k] B[k][j]; lane l holds A[i = l & 15][k = 8 (l >> 4) + 0..7], B[k = 8 (l >> 4) + 0..7][j = l & 15];
+// result: lane l, reg r holds D[row = 4 (l >> 4) + r][col = l & 15]
+template <int DT> __device__ __forceinline__ f32x4 mm16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if constexpr (DT == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+// LDS-DMA, 16 B per lane, SADDR form: source = 64-bit scalar base + zero-extended 32-bit lane byte offset -- no per-issue vector address
+// arithmetic, and opaque to the compiler's waitcnt insertion (the loop that uses it counts vmcnt itself)
+__device__ __forceinline__ void dma16(unsigned lds_wave_base, unsigned voff, const void* sbase) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
+}
 template <int DT> __device__ __forceinline__ bf16x4 cvt_c(f32x4 v) {            // primary 16-bit output
   if constexpr (DT == 2) return f4_to_h4raw(v); else return f4_to_bf4(v);
 }
@@ -110,6 +121,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int RA = (BM * 8) / NT, RB = (BN * 8) / NT;   // 16-byte chunks per thread per stage
   static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/threads mismatch");
+  static_assert(PIPE != 4 || (BN / WAVES_N == 64), "the 16x16x32 quad mapping of the epilogues is written for 64-column wave tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -150,14 +162,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
       int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
       int gm = min(m0 + row, p.M - 1);
       if (p.a_rows) gm = p.a_rows[gm];
-      offA[r] = (unsigned)gm * (unsigned)p.lda + lc * 8;
+      offA[r] = ((unsigned)gm * (unsigned)p.lda + lc * 8) * (PIPE == 4 ? 2u : 1u);      // PIPE 4: BYTE offsets (SADDR-form DMA; < 2^32 by dispatch)
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
       int gn = min(n0 + row, p.N - 1);
       if (p.b_rows) gn = p.b_rows[gn];
-      offB[r] = (unsigned)gn * (unsigned)p.ldb + lc * 8;
+      offB[r] = ((unsigned)gn * (unsigned)p.ldb + lc * 8) * (PIPE == 4 ? 2u : 1u);
       if (p.b_blocked) offB[r] = (unsigned)(row & 255) * 64 + lc * 8;       // inside the 256x64 block
     }
     // tile-blocked weights: block (n0/256, kt) of operand with K' columns starts at ((n0/256)*(K'/64) + kt) * 16384 elements
@@ -169,6 +181,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
   const int nk1 = p.K / BK, nk = nk1 + p.K2 / BK;
 
   auto stage = [&](int t, int buf) {
+    if constexpr (PIPE == 4) {                               // (the persistent loop's prefetch of the next tile's K-tile 0)
+      const char* Ab = (const char*)(t >= p.K / BK ? A2 + (t - p.K / BK) * BK : A + t * BK);
+      const char* Bb = (const char*)(t >= p.K / BK ? B2 + (t - p.K / BK) * BK : B + t * BK);
+      const unsigned l = (unsigned)(__UINTPTR_TYPE__)LDS_PTR(smem) + buf * STAGE + wave * 1024;
+#pragma unroll
+      for (int r = 0; r < RA; ++r) dma16(l + r * NT * 16, offA[r], Ab);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) dma16(l + A_BYTES + r * NT * 16, offB[r], Bb);
+      return;
+    }
     const bf16* Ap = A; const bf16* Bp = B + blkB1; int k0 = t * BK;
     if (t >= nk1) { Ap = A2; Bp = B2 + blkB2; k0 = (t - nk1) * BK; }
     const long long kb = p.b_blocked ? (long long)(k0 >> 6) * 16384 : k0;      // blocked: whole 256x64 blocks per K-tile
@@ -183,7 +205,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
   // PIPE == 2 (8-phase loop): the two wave-rows interleave in 64-row slabs -- wave-row wr owns rows {ih*128 + wr*64 + [0,64)},
   // ih = 0,1 -- so that the first 32-row block pair of EVERY wave lies in the upper half-tile of A (rows 0..127) and the
   // second pair in the lower one: a half-tile is dead (and can be re-staged) as soon as its phase has been read.
-  constexpr bool ILV = (PIPE == 2);
+  constexpr bool ILV = (PIPE == 2 || PIPE == 4);
+  // PIPE 4 computes on v_mfma_f32_16x16x32: a 32-row block of the wave tile is 2 x 4 blocks of 16 x 16, and register quad q of acc[i][j] is the
+  // block (rows j * 16 .. + 15, columns q * 16 .. + 15) of 32-row block i: lane l holds row (l & 15) and columns 4 (l >> 4) + 0..3 of it.
+  // (32x32x16, every other PIPE: quad q of acc[i][j] = row (l & 31), columns j * 32 + 8 q + 4 (l >> 5) + 0..3.)  The epilogues address quads
+  // through erow / ecol and are otherwise the same code.
+  constexpr bool M16 = (PIPE == 4);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  auto erow = [&](int j) { return M16 ? j * 16 + l15 : l31; };
+  auto ecol = [&](int j, int q) { return M16 ? q * 16 + 4 * g4 : j * 32 + 8 * q + 4 * h; };
   auto ro = [](int i) constexpr { return ILV ? (i >> 1) * 128 + (i & 1) * 32 : i * 32; };   // row offset of 32-row block i inside the wave's rows
   const int wm0 = (wave / WAVES_N) * (ILV ? 64 : WM), wn0 = (wave % WAVES_N) * WN;
   // LDS read addressing: row -> byte base and swizzle key
@@ -412,6 +442,127 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
       bar();
     }
     if (grp == 0) bar();                                   // balance the barrier count
+  } else if constexpr (PIPE == 4) {
+    // ---- 4-phase main loop on v_mfma_f32_16x16x32 (round 5; tools/kloop_lab.hip V3, tools/power_lab.hip).
+    //   Why 16x16x32: on random operands the matrix pipe alone is POWER-limited -- 1.95 PFLOP/s at the 1.4 kW package cap with 32x32x16,
+    //   2.2 PFLOP/s with 16x16x32 (a quarter of the accumulator traffic per flop): the same flops for ~11 % fewer joules, which is what a
+    //   loop that runs at the power cap is paid in (profiles/r05_power_lab.txt).
+    //   Same LDS image, same LDS-DMA half-tiles (A0 A1 B0 B1, 2 instructions per wave each) and the same row ownership as the 8-phase loop; the
+    //   two wave-rows run ONE barrier apart.  Per K-tile and wave two segments of 32 MFMAs (4 barriers instead of 8):
+    //        S1 = [ reads A(ih0) + B, 16 x ds_read_b128 | bar | 32 MFMAs: rows ih0 x all 64 columns x K=64 | bar ]
+    //        S2 = [ reads A(ih1),      8 x ds_read_b128 | bar | 32 MFMAs: rows ih1                          | bar ]
+    //   LDS-DMA issue (from inside the MFMA clusters, SADDR form: no vector address arithmetic):
+    //        M-S1(t): X(t) = A1(t+1)                  M-S2(t): Y(t) = A0(t+2), B0(t+2), B1(t+2)
+    //   Counted waits, both in the READ segments (every wave executes them, whichever wave-row it is in):
+    //        end of R-S1(t): vmcnt(6) -> X(t-1) = A1(t) has landed           end of R-S2(t): vmcnt(2) -> Y(t-1) = A0, B0, B1 of t+1 have landed
+    //   RAW: a half-tile is first read (by the leading wave-row) in the segment AFTER a barrier that every wave passed behind its own wait:
+    //        A1(t) is waited for in R-S1(t) (intervals 1 / 2 of K-tile t) and read from R-S2(t) on (interval 3); A0, B0, B1(t+1) are waited for in
+    //        R-S2(t) (intervals 3 / 4) and read from R-S1(t+1) on (interval 5).  (The 8-phase loop's single wait at the end of P4 was one
+    //        barrier short of this for the lagging wave-row's share -- 8 phases of slack in practice, but not ordered.)
+    //   WAR: A0, B0, B1(t) are last read in R-S1(t) by the lagging row (interval 2, retired by its lgkmcnt(0) at the start of interval 3) and
+    //        re-staged from M-S2(t) (intervals 4 / 5); A1(t) is last read in interval 4 and re-staged from M-S1(t+1) (intervals 6 / 7).
+    static_assert(BM == 256 && BN == 256 && WAVES_M == 2 && WAVES_N == 4, "the 4-phase loop is laid out for 256x256 tiles, 2x4 waves");
+    const int grp = wave >> 2;
+    const int colsw = (g4 ^ (l15 >> 1)) << 4;             // swizzled 16-byte chunk of k-step 0 (key (row >> 1) & 7 = (l & 15) >> 1 for every block); k-step 1: ^ 64
+    const int rdA = (wm0 + l15) * 128 + colsw, rdB = A_BYTES + (wn0 + l15) * 128 + colsw;
+    const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)LDS_PTR(smem) + wave * 1024;
+    bf16x8 a16[4][2], b16[4][2];
+    auto tileA = [&](int t) -> const char* { return (const char*)(t >= nk1 ? A2 + (t - nk1) * BK : A + t * BK); };
+    auto tileB = [&](int t) -> const char* { return (const char*)(t >= nk1 ? B2 + (t - nk1) * BK : B + t * BK); };
+    auto issueA = [&](const char* base, int t, auto HALF) {
+      constexpr int hf = decltype(HALF)::value;
+      const unsigned l = lds0 + (t & 1) * STAGE;
+#pragma unroll
+      for (int r = 2 * hf; r < 2 * hf + 2; ++r) dma16(l + r * NT * 16, offA[r], base);
+    };
+    auto issueB = [&](const char* base, int t, auto HALF) {
+      constexpr int hf = decltype(HALF)::value;
+      const unsigned l = lds0 + (t & 1) * STAGE + A_BYTES;
+#pragma unroll
+      for (int r = 2 * hf; r < 2 * hf + 2; ++r) dma16(l + r * NT * 16, offB[r], base);
+    };
+    auto readS1 = [&](const char* s_) {                    // k-step 0 of B and A first: the order the MFMAs consume them in
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) b16[nb][kk] = *(const bf16x8*)(s_ + ((rdB + nb * 2048) ^ (kk << 6)));
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) a16[mb][kk] = *(const bf16x8*)(s_ + ((rdA + mb * 2048) ^ (kk << 6)));
+      }
+    };
+    auto readS2 = [&](const char* s_) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) a16[mb][kk] = *(const bf16x8*)(s_ + ((rdA + 16384 + mb * 2048) ^ (kk << 6)));
+    };
+    auto mma = [&](auto IH, auto&& d0, auto&& d1, auto&& d2) {
+      constexpr int ih = decltype(IH)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+          f32x16& C = acc[2 * ih + (mb >> 1)][mb & 1];
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            f32x4 c = {C[4 * nb], C[4 * nb + 1], C[4 * nb + 2], C[4 * nb + 3]};
+            c = mm16<DT>(b16[nb][kk], a16[mb][kk], c);
+            C[4 * nb] = c[0]; C[4 * nb + 1] = c[1]; C[4 * nb + 2] = c[2]; C[4 * nb + 3] = c[3];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk == 0 && mb == 0) d0();
+          if (kk == 0 && mb == 1) d1();
+          if (kk == 0 && mb == 2) d2();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto lgkm0 = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto nop = [] {};
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // ---- prologue: K-tile 0 complete, A0 / B0 / B1 of K-tile 1 in flight (= Y(-1); X(0) = A1(1) comes from M-S1(0))
+    if (!have0) { issueA(tileA(0), 0, I0{}); issueB(tileB(0), 0, I0{}); issueB(tileB(0), 0, I1{}); issueA(tileA(0), 0, I1{}); }
+    else bar();                                            // persistent loop: the epilogue staging region overlaps buffer 1
+    if (nk > 1) {
+      issueA(tileA(1), 1, I0{}); issueB(tileB(1), 1, I0{}); issueB(tileB(1), 1, I1{});
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    if (grp == 1) bar();                                   // the lower wave-row runs one barrier behind
+    for (int t = 0; t < nk; ++t) {
+      const char* sT = smem + (t & 1) * STAGE;
+      const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+      const char* pA1 = tileA(min(t + 1, nk - 1));        // operand bases of the half-tiles this K-tile's clusters issue (scalar unit)
+      const char* pA2 = tileA(min(t + 2, nk - 1));
+      const char* pB2 = tileB(min(t + 2, nk - 1));
+      // R-S1.  Outstanding behind the reads, newest first: Y(t-1) [6, if issued] | X(t-1) [2]  ->  X(t-1) = A1(t) landed
+      readS1(sT);
+      if (more1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bar();
+      lgkm0();
+      mma(I0{}, [&] { if (more1) issueA(pA1, t + 1, I1{}); }, nop, nop);
+      bar();
+      // R-S2.  Outstanding: X(t) [2, if issued] | Y(t-1)  ->  Y(t-1) = A0, B0, B1 of K-tile t+1 landed
+      readS2(sT);
+      if (more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bar();
+      lgkm0();
+      mma(I1{}, [&] { if (more2) issueA(pA2, t + 2, I0{}); }, [&] { if (more2) issueB(pB2, t + 2, I0{}); }, [&] { if (more2) issueB(pB2, t + 2, I1{}); });
+      bar();
+    }
+    if (grp == 0) bar();                                   // balance the barrier count
   } else if constexpr (WAVES_M == 2 && WAVES_N == 4) {
     // ---- ping-pong main loop (8 waves).  The two wave-rows of the tile (waves 0-3 / 4-7; waves w and w+4 share a
     // SIMD) run the same 4-phase K-tile sequence  R0 | M0 | R1 | M1  (R = fragment reads of two k-steps (+ LDS-DMA
@@ -520,7 +671,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        *(f32x4*)(ep + l31 * EP_LD + j * 32 + 8 * q + 4 * h) =
+        *(f32x4*)(ep + erow(j) * EP_LD + ecol(j, q)) =
             f32x4{ai[j][4 * q], ai[j][4 * q + 1], ai[j][4 * q + 2], ai[j][4 * q + 3]};
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -547,7 +698,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         bq[j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int n = en0 + wn0 + j * 32 + 8 * q + 4 * h;
+        const int n = en0 + wn0 + ecol(j, q);
         if (p.bias) bq[j][q] = *(const f32x4*)(p.bias + n);
         if (p.bias2) bq[j][q] += *(const f32x4*)(p.bias2 + n);
       }
@@ -570,7 +721,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 v = f32x4{ai[j][4 * q], ai[j][4 * q + 1], ai[j][4 * q + 2], ai[j][4 * q + 3]} * p.alpha + bq[j][q];
-          char* dst = epb + l31 * RS + (j * 32 + 8 * q + 4 * h) * 2;
+          char* dst = epb + erow(j) * RS + ecol(j, q) * 2;
           if constexpr ((EPI & F_PGRAD) != 0) {
             f32x2 a0, a1, g0, g1;
 #ifdef KO_EPI_ACT
@@ -914,6 +1065,10 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   long long t256 = (long long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
   int cfg = d->tile_cfg;
   bool old_loop = false;
+  // K loop of the 256x256 kernels: 4 = the 4-phase loop on 16x16x32 MFMAs (default); 2 = the 8-phase loop on 32x32x16 (rounds 2-4), kept for the
+  // tile-blocked weight layout, for operands whose BYTE offsets do not fit the 32-bit lane offsets of the SADDR-form DMA, and (harness builds) for A/B runs
+  const bool big_off = (long long)(d->a_rows ? d->a_src_rows : d->M) * d->lda >= (1LL << 31) || (long long)(d->b_rows ? d->b_src_rows : d->N) * d->ldb >= (1LL << 31);
+  bool loop8 = d->b_blocked || big_off;
   a.dbg = 0;
   a.stagger_ticks = 0;
   a.b_blocked = d->b_blocked;
@@ -933,6 +1088,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   // 2563 / 2564: the round-1 ping-pong K loop (one vmcnt(0) per K-tile), fast / general epilogue (A/B + bit-identity tests)
   if (cfg == 2563 || cfg == 2564) { old_loop = true; cfg = cfg == 2563 ? 256 : 2561; }
   if (cfg == 2562) cfg = 256;                       // 2562: fast epilogue without the persistent loop (A/B)
+  if (cfg == 2565 || cfg == 2566) { loop8 = true; cfg = cfg == 2565 ? 256 : 2561; }   // the 8-phase loop, fast / general epilogue (A/B against the 4-phase loop)
+  if (a.dbg) loop8 = true;                          // the knock-out experiments are written into the older loops
 #endif
   MART_CHECK(!d->b_blocked || cfg == 256, "gemm_nt: b_blocked requires the 256x256 tile");
 #ifdef MART_EXPERIMENTS
@@ -960,6 +1117,15 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
                        ((uintptr_t)d->preact % 8 == 0) && ((uintptr_t)d->C2 % 8 == 0) && ((uintptr_t)d->bias % 16 == 0) &&
                        ((uintptr_t)d->bias2 % 16 == 0) && (d->stride_c % 4 == 0) && (d->stride_aux % 4 == 0);
   const int dt = d->in_f16 ? (d->c_f16 ? 2 : 1) : 0;
+  // fast-epilogue instantiations exist on the 4-phase loop only (and, in harness builds, on the 8-phase loop for A/B); a product call that needs the
+  // 8-phase loop (loop8) takes its general-epilogue kernel
+#ifdef MART_EXPERIMENTS
+#define L256(...) (loop8 ? launch<256, 256, 2, 4, 2, __VA_ARGS__>(a, batch, st) : launch<256, 256, 2, 4, 4, __VA_ARGS__>(a, batch, st))
+  const bool fast_ok = true;
+#else
+#define L256(...) launch<256, 256, 2, 4, 4, __VA_ARGS__>(a, batch, st)
+  const bool fast_ok = !loop8;
+#endif
   const bool two_acts = d->mulz && d->act != ACT_NONE;               // not a fast combination
   if (d->c_split3) {
     // C is bf16 [M, 3N]: hi at column n, lo at N + n, hi again at 2N + n -- the three 16-bit outputs of the packed epilogue
@@ -967,9 +1133,10 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
                "gemm_nt: c_split3 needs a bf16 C of >= 3N columns, N a multiple of the tile, 16-byte aligned rows and none of c_f32 / preact / C2 / residual / mulz / fp16 operands");
     a.preact = (bf16*)d->C + d->N; a.C2 = (bf16*)d->C + 2 * d->N; a.ldc2 = d->ldc;
     const int m3 = F_PREACT | F_C2 | F_SPLIT3 | (d->act != ACT_NONE ? F_ACT : 0);
-    if (m3 == (F_PREACT | F_C2 | F_SPLIT3 | F_ACT) && d->act == ACT_QGELU) return launch<256, 256, 2, 4, 2, F_PREACT | F_C2 | F_SPLIT3 | F_ACT, ACT_QGELU>(a, batch, st);
-    if (m3 == (F_PREACT | F_C2 | F_SPLIT3 | F_ACT) && d->act == ACT_GELU) return launch<256, 256, 2, 4, 2, F_PREACT | F_C2 | F_SPLIT3 | F_ACT, ACT_GELU>(a, batch, st);
-    return launch<256, 256, 2, 4, 2, F_PREACT | F_C2 | F_SPLIT3, ACT_NONE>(a, batch, st);
+    MART_CHECK(fast_ok, "gemm_nt: c_split3 is not available with b_blocked / operands beyond 2^31 elements");
+    if (m3 == (F_PREACT | F_C2 | F_SPLIT3 | F_ACT) && d->act == ACT_QGELU) return L256(F_PREACT | F_C2 | F_SPLIT3 | F_ACT, ACT_QGELU);
+    if (m3 == (F_PREACT | F_C2 | F_SPLIT3 | F_ACT) && d->act == ACT_GELU) return L256(F_PREACT | F_C2 | F_SPLIT3 | F_ACT, ACT_GELU);
+    return L256(F_PREACT | F_C2 | F_SPLIT3, ACT_NONE);
   }
   const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->preact_grad ? F_PGRAD : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
                    (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
@@ -978,20 +1145,20 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   // while the matrix cores idle.  Groups of workgroups that share an A panel start 3 us apart (8 phases): +15 % on the
   // out-proj shape, +2-3 % on fc2 (tools/nt_harness time 5 0 70300); only where there are rounds enough to pay for the delay.
   if (d->res_f32 && d->c_f32 && cfg == 256 && a.stagger_ticks == 0 && t256 >= 4 * 256 && batch == 1) a.stagger_ticks = 300;
-  if (aligned) {
+  if (aligned && fast_ok) {
     // persistent loop: +6-7 % where the epilogue is light (bf16 out); with the fp32 residual or two bf16 outputs it is
     // neutral at best (re-measured after the epilogue work: fc1 0.571 vs 0.572 ms, step +0.3 %) -> only for the light masks
     const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;
 #ifdef MART_EXPERIMENTS
 #define MART_FAST(M_, K_)                                                                   \
     if (dt == 0 && mask == (M_) && kind == (K_)) {                                                       \
-      if (tile == 256 && !old_loop) return persist ? launch<256, 256, 2, 4, 2, (M_), (K_), true>(a, batch, st) : launch<256, 256, 2, 4, 2, (M_), (K_)>(a, batch, st); \
+      if (tile == 256 && !old_loop) return persist ? L256((M_), (K_), true) : L256((M_), (K_)); \
       if (persist) return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_), true>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_), true>(a, batch, st); \
       return tile == 256 ? launch<256, 256, 2, 4, 0, (M_), (K_)>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st); }
 #else
 #define MART_FAST(M_, K_)                                                                   \
     if (dt == 0 && mask == (M_) && kind == (K_)) {                                                       \
-      if (tile == 256) return persist ? launch<256, 256, 2, 4, 2, (M_), (K_), true>(a, batch, st) : launch<256, 256, 2, 4, 2, (M_), (K_)>(a, batch, st); \
+      if (tile == 256) return persist ? L256((M_), (K_), true) : L256((M_), (K_)); \
       return persist ? launch<128, 128, 2, 2, 0, (M_), (K_), true>(a, batch, st) : launch<128, 128, 2, 2, 0, (M_), (K_)>(a, batch, st); }
 #endif
     const int kind = d->mulz ? d->mul_act : d->act;
@@ -1012,7 +1179,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
     // fp16 operands: the forward linear layers of the text stream (engine.text_f16)
 #define MART_FAST_H(M_, K_, DT_, P_)                                                           \
     if (dt == (DT_) && mask == (M_) && kind == (K_)) {                                         \
-      if (tile == 256) return launch<256, 256, 2, 4, 2, (M_), (K_), (P_), (DT_)>(a, batch, st); \
+      if (tile == 256) return L256((M_), (K_), (P_), (DT_)); \
       return launch<128, 128, 2, 2, 0, (M_), (K_), (P_), (DT_)>(a, batch, st); }
     MART_FAST_H(0, ACT_NONE, 1, true)                                 // Q/K/V (bf16 out, the attention kernels' operand type)
     MART_FAST_H(F_CF32, ACT_NONE, 1, false)                           // attention.output.dense / output.dense: f32 into the LayerNorm
@@ -1022,9 +1189,13 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
     MART_FAST_H(F_ACT, ACT_GELU, 2, false)                            // ... under no_grad
 #undef MART_FAST_H
   }
-  if (dt == 1) return (cfg == 256 || cfg == 2561) ? launch<256, 256, 2, 4, 2, -1, 0, false, 1>(a, batch, st) : launch<128, 128, 2, 2, 0, -1, 0, false, 1>(a, batch, st);
-  if (dt == 2) return (cfg == 256 || cfg == 2561) ? launch<256, 256, 2, 4, 2, -1, 0, false, 2>(a, batch, st) : launch<128, 128, 2, 2, 0, -1, 0, false, 2>(a, batch, st);
-  if ((cfg == 256 || cfg == 2561) && !old_loop) return launch<256, 256, 2, 4, 2>(a, batch, st);
+  // general epilogue: both loops exist in every build
+#define G256(DT_) (loop8 ? launch<256, 256, 2, 4, 2, -1, 0, false, (DT_)>(a, batch, st) : launch<256, 256, 2, 4, 4, -1, 0, false, (DT_)>(a, batch, st))
+  if (dt == 1) return (cfg == 256 || cfg == 2561) ? G256(1) : launch<128, 128, 2, 2, 0, -1, 0, false, 1>(a, batch, st);
+  if (dt == 2) return (cfg == 256 || cfg == 2561) ? G256(2) : launch<128, 128, 2, 2, 0, -1, 0, false, 2>(a, batch, st);
+  if ((cfg == 256 || cfg == 2561) && !old_loop) return G256(0);
+#undef G256
+#undef L256
 #ifdef MART_EXPERIMENTS
   if (cfg == 256 || cfg == 2561) return launch<256, 256, 2, 4>(a, batch, st);
 #endif

@@ -217,7 +217,7 @@ class UnimoEngine:
         ``trans_hidden_states`` (lit_models/transformer.py:94-95,103-107: the [MASK] row and four more per example).  Nothing else reads
         the last text layer's other rows (modeling_unimo.py:616 exports the K/V of layers idx - 1 <= 10 only), so everything behind its
         attention / fusion -- output projection, FFN, both LayerNorms, the head transform, and their backward -- runs on B * nr rows
-        instead of B * L.  Exact: the computed rows are what the dense pass computes; the returned tensor is zero elsewhere."""
+        instead of B * L.  Exact: the computed rows are what the dense pass computes; the returned tensor is NaN elsewhere."""
         self._pass_begin()
         st, H, nh, I = self.st, self.H, self.nh, self.I
         dev = input_ids.device
@@ -448,7 +448,9 @@ class UnimoEngine:
             sv["head"] = (xtb, y, zh, hm, hr)
             if Mh != Mt:                                    # the reference's [B, L, H] tensor with the requested rows filled in
                 tc = trans
-                trans, transb = torch.zeros((Mt, H), device=dev, dtype=F32), torch.zeros((Mt, H), device=dev, dtype=BF)
+                # NaN, not zero, outside the requested rows: a consumer that breaks the promise (scores another position, reduces over all
+                # of trans_hidden_states) gets NaN logits / a NaN loss instead of silently bias-only numbers (the reference computes every row)
+                trans, transb = torch.full((Mt, H), float("nan"), device=dev, dtype=F32), torch.full((Mt, H), float("nan"), device=dev, dtype=BF)
                 ops.scatter_rows(tc, R, nr, trans)
                 ops.scatter_rows(tc, R, nr, transb)
         self._text_done()
@@ -464,6 +466,9 @@ class UnimoEngine:
         """Accumulates d(loss)/d(param) into FlatStore.grad given d(loss)/d(trans_hidden_states) (f32 [B,L,H])."""
         st, H, nh, I = self.st, self.H, self.nh, self.I
         dev = dtrans.device
+        # the side / text streams fork from this (main) stream: it has to have waited for an off-stream gradient zero-fill / W^T refresh
+        # (FlatStore.pending, MART_ASYNC_STEP=1 with zero_grad() between forward and backward) before any of them writes a gradient
+        st.join_pending()
         B, Lq, P, Nv, Nvp = sv["B"], sv["L"], sv["P"], sv["Nv"], sv["Nvp"]
         train, seed = sv["train"], sv["seed"]
         Mv, Mt = B * Nv, B * Lq

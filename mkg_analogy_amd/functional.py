@@ -214,8 +214,10 @@ class LazyLogits:
     Indexing patterns used by the trainer surface are scored on demand; ``materialize()`` builds the full tensor."""
 
     def __init__(self, trans: torch.Tensor, trans_bf16: torch.Tensor, store, word_name: str = WORD, bias_name: str = BIAS, precise=None,
-                 head_split: bool = True):
+                 head_split: bool = True, valid_rows=None):
         self.trans, self.trans_bf16, self.store = trans, trans_bf16, store
+        # forward(needed_rows=...): flat ids (b * L + position, int32 [B, n]) of the only rows of ``trans`` that were computed -- the rest is NaN
+        self.valid_rows = valid_rows
         self.head_split = head_split                # the ENGINE's switch (one source of truth for the transform and the scoring GEMM)
         self.word_name, self.bias_name = word_name, bias_name
         self.precise = precise                      # engine_precise.PreciseUnimoForward: fp32-accurate scoring (eval only)
@@ -228,7 +230,12 @@ class LazyLogits:
     def __getitem__(self, key):
         if isinstance(key, tuple) and len(key) == 2 and torch.is_tensor(key[0]) and torch.is_tensor(key[1]):
             L = self.trans.shape[1]
-            rows = (key[0].to(self.trans.device).to(torch.int64) * L + key[1].to(self.trans.device).to(torch.int64)).to(torch.int32).contiguous()
+            pos = key[1].to(self.trans.device).to(torch.int64)
+            pos = torch.where(pos < 0, pos + L, pos)
+            rows = (key[0].to(self.trans.device).to(torch.int64) * L + pos).to(torch.int32).contiguous()
+            if self.valid_rows is not None and not bool(torch.isin(rows, self.valid_rows.reshape(-1)).all()):     # (host sync: not the trainer's path)
+                raise ValueError("logits[b, pos]: a position outside the needed_rows this forward pass was promised; call the model without "
+                                 "needed_rows (or name the position) to score it")
             return LazyRows(self, rows)
         return self.materialize()[key]
 
@@ -241,6 +248,9 @@ class LazyLogits:
         return LazyRows(self, row)
 
     def materialize(self) -> torch.Tensor:
+        if self.valid_rows is not None:
+            raise ValueError("logits.materialize(): this forward pass computed only the needed_rows it was given (every other row of "
+                             "trans_hidden_states is NaN); call the model without needed_rows for the full [B, L, V] tensor")
         B, L, _ = self.trans.shape
         rows = torch.arange(B * L, device=self.trans.device, dtype=torch.int32)
         ids = torch.arange(self.vocab, device=self.trans.device, dtype=torch.int32)

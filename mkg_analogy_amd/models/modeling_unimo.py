@@ -294,7 +294,8 @@ class UnimoForMaskedLM(nn.Module):
                 needed_rows=None):
         """``needed_rows`` (optional, int [B] or [B, n] token positions): a promise that only these rows of ``trans_hidden_states`` / ``logits`` will
         be read (the trainer surface reads the [MASK] row and four more, lit_models/transformer.py:94-95,103-107).  The last text layer's
-        post-attention part and the head transform then run on those rows only; the returned ``trans_hidden_states`` is zero elsewhere.
+        post-attention part and the head transform then run on those rows only; the returned ``trans_hidden_states`` is NaN elsewhere, and
+        ``logits`` refuses to score (or materialise) any other row.
         Exact for the rows named; omit it to get every row as the reference does."""
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention maps / per-layer hidden states are not materialised by the fused HIP path")
@@ -346,12 +347,13 @@ class UnimoForMaskedLM(nn.Module):
         self._engine.save_for_backward = torch.is_grad_enabled()
         rows = None
         if needed_rows is not None and labels is None:
-            nr_ = needed_rows.to(dev).reshape(B, -1).to(torch.int64).clamp_(0, L - 1)
+            nr_ = needed_rows.to(dev).reshape(B, -1).to(torch.int64)
+            nr_ = torch.where(nr_ < 0, nr_ + L, nr_).clamp(0, L - 1)     # negative positions wrap as in the reference's fancy indexing; out of place
             rows = (torch.arange(B, device=dev, dtype=torch.int64)[:, None] * L + nr_).to(torch.int32).contiguous()
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
                                       image_table, image_index, rows)
         st.join_pending()                           # gradient zero-fill / W^T refresh issued next to this forward pass (optim.FusedAdamW)
-        logits = Fn.LazyLogits(trans, holder["trans_bf16"], st, head_split=self._engine.head_split)
+        logits = Fn.LazyLogits(trans, holder["trans_bf16"], st, head_split=self._engine.head_split, valid_rows=rows)
         loss = None
         if labels is not None:                      # CrossEntropyLoss over the full vocabulary (:880-882); not used by MarT
             full = logits.materialize()

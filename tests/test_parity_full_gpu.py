@@ -389,19 +389,37 @@ def test_last_layer_row_subset_equals_the_dense_path(tag, pre):
             worst, wn = r, n
     print(f"\n{tag}: loss dense {l0:.7f} row subset {l1:.7f}; worst gradient rel-L2 difference over {len(st.slots)} tensors {worst:.3e} ({wn})")
     assert abs(l0 - l1) < 2e-6 * max(1.0, abs(l0)) and worst < 2e-3, (l0, l1, worst, wn)
-    # forward values: requested rows identical to the dense pass, the others zero
+    # forward values: requested rows identical to the dense pass, the others NaN
     keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values") + (() if pre else ("sep_idx",))
     need = torch.stack([gb["rel_idx"][:, 0], gb["rel_idx"][:, 1], gb["q_head_idx"]], 1) if not pre else (gb["input_ids"] == 103).int().argmax(1)[:, None]
     need = torch.cat([need, need[:, :1]], 1)                     # a repeated position: computed twice, scattered once
+    need_before = need.clone()
     with torch.no_grad():
         _, dense = model(**{k: gb[k] for k in keys}, return_dict=True)
-        _, part = model(**{k: gb[k] for k in keys}, return_dict=True, needed_rows=need)
+        out_p, part = model(**{k: gb[k] for k in keys}, return_dict=True, needed_rows=need)
+    assert torch.equal(need, need_before)                        # the caller's tensor is not clamped in place
     ar = torch.arange(B, device="cuda")[:, None]
     d = float((dense[ar, need] - part[ar, need]).abs().max())
     mask = torch.ones(B, L, dtype=torch.bool, device="cuda")
     mask[ar, need] = False
-    print(f"   requested rows: max|dense - subset| {d:.3e}; other rows max {float(part[mask].abs().max()):.1e}")
-    assert d < 1e-5 and float(part[mask].abs().max()) == 0.0
+    print(f"   requested rows: max|dense - subset| {d:.3e}; other rows all NaN: {bool(torch.isnan(part[mask]).all())}")
+    assert d < 1e-5 and bool(torch.isnan(part[mask]).all())
+    # the guard: a requested position scores, any other position (or the full tensor) raises instead of returning bias-only numbers
+    lg = out_p.logits
+    ok = lg[ar[:, 0], need[:, 0]][:, BASE:BASE + 8]
+    assert bool(torch.isfinite(ok.float()).all())
+    other = (need[:, 0] + 1) % L
+    other = torch.where((other[:, None] == need).any(1), (other + 1) % L, other)
+    other = torch.where((other[:, None] == need).any(1), (other + 1) % L, other)
+    other = torch.where((other[:, None] == need).any(1), (other + 1) % L, other)
+    with pytest.raises(ValueError, match="needed_rows"):
+        lg[ar[:, 0], other]
+    with pytest.raises(ValueError, match="needed_rows"):
+        lg.materialize()
+    # negative positions wrap like the reference's fancy indexing
+    with torch.no_grad():
+        _, neg = model(**{k: gb[k] for k in keys}, return_dict=True, needed_rows=need - L)
+    assert float((neg[ar, need] - part[ar, need]).abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("tag", ["g8_pretrain_cond", "g8_pretrain_plain", "g8b_pretrain_p196_cond"])
