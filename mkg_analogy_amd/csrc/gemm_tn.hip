@@ -8,6 +8,7 @@
 // Optional fused column sums of X (bias gradients): VALU sums of the fragments the MFMAs consume anyway.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 #include "mart_hip.h"
 
 namespace {
@@ -393,8 +394,227 @@ __global__ __launch_bounds__(NT) void gemm_tn8_kernel(Args2 p) {
   }
 }
 
+
+#ifdef MART_EXPERIMENTS
+// ============================================================================================================================
+// Round 5 EXPERIMENT (harness builds only, -DMART_EXPERIMENTS + MART_TN_LOOP=4): the same product on v_mfma_f32_16x16x32 with the 4-phase loop of
+// gemm_nt.hip (PIPE 4).  Measured (tools/tn_harness, profiles/r05_tn_harness_4phase16.txt): 0.482 / 0.471 / 0.358 / 0.130 ms on the four vision
+// weight-gradient shapes against 0.468 / 0.466 / 0.351 / 0.132 for the 8-phase loop on 32x32x16 -- 1-3 % SLOWER where gemm_nt gained 3-6 %: with
+// two transposed reads per fragment the 32-read segment S1 is longer than the partner's 32-MFMA cluster.  Not shipped.
+//   * half-tiles as above ([64 m][256 B]: Xl Xr Yl Yr), 16-byte-chunk swizzle chunk ^ ((m & 3) << 2) ^ (((m >> 3) & 1) << 1): the two 4 x 16
+//     blocks one 32-lane group of a transposed read covers now sit 8 contraction rows apart (lane group g = l >> 4 holds k = 8 g + 0..7 of a
+//     32-deep k-step), and the extra key bit puts them in different 32-byte halves of a 64-byte bank group (conflict-free).
+//   * per 64-row step and wave two segments of 32 MFMAs:  S1 = [reads X(ih0) + Y | bar | MFMAs | bar],  S2 = [reads X(ih1) | bar | MFMAs | bar];
+//     LDS-DMA (SADDR form) from inside the MFMA clusters: M-S1(t): Xr(t+1);  M-S2(t): Xl, Yl, Yr of step t+2;  counted waits in the READ
+//     segments (end of R-S1: vmcnt(6) -> Xr(t) landed; end of R-S2: vmcnt(2) -> Xl, Yl, Yr of t+1 landed): RAW / WAR argument as in gemm_nt.hip.
+//   * accumulator quads: acc[i][j][4 q ..] = block (nx: ih = i >> 1, 16-column block xb = 2 (i & 1) + j; ny: 16-column block q); lane l holds
+//     ny = l & 15 and nx = 4 (l >> 4) + 0..3 of it.  Slab layout unchanged (fragment-major); tn_reduce4_k decodes this mapping.
+__global__ __launch_bounds__(NT) void gemm_tn4_kernel(Args2 p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int wr = wave >> 2, wq = wave & 3;
+  const int ntile = p.ntile;
+  const int lid = xcd_remap((int)(blockIdx.x + ntile * blockIdx.y), (int)(ntile * gridDim.y));
+  const int tile = lid % ntile, split = lid / ntile;
+  const int tx = tile / p.tiles_y, ty = tile % p.tiles_y;
+  const int nx0 = tx * BNX, ny0 = ty * BNY;
+  const int ms = split * p.rows_per_split;
+  const int me = min(p.M, ms + p.rows_per_split);
+  const int nsteps = (me - ms) / BKM;
+
+  // staging: half-tile = 1024 chunks of 16 B, two per thread: chunk c -> row c >> 4, physical chunk c & 15
+  unsigned srcX[2][2], srcY[2][2];                   // [half][r]: BYTE offset of this thread's chunk at contraction row 0 of a step (< 64 rows * ld * 2)
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int c = r * NT + tid, row = c >> 4, pc = c & 15, lc = pc ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 1);
+      srcX[hf][r] = ((unsigned)row * (unsigned)p.ldx + (unsigned)min(nx0 + hf * 128 + lc * 8, p.ldx - 8)) * 2u;
+      srcY[hf][r] = ((unsigned)row * (unsigned)p.ldy + (unsigned)min(ny0 + hf * 128 + lc * 8, p.ldy - 8)) * 2u;
+    }
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)LDS_PTR(smem) + wave * 1024;
+  auto dma = [&](unsigned lds, unsigned voff, const void* sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory");
+  };
+  auto issueX = [&](int t, auto HALF) {
+    constexpr int hf = decltype(HALF)::value;
+    const char* base = (const char*)(p.X + (long long)(ms + t * BKM) * p.ldx);
+    const unsigned l = lds0 + (t & 1) * STAGE + hf * HALF_BYTES;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) dma(l + r * NT * 16, srcX[hf][r], base);
+  };
+  auto issueY = [&](int t, auto HALF) {
+    constexpr int hf = decltype(HALF)::value;
+    const char* base = (const char*)(p.Y + (long long)(ms + t * BKM) * p.ldy);
+    const unsigned l = lds0 + (t & 1) * STAGE + X_BYTES + hf * HALF_BYTES;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) dma(l + r * NT * 16, srcY[hf][r], base);
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; }
+  float cs[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  const bool do_colsum = p.colsum && ty == 0;
+
+  // transposed fragment: 16 columns starting at col0 (inside the half-tile), contraction rows 32 kk + 8 g4 + {0..7}
+  const int prow = l15 >> 2;
+  const int fo = (prow * 256) + ((l15 & 3) & 1) * 8;          // row part + byte inside the 16-byte chunk
+  auto frag = [&](const char* half, int col0, int kk) -> bf16x8 {
+    const int r0 = kk * 32 + 8 * g4;                           // (+ prow, + 4): (row & 3) = prow, (row >> 3) & 1 = g4 & 1
+    const int chunk = ((col0 >> 3) + ((l15 & 3) >> 1)) ^ (prow << 2) ^ ((g4 & 1) << 1);
+    const char* a = half + r0 * 256 + fo + (chunk << 4);
+    s16x4 lo = lds_tr_read(a);
+    s16x4 hi = lds_tr_read(a + 4 * 256);
+    return join_tr(lo, hi);
+  };
+  bf16x8 xf[4][2], yf[4][2];                         // [16-column block][k-step]
+  auto readX = [&](const char* st, auto IH) {
+    constexpr int ih = decltype(IH)::value;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int xb = 0; xb < 4; ++xb) xf[xb][kk] = frag(st + ih * HALF_BYTES, wr * 64 + xb * 16, kk);
+  };
+  auto readXY = [&](const char* st) {                // S1: k-step 0 of Y and X first (the order the MFMAs consume them in)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int yb = 0; yb < 4; ++yb) yf[yb][kk] = frag(st + X_BYTES + (wq >> 1) * HALF_BYTES, (wq & 1) * 64 + yb * 16, kk);
+#pragma unroll
+      for (int xb = 0; xb < 4; ++xb) xf[xb][kk] = frag(st, wr * 64 + xb * 16, kk);
+    }
+  };
+  // bias gradients: wave column wq sums k-step wq >> 1 of the blocks xb = (wq & 1), (wq & 1) + 2 -- fragments the MFMAs consume anyway.  One
+  // literal-index arm per wave column (a loop over "if (wq == ...)" made the compiler index xf[][] through scratch, whose loads and stores
+  // then drained the LDS-DMA queue every step: 3.4 x slower)
+  auto colsum_arm = [&](auto IH, auto KK, auto PAR) {
+    constexpr int ih = decltype(IH)::value, kk = decltype(KK)::value, par = decltype(PAR)::value;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      u32x4 w = __builtin_bit_cast(u32x4, xf[par + 2 * u][kk]);
+      asm volatile("" : "+v"(w));                      // (a register copy: keeps the fragment array out of memory)
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0 += __builtin_bit_cast(float, w[e] << 16);
+        s1 += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+      }
+      cs[ih][u] += s0 + s1;
+    }
+  };
+  auto colsum_step = [&](auto IH) {
+    using J0 = std::integral_constant<int, 0>;
+    using J1 = std::integral_constant<int, 1>;
+    if (do_colsum) {
+      if (wq == 0) colsum_arm(IH, J0{}, J0{});
+      else if (wq == 1) colsum_arm(IH, J0{}, J1{});
+      else if (wq == 2) colsum_arm(IH, J1{}, J0{});
+      else colsum_arm(IH, J1{}, J1{});
+    }
+  };
+  auto mma = [&](auto IH, auto&& d0, auto&& d1, auto&& d2) {
+    constexpr int ih = decltype(IH)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int xb = 0; xb < 4; ++xb) {
+        f32x16& C = acc[2 * ih + (xb >> 1)][xb & 1];
+#pragma unroll
+        for (int yb = 0; yb < 4; ++yb) {
+          f32x4 c = {C[4 * yb], C[4 * yb + 1], C[4 * yb + 2], C[4 * yb + 3]};
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[xb][kk], yf[yb][kk], c, 0, 0, 0);
+          C[4 * yb] = c[0]; C[4 * yb + 1] = c[1]; C[4 * yb + 2] = c[2]; C[4 * yb + 3] = c[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk == 0 && xb == 0) d0();
+        if (kk == 0 && xb == 1) d1();
+        if (kk == 0 && xb == 2) d2();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto lgkm0 = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto nop = [] {};
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // prologue: step 0 complete; Xl, Yl, Yr of step 1 in flight (Xr(1) comes from M-S1(0))
+  issueX(0, I0{}); issueY(0, I0{}); issueY(0, I1{}); issueX(0, I1{});
+  if (nsteps > 1) {
+    issueX(1, I0{}); issueY(1, I0{}); issueY(1, I1{});
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  bar();
+  if (wr == 1) bar();                                 // the lower wave-row runs one barrier behind
+  for (int t = 0; t < nsteps; ++t) {
+    const char* st = smem + (t & 1) * STAGE;
+    const bool more1 = t + 1 < nsteps, more2 = t + 2 < nsteps;
+    // R-S1
+    readXY(st);
+    if (more1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    lgkm0();
+    mma(I0{}, [&] { if (more1) issueX(t + 1, I1{}); }, nop, nop);
+    colsum_step(I0{});
+    bar();
+    // R-S2
+    readX(st, I1{});
+    if (more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    lgkm0();
+    mma(I1{}, [&] { if (more2) issueX(t + 2, I0{}); }, [&] { if (more2) issueY(t + 2, I0{}); }, [&] { if (more2) issueY(t + 2, I1{}); });
+    colsum_step(I1{});
+    bar();
+  }
+  if (wr == 0) bar();                                 // balance the barrier count
+
+  // ---- partial tile -> workspace slab, fragment-major (same index as gemm_tn8_kernel; the quads mean different elements: see tn_reduce4_k)
+  float* slab = p.ws + ((long long)split * ntile + tile) * SLAB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(slab + ((((wave * 4 + i) * 2 + j) * 4 + q) * 64 + lane) * 4) =
+            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+  if (do_colsum) {                                   // workgroup-uniform
+    __syncthreads();                                 // K-loop buffers are free
+    float* red = (float*)smem;                       // [2 k-steps][256 nx]: wave column wq holds k-step wq >> 1 of the blocks xb = (wq & 1) + 2 u
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float tot = cs[ih][u];
+        tot += __shfl_xor(tot, 16);
+        tot += __shfl_xor(tot, 32);
+        if (g4 == 0) red[(wq >> 1) * BNX + ih * 128 + wr * 64 + ((wq & 1) + 2 * u) * 16 + l15] = tot;
+      }
+    __syncthreads();
+    if (tid < BNX) p.ws_col[((long long)split * (ntile / p.tiles_y) + tx) * BNX + tid] = red[tid] + red[BNX + tid];
+  }
+}
+
+#endif  // MART_EXPERIMENTS
+
 // out[nx][ny] += alpha * sum_{split} slab[split][tile](nx, ny), splits in order; colsum likewise.  One thread = one register quad
 // of one fragment (4 consecutive nx at one ny); the 32 lanes of a half-wave cover 32 consecutive ny (128-byte segments).
+template <bool M16>                                  // M16: the slabs were written by gemm_tn4_kernel (16x16x32 quads)
 __global__ __launch_bounds__(256) void tn_reduce_k(Args2 p) {
   const int ntile = p.ntile, tiles_x = ntile / p.tiles_y;
   const int nblk_tiles = ntile * (SLAB / 4 / 256);
@@ -417,8 +637,9 @@ __global__ __launch_bounds__(256) void tn_reduce_k(Args2 p) {
   const float* src = p.ws + (long long)tile * SLAB + (long long)qi * 4;
   for (int s = 0; s < p.splits; ++s) tot += *(const f32x4*)(src + (long long)s * ntile * SLAB);
   const int tx = tile / p.tiles_y, ty = tile % p.tiles_y;
-  const int ny = ty * BNY + wq * 64 + j * 32 + l31;
-  const int nxb = tx * BNX + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + 8 * q + 4 * h;
+  const int ny = M16 ? ty * BNY + wq * 64 + q * 16 + (lane & 15) : ty * BNY + wq * 64 + j * 32 + l31;
+  const int nxb = M16 ? tx * BNX + (i >> 1) * 128 + wr * 64 + (2 * (i & 1) + j) * 16 + 4 * (lane >> 4)
+                      : tx * BNX + (i >> 1) * 128 + wr * 64 + (i & 1) * 32 + 8 * q + 4 * h;
   if (ny >= p.NY) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -491,21 +712,36 @@ extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
       static MartAttrOnce once8;
       bool* set8 = once8.slot();
       if (!*set8) {
-        if (hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess
+#ifdef MART_EXPERIMENTS
+            || hipFuncSetAttribute((const void*)gemm_tn4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess
+#endif
+        ) {
           mart_set_error("gemm_tn: hipFuncSetAttribute failed");
           return -2;
         }
         *set8 = true;
       }
+#ifdef MART_EXPERIMENTS
+      static const int loop_env = getenv("MART_TN_LOOP") ? atoi(getenv("MART_TN_LOOP")) : 8;
+      const bool loop4 = loop_env == 4 && (long long)64 * a.ldx * 2 < (1LL << 31) && (long long)64 * a.ldy * 2 < (1LL << 31);
+#else
+      constexpr bool loop4 = false;
+#endif
       Args2 b;
       b.X = a.X; b.Y = a.Y; b.ldx = a.ldx; b.ldy = a.ldy; b.M = Mmain; b.NX = a.NX; b.NY = a.NY; b.out = a.out; b.ldo = a.ldo;
       b.out_rows = a.out_rows; b.colsum = a.colsum; b.colsum_by_row = a.colsum_by_row; b.splits = sp; b.rows_per_split = r;
       b.tiles_y = tiles_y; b.ntile = tiles; b.alpha = a.alpha;
       b.ws = (float*)d->workspace; b.ws_col = b.ws + (size_t)sp * tiles * SLAB;
+#ifdef MART_EXPERIMENTS
+      if (loop4) hipLaunchKernelGGL(gemm_tn4_kernel, dim3(tiles, sp, 1), dim3(NT), LDS, (hipStream_t)stream, b);
+      else
+#endif
       hipLaunchKernelGGL(gemm_tn8_kernel, dim3(tiles, sp, 1), dim3(NT), LDS, (hipStream_t)stream, b);
       MART_LAUNCH_CHECK();
       const int nblk = tiles * (SLAB / 4 / 256) + (d->colsum ? (tiles_x * BNX + 255) / 256 : 0);
-      hipLaunchKernelGGL(tn_reduce_k, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b);
+      if (loop4) hipLaunchKernelGGL(tn_reduce_k<true>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b);
+      else hipLaunchKernelGGL(tn_reduce_k<false>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, b);
       MART_LAUNCH_CHECK();
     }
     if (d->M > Mmain) {
