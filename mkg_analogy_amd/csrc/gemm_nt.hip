@@ -50,6 +50,19 @@ template <typename T> __device__ __forceinline__ T ld_stream(const T* p) {
 #define NT_DBG(p) 0
 #endif
 
+#ifdef MART_EXPERIMENTS
+// cycle stamps of ONE workgroup (tile_cfg 2567; tools/nt_harness stamp): [wave][0 loop start, 1 loop end, 2 epilogue start, 3..6 after block 0..3, 7 end]
+__device__ unsigned long long g_nt_stamps[8 * 8];
+__device__ __forceinline__ unsigned long long nt_memtime() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define NT_STAMP(k) do { if ((NT_DBG(p) & 8) && (int)blockIdx.x == 300 && lane == 0) g_nt_stamps[wave * 8 + (k)] = nt_memtime(); } while (0)
+#else
+#define NT_STAMP(k) do { } while (0)
+#endif
+
 struct Args {
   const bf16* A; const bf16* B; const bf16* A2; const bf16* B2;
   int lda, ldb;
@@ -541,6 +554,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
     }
     bar();
     if (grp == 1) bar();                                   // the lower wave-row runs one barrier behind
+    NT_STAMP(0);
     for (int t = 0; t < nk; ++t) {
       const char* sT = smem + (t & 1) * STAGE;
       const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
@@ -563,6 +577,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
       bar();
     }
     if (grp == 0) bar();                                   // balance the barrier count
+    NT_STAMP(1);
   } else if constexpr (WAVES_M == 2 && WAVES_N == 4) {
     // ---- ping-pong main loop (8 waves).  The two wave-rows of the tile (waves 0-3 / 4-7; waves w and w+4 share a
     // SIMD) run the same 4-phase K-tile sequence  R0 | M0 | R1 | M1  (R = fragment reads of two k-steps (+ LDS-DMA
@@ -657,6 +672,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
   constexpr int LPR = WN / 4, RPI = 64 / LPR;                    // lanes per row, rows per wave-instruction
   constexpr int NIT = 32 / RPI;
   __syncthreads();                                               // every wave is done with the K-loop buffers
+  NT_STAMP(2);
   const int em0 = m0, en0 = n0;                                  // the tile being written out
   bool more = false;
   if constexpr (PERSIST) {
@@ -776,12 +792,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
     };
-    block(0, acc[0]);
-    if constexpr (TM > 1) block(1, acc[1]);
-    if constexpr (TM > 2) block(2, acc[2]);
-    if constexpr (TM > 3) block(3, acc[3]);
+    block(0, acc[0]); NT_STAMP(3);
+    if constexpr (TM > 1) { block(1, acc[1]); NT_STAMP(4); }
+    if constexpr (TM > 2) { block(2, acc[2]); NT_STAMP(5); }
+    if constexpr (TM > 3) { block(3, acc[3]); NT_STAMP(6); }
     };
     if (mrem >= ro(TM - 1) + 32) run(std::false_type{}); else run(std::true_type{});
+    NT_STAMP(7);
   } else if constexpr (EPI >= 0) {
     // ---- fast lane: full-width tiles, 16-byte aligned rows (checked by the host dispatcher).  The streamed operands of a
     // 32-row block (fp32 residual, z of the activation derivative) are fetched BEFORE the LDS round trip of the
@@ -872,15 +889,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
       if constexpr (NPRE > 1) fetch(1);
       if constexpr (NPRE > 2) fetch(2);
       if constexpr (NPRE > 3) fetch(3);
-      block(0, acc[0]);
+      block(0, acc[0]); NT_STAMP(3);
       if constexpr (NPRE < TM) fetch(NPRE);                        // refill the slot block 0 just freed
-      if constexpr (TM > 1) block(1, acc[1]);
+      if constexpr (TM > 1) { block(1, acc[1]); NT_STAMP(4); }
       if constexpr (NPRE + 1 < TM) fetch(NPRE + 1);
-      if constexpr (TM > 2) block(2, acc[2]);
+      if constexpr (TM > 2) { block(2, acc[2]); NT_STAMP(5); }
       if constexpr (NPRE + 2 < TM) fetch(NPRE + 2);
-      if constexpr (TM > 3) block(3, acc[3]);
+      if constexpr (TM > 3) { block(3, acc[3]); NT_STAMP(6); }
     };
     if (em0 + wm0 + ro(TM - 1) + 32 <= p.M) run(std::false_type{}); else run(std::true_type{});
+    NT_STAMP(7);
     static_assert(TM <= 4, "epilogue blocks are written out for TM <= 4");
   } else {
   // ---- general lane: lane owns row m, 4 consecutive n per register quad
@@ -1033,6 +1051,12 @@ int launch(const Args& a, int batch, hipStream_t st) {
 
 }  // namespace
 
+#ifdef MART_EXPERIMENTS
+extern "C" int mart_debug_nt_stamps(unsigned long long* host_out) {        // 8 waves x 8 stamps of the last tile_cfg 2567 launch
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   MART_CHECK(d != nullptr, "gemm_nt: null descriptor");
   MART_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: M,N,K must be positive");
@@ -1089,7 +1113,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (cfg == 2563 || cfg == 2564) { old_loop = true; cfg = cfg == 2563 ? 256 : 2561; }
   if (cfg == 2562) cfg = 256;                       // 2562: fast epilogue without the persistent loop (A/B)
   if (cfg == 2565 || cfg == 2566) { loop8 = true; cfg = cfg == 2565 ? 256 : 2561; }   // the 8-phase loop, fast / general epilogue (A/B against the 4-phase loop)
-  if (a.dbg) loop8 = true;                          // the knock-out experiments are written into the older loops
+  if (cfg == 2567) { a.dbg = 8; cfg = 256; }        // cycle stamps of workgroup 300 (mart_debug_nt_stamps)
+  if (a.dbg & 7) loop8 = true;                      // the knock-out experiments are written into the older loops
 #endif
   MART_CHECK(!d->b_blocked || cfg == 256, "gemm_nt: b_blocked requires the 256x256 tile");
 #ifdef MART_EXPERIMENTS
@@ -1148,7 +1173,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (aligned && fast_ok) {
     // persistent loop: +6-7 % where the epilogue is light (bf16 out); with the fp32 residual or two bf16 outputs it is
     // neutral at best (re-measured after the epilogue work: fc1 0.571 vs 0.572 ms, step +0.3 %) -> only for the light masks
-    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;
+    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;     // (stamps: one tile per workgroup)
 #ifdef MART_EXPERIMENTS
 #define MART_FAST(M_, K_)                                                                   \
     if (dt == 0 && mask == (M_) && kind == (K_)) {                                                       \

@@ -57,6 +57,8 @@ static void make_desc(mart_gemm_nt_desc& d, const Case& c, const Bufs& b, int ro
   static const int hot = getenv("NT_HOT") ? atoi(getenv("NT_HOT")) : 0;    // timing only (wrong numbers): 1: every A row aliases row 0, 2: B too, so the
   if (hot >= 1) d.lda = 0;                                                   // LDS-DMA stream hits L1 / L2 -- the K loop without memory-side latency
   if (hot >= 2) d.ldb = 0;
+  static const int nobias = getenv("NT_NOBIAS") ? atoi(getenv("NT_NOBIAS")) : 0;     // the data-gradient products of the step carry no bias
+  if (nobias) d.bias = nullptr;
   switch (c.epi) {
     case 0: break;
     case 1: d.c_f32 = 1; d.res_f32 = b.res; break;
@@ -169,6 +171,25 @@ int main(int argc, char** argv) {
       for (int k = 0; k < 2; ++k) std::sort(ms[k].begin(), ms[k].end());
       double m0 = ms[0][ms[0].size() / 2], m1 = ms[1][ms[1].size() / 2];
       printf("time %-40s old %.4f ms (%6.1f TF/s)   new %.4f ms (%6.1f TF/s)   x%.3f\n", c.name, m0, fl / m0 * 1e-9, m1, fl / m1 * 1e-9, m0 / m1);
+    }
+  }
+  if (!strcmp(mode, "stamp")) {
+    // cycle stamps of workgroup 300 (tile_cfg 2567, -DMART_EXPERIMENTS library): K loop and epilogue of one tile, per wave
+    typedef int (*st_t)(unsigned long long*);
+    st_t getst = (st_t)dlsym(RTLD_DEFAULT, "mart_debug_nt_stamps");
+    if (!getst) { printf("library has no mart_debug_nt_stamps (build with -DMART_EXPERIMENTS)\n"); return 1; }
+    for (const Case& c : timing) {
+      mart_gemm_nt_desc d;
+      for (int w = 0; w < 4; ++w) { make_desc(d, c, b, w, 0, 2567); if (mart_gemm_nt(&d, st)) { printf("launch failed: %s\n", mart_last_error()); return 1; } }
+      CK(hipStreamSynchronize(st));
+      unsigned long long hs[64]; if (getst(hs)) { printf("stamp copy failed\n"); return 1; }
+      printf("stamp %-40s (cycles; workgroup 300)\n", c.name);
+      for (int w = 0; w < 8; w += 1) {
+        const unsigned long long* t = hs + w * 8;
+        printf("   wave %d: K loop %6lld (%5.0f / K-tile) | -> epilogue start %5lld | blocks %5lld %5lld %5lld %5lld | tail %4lld | epilogue total %6lld\n", w,
+               (long long)(t[1] - t[0]), (double)(t[1] - t[0]) / ((c.K + c.K2) / 64), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[4] - t[3]),
+               (long long)(t[5] - t[4]), (long long)(t[6] - t[5]), (long long)(t[7] - t[6]), (long long)(t[7] - t[2]));
+      }
     }
   }
   if (!strcmp(mode, "ab")) {
