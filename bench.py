@@ -375,16 +375,20 @@ def main():
         n, fl, kms, by = fam.get("gemm_nt_256", [0, 0.0, 0.0, 0.0])
         n_ov, fl_ov, kms_ov, _ = fam_ov.get("gemm_nt_256", [0, 0.0, 0.0, 0.0])
         ach = fl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-        # HBM traffic of the dominant kernel: PMC passes of this same command (tools/pmc.sh, profiles/r04_pmc_gemm_nt.json).  The file
-        # names the kernel source it was collected on; when gemm_nt.hip has changed since, the number is withheld instead of going stale.
+        # HBM traffic of the dominant kernel: PMC passes of this same command (tools/pmc.sh -> profiles/rNN_pmc_gemm_nt.json, newest round first).
+        # The file names the kernel source it was collected on; when gemm_nt.hip has changed since, the number is withheld instead of going stale.
         traffic, traffic_note = None, "no PMC collection for this configuration"
-        pmc = os.path.join(ROOT, "profiles", "r04_pmc_gemm_nt.json")
-        if os.path.exists(pmc) and a.batch == 256 and a.patch == 16 and a.seq_len == 64 and a.model == "mkgformer" and not pre:
-            pj = json.load(open(pmc))
-            if pj.get("source_sha16") == source_sha16("gemm_nt.hip", "common.h"):
-                traffic, traffic_note = pj.get("hbm_bytes_per_launch"), f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, {pj.get('launches_averaged')} launches (profiles/r04_pmc_gemm_nt.json)"
-            else:
-                traffic_note = "profiles/r04_pmc_gemm_nt.json was collected on an older gemm_nt.hip: withheld"
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_gemm_nt.json")), reverse=True)
+        if pmcs and a.batch == 256 and a.patch == 16 and a.seq_len == 64 and a.model == "mkgformer" and not pre:
+            sha = source_sha16("gemm_nt.hip", "common.h")
+            traffic_note = f"profiles/{os.path.basename(pmcs[0])} was collected on an older gemm_nt.hip: withheld"
+            for pmc in pmcs:
+                pj = json.load(open(pmc))
+                if pj.get("source_sha16") == sha:
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_note = f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, {pj.get('launches_averaged')} launches (profiles/{os.path.basename(pmc)})"
+                    break
 
         def famrow(key, name, bound_tf=2500.0):
             c, f, m, _ = fam.get(key, [0, 0.0, 0.0, 0.0])
@@ -400,7 +404,7 @@ def main():
                               famrow("gemm_nt_128", "gemm_nt_kernel<128,128,2,2> (small products: head, short grids)"),
                               hbmrow("ln_bwd_vision", "ln_bwd_k (vision stream: dy bf16 + x f32 + residual gradient f32 in, f32 + bf16 out)"),
                               hbmrow("ln_fwd_vision", "ln_fwd_k (vision stream: x f32 in, bf16 out)")) if r]
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,256,2,4> (bf16 MFMA 32x32x16 NT GEMM, 8-phase K loop, fused epilogues)", "achieved": round(ach, 1),
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,256,2,4> (bf16 MFMA 16x16x32 NT GEMM, 4-phase K loop, fused epilogues)", "achieved": round(ach, 1),
                 "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": round(by / max(n, 1)), "launches_per_step": n, "ms_per_step": round(kms, 3),
                 "avg_launch_ms": round(kms / max(n, 1), 4), "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 1),

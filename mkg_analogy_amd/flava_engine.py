@@ -61,9 +61,11 @@ def flava_layout_order(nt: int, ni: int, nm: int) -> List[str]:
 
 
 def flava_f16_weight(name: str) -> bool:
-    """GEMM weights of the text and multimodal stacks: the tensors that get an fp16 forward shadow (FlavaEngine.f16, as engine.UnimoEngine.text_f16)."""
-    return (name.startswith(("flava.text_model.encoder.layer.", "flava.multimodal_model.encoder.layer.")) and name.endswith(".weight")
-            and "layernorm" not in name)
+    """GEMM weights of the three encoder stacks: the tensors that get an fp16 forward shadow (FlavaEngine.f16 / .f16_img, as engine.UnimoEngine.text_f16)."""
+    if name in ("flava.image_model.embeddings.patch_embeddings.projection.weight", "flava.image_to_mm_projection.weight", "flava.text_to_mm_projection.weight"):
+        return True
+    return (name.startswith(("flava.text_model.encoder.layer.", "flava.multimodal_model.encoder.layer.", "flava.image_model.encoder.layer."))
+            and name.endswith(".weight") and "layernorm" not in name)
 
 
 def FLAVA_DEAD(nl: Tuple[int, int, int]) -> Tuple[str, ...]:
@@ -103,6 +105,10 @@ class FlavaEngine:
         # the forward linear layers of the TEXT and MULTIMODAL stacks on fp16 operands (same switch and reasoning as engine.UnimoEngine.text_f16:
         # the logits are read off the multimodal stack's text positions; the image stack -- 2/3 of the FLOPs -- stays bf16)
         self.f16 = os.environ.get("MART_TEXT_F16", "1") == "1" and getattr(store, "f16_weight", None) is flava_f16_weight
+        # round 5: the IMAGE stack's forward products on fp16 operands as well (every operand is a LayerNorm output, an attention context or a GELU
+        # output; same MFMA rate, 8 x finer rounding): VERDICT r4 item 7 -- the image stack was the largest remaining term of the bf16 logit error
+        # (G9 / G9b at 7.7e-3 / 8.3e-3 of a 1e-2 budget).  Costs the fp16 twins' writes in a training step (+1.1 GB per layer at B = 256)
+        self.f16_img = self.f16 and os.environ.get("MART_IMAGE_F16", "1") == "1"
 
     # ------------------------------------------------------------------ one pre-LN block
     def _layer_fwd(self, p: str, x, M: int, attn_kw: dict, want_bf16: bool, f16: bool = False):
@@ -186,22 +192,43 @@ class FlavaEngine:
         sv: Dict[str, object] = dict(B=B, L=Lq, P=P, Nv=Nv, Sm=Sm, ids=input_ids, tt=token_type_ids)
         # ---- image embeddings (FlavaImageEmbeddings.forward :308-343): conv(+bias) as GEMM, cls, positions (tail image: pos[:P])
         Kp = 3 * p * p
-        patches = _e((B * 2 * P, Kp), BF, dev)
-        if image_index is not None:
-            ops.patchify_gather(image_table, image_index.contiguous(), patches, B, S, p)
-        else:
-            pix = pixel_values.contiguous()
-            assert pix.dtype == F32 and tuple(pix.shape) == (B, 2, 3, S, S)
-            ops.patchify(pix, patches, B, S, p)
         e = "flava.image_model.embeddings."
-        pe = _e((B * 2 * P, H), BF, dev)
-        ops.gemm_nt(patches, st.w(e + "patch_embeddings.projection.weight").view(H, Kp), pe, bias=st.m(e + "patch_embeddings.projection.bias"))
         xi = _e((Mi, H), F32, dev)
-        ops.vision_assemble(pe, st.m(e + "cls_token"), st.m(e + "position_embeddings"), xi, B, P, H, tail_shift=1)
+        if self.f16:
+            # patch embedding on fp16 operands with an f32 result: the bf16 rounding of the pixel patches and of the embedding itself (2^-9 each) was
+            # the floor of every image tap (G9b: 2.9e-3 after layer 0, the text taps 2-5e-4).  The bf16 copy is the weight gradient's operand.
+            assert st.f16_weight(e + "patch_embeddings.projection.weight")
+            pf = _e((B * 2 * P, Kp), F32, dev)
+            if image_index is not None:
+                ops.patchify_f32(image_table, image_index.contiguous(), pf, B, S, p)
+            else:
+                pix = pixel_values.contiguous()
+                assert pix.dtype == F32 and tuple(pix.shape) == (B, 2, 3, S, S)
+                ops.patchify_f32(pix, None, pf, B, S, p)
+            ph = _e((B * 2 * P, Kp), HF, dev)
+            ops.cast_f32_f16(pf, ph)
+            patches = None
+            if bool(getattr(self, "save_for_backward", True)):
+                patches = _e((B * 2 * P, Kp), BF, dev)
+                ops.cast_f32_bf16(pf, patches)
+            pe32 = _e((B * 2 * P, H), F32, dev)
+            ops.gemm_nt(ph, st.h(e + "patch_embeddings.projection.weight").view(H, Kp), pe32, bias=st.m(e + "patch_embeddings.projection.bias"))
+            ops.vision_assemble_f32(pe32, st.m(e + "cls_token"), st.m(e + "position_embeddings"), xi, B, P, H, tail_shift=1)
+        else:
+            patches = _e((B * 2 * P, Kp), BF, dev)
+            if image_index is not None:
+                ops.patchify_gather(image_table, image_index.contiguous(), patches, B, S, p)
+            else:
+                pix = pixel_values.contiguous()
+                assert pix.dtype == F32 and tuple(pix.shape) == (B, 2, 3, S, S)
+                ops.patchify(pix, patches, B, S, p)
+            pe = _e((B * 2 * P, H), BF, dev)
+            ops.gemm_nt(patches, st.w(e + "patch_embeddings.projection.weight").view(H, Kp), pe, bias=st.m(e + "patch_embeddings.projection.bias"))
+            ops.vision_assemble(pe, st.m(e + "cls_token"), st.m(e + "position_embeddings"), xi, B, P, H, tail_shift=1)
         sv["patches"] = patches
         ikw = dict(B=B, Sq=Nv, Sk=Nv)
         for l in range(self.ni):
-            xi, xib, sv[f"i{l}"] = self._layer_fwd(f"flava.image_model.encoder.layer.{l}.", xi, Mi, ikw, l == self.ni - 1)
+            xi, xib, sv[f"i{l}"] = self._layer_fwd(f"flava.image_model.encoder.layer.{l}.", xi, Mi, ikw, l == self.ni - 1, self.f16_img)
             if self.taps is not None:
                 self.taps[f"i{l}"] = xi.view(B, Nv, H).clone()             # per-layer outputs (tests: golden G9b)
         # ---- text embeddings + stack (FlavaTextEmbeddings :406-438; FLAVA reweight :494-496)
@@ -227,10 +254,21 @@ class FlavaEngine:
         # ---- multimodal input: [cls | image_to_mm(img) | text_to_mm(txt)]  (:1430,1450,1455-1456; cls :1182-1184)
         xm = _e((B, Sm, H), F32, dev)
         xm[:, 0, :].copy_(st.m("flava.multimodal_model.cls_token").view(1, H))
-        ops.gemm_nt(xib, st.w("flava.image_to_mm_projection.weight"), xm[0, 1:], bias=st.m("flava.image_to_mm_projection.bias"),
-                    M=Nv, batch=B, stride_a=Nv * H, stride_c=Sm * H)
-        ops.gemm_nt(xtb, st.w("flava.text_to_mm_projection.weight"), xm[0, 1 + Nv:], bias=st.m("flava.text_to_mm_projection.bias"),
-                    M=Lq, batch=B, stride_a=Lq * H, stride_c=Sm * H)
+        if self.f16:
+            # the projections read the UN-normalised last hidden states: as bf16 copies their 2^-9 rounding was the whole error of the first
+            # multimodal tap (G9b m0: 2.4e-3 with every stack below it at 4-7e-4); fp16 copies + fp16 weight shadows, f32 result as before
+            xih, xth = _e((Mi, H), HF, dev), _e((Mt, H), HF, dev)
+            ops.cast_f32_f16(xi, xih)
+            ops.cast_f32_f16(xt, xth)
+            ops.gemm_nt(xih, st.h("flava.image_to_mm_projection.weight"), xm[0, 1:], bias=st.m("flava.image_to_mm_projection.bias"),
+                        M=Nv, batch=B, stride_a=Nv * H, stride_c=Sm * H)
+            ops.gemm_nt(xth, st.h("flava.text_to_mm_projection.weight"), xm[0, 1 + Nv:], bias=st.m("flava.text_to_mm_projection.bias"),
+                        M=Lq, batch=B, stride_a=Lq * H, stride_c=Sm * H)
+        else:
+            ops.gemm_nt(xib, st.w("flava.image_to_mm_projection.weight"), xm[0, 1:], bias=st.m("flava.image_to_mm_projection.bias"),
+                        M=Nv, batch=B, stride_a=Nv * H, stride_c=Sm * H)
+            ops.gemm_nt(xtb, st.w("flava.text_to_mm_projection.weight"), xm[0, 1 + Nv:], bias=st.m("flava.text_to_mm_projection.bias"),
+                        M=Lq, batch=B, stride_a=Lq * H, stride_c=Sm * H)
         sv["xib"], sv["xtb"] = xib, xtb
         xm = xm.view(Mm, H)
         mkw = dict(B=B, Sq=Sm, Sk=Sm)

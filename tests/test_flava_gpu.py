@@ -56,7 +56,7 @@ def test_flava_forward_backward_vs_oracle():
     e_l = float((ml.detach().float().cpu() - ml_ref.detach()).abs().max())
     scale = max(1.0, float(ml_ref.detach().abs().max()))
     print(f"\nflava: loss hip {float(loss.detach()):.5f} oracle {float(loss_ref.detach()):.5f}; trans rel-L2 {rel_t:.3e}; logits max|err| {e_l:.3e} (scale {scale:.2f})")
-    assert rel_t < 2e-2 and e_l < 1e-2 * scale and abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-2
+    assert rel_t < 4e-3 and e_l < 4e-3 and abs(float(loss.detach()) - float(loss_ref.detach())) < 5e-3       # measured 7.5e-4 / 1.6e-3 / 7e-4
     ev = lit._eval(dict(gb), 0)
     ranks_ref = O.ranks_double_sort(ml_ref.detach(), batch["label"])
     amb = ((ml_ref.detach() - ml_ref.detach()[torch.arange(B), batch["label"]][:, None]).abs() < 2 * e_l).sum(1).numpy() - 1
@@ -161,13 +161,15 @@ def test_flava_vs_reference_at_real_dimensions():
     scale = max(1.0, float(ref_l.abs().max()))
     r_t = float((tr - ref_t).norm() / ref_t.norm())
     print(f"   bf16 path max|dlogit| {e_l:.3e} rms {rms:.3e} (logit scale {scale:.2f}) trans rows rel-L2 {r_t:.3e}   [text + multimodal stacks on fp16 operands: {model.engine.f16}]")
-    f16_0 = model.engine.f16
-    model.engine.f16 = False
+    f16_0, f16i_0 = model.engine.f16, model.engine.f16_img
+    model.engine.f16 = model.engine.f16_img = False
     mlp, _ = forward()
-    model.engine.f16 = f16_0
+    model.engine.f16, model.engine.f16_img = f16_0, f16i_0
     print(f"   MART_TEXT_F16=0 (all three stacks bf16): max|dlogit| {float((mlp - ref_l).abs().max()):.3e} rms {float((mlp - ref_l).pow(2).mean().sqrt()):.3e}")
-    assert r_t < 2e-2
-    assert e_l < 1e-2, f"north_star: bf16 logits within 1e-2 of the reference (FLAVA, text + multimodal stacks on fp16 operands): {e_l:.3e}"
+    # north_star asks for 1e-2; round 5 (fp16 operands in all three stacks, patch embedding and the two multimodal projections on fp16 operands with f32
+    # results: the projections read UN-normalised hidden states, whose bf16 copies were 3/4 of the error) measures 1.6e-3 -- gated at 4e-3
+    assert r_t < 4e-3
+    assert e_l < 4e-3, f"bf16-path logits vs the reference (FLAVA, forward products on fp16 operands): {e_l:.3e}"
     st = model.store
     st.zero_grad()
     loss = lit.training_step(dict(gb), 1)
@@ -185,7 +187,7 @@ def test_flava_vs_reference_at_real_dimensions():
             assert got < 1e-3, (n, got, ref)
             continue
         worst = max(worst, abs(got - ref) / ref)
-        assert abs(got - ref) / ref < 0.10, (n, got, ref)
+        assert abs(got - ref) / ref < 0.02, (n, got, ref)          # measured 0.66 % (round 4 gate: 10 %)
     bad = []
     for k in g:
         if not k.startswith("gs::"):
@@ -266,8 +268,8 @@ def test_flava_b8_per_layer_vs_reference():
     model.engine.taps = None
     e_l, rms = float((ml - ref_l).abs().max()), float((ml - ref_l).pow(2).mean().sqrt())
     print(f"\ng9b flava B=8: bf16 path taps rel-L2 { {k: round(v, 5) for k, v in errs.items()} }\n   logits max|dlogit| {e_l:.3e} rms {rms:.3e}")
-    assert all(v < 1e-2 for v in errs.values()), errs
-    assert e_l < 1e-2, f"north_star: bf16 logits within 1e-2 of the reference (got {e_l:.3e})"
+    assert all(v < 3e-3 for v in errs.values()), errs             # measured 2e-4 ... 8e-4 at every tap of the three stacks (round 4: up to 3.3e-3)
+    assert e_l < 4e-3, f"bf16-path logits vs the reference (measured 1.9e-3; north_star 1e-2): {e_l:.3e}"
     st = model.store
     st.zero_grad()
     loss = lit.training_step(dict(gb), 1)
@@ -285,7 +287,7 @@ def test_flava_b8_per_layer_vs_reference():
             continue
         worst = max(worst, abs(float(st.g(n).double().norm()) - ref) / ref)
     print(f"   loss hip {float(loss.detach()):.5f} reference {float(g['loss']):.5f}; worst gradient-norm deviation {worst:.3e}")
-    assert worst < 0.05
+    assert worst < 0.02                                           # measured 0.57 % (round 4 gate: 5 %)
 
 
 def test_flava_fp32_training_step_vs_reference():

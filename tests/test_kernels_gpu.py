@@ -46,6 +46,38 @@ def test_gemm_nt_plain(ops, M, N, K, cfg):
     close(outb, A.float() @ B.float().t(), 2e-2, 1e-2, "gemm_nt bf16 out")
 
 
+@pytest.mark.parametrize("K,K2", [(64, 0), (192, 0), (64, 64), (128, 192), (832, 0)])
+def test_gemm_nt_4phase_loop_edges(ops, K, K2):
+    """The 4-phase loop of the 256x256 kernel (gemm_nt.hip PIPE 4: 16x16x32 MFMAs, half-tile LDS-DMA two K-tiles ahead, counted waits in the read
+    segments) at the contraction lengths where its prologue / drain paths differ: one, two, three K-tiles, the dual-K switch on the first and in the
+    middle of the ring, an odd tile count -- plain f32 output, the persistent bf16 lane over more tiles than CUs, a row gather on A and the
+    general-epilogue kernel, all against torch and each other (bit-equal where the same loop computes the same sums)."""
+    M, N = 256 * 270 + 33, 768
+    Af, Bf = rnd(M, K + K2, seed=21), rnd(N, K + K2, seed=22, scale=0.06)      # the second operand pair shares the first one's row stride (API contract)
+    A, B = Af[:, :K], Bf[:, :K]
+    A2, B2 = (Af[:, K:], Bf[:, K:]) if K2 else (None, None)
+    ref = A.float() @ B.float().t() + (A2.float() @ B2.float().t() if K2 else 0.0)
+    bias = rnd(N, seed=25, dtype=F32)
+    kw = dict(A2=A2, B2=B2) if K2 else {}
+    of = torch.empty(M, N, device=DEV, dtype=F32)
+    ops.gemm_nt(A, B, of, bias=bias, tile_cfg=256, **kw)
+    close(of, ref + bias, 2e-3, 2e-3, "4-phase f32")
+    ob, og = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, B, ob, bias=bias, tile_cfg=256, **kw)                  # persistent bf16 lane (813 tiles on 256 CUs)
+    ops.gemm_nt(A, B, og, bias=bias, tile_cfg=2561, **kw)                 # general epilogue, same loop
+    assert torch.equal(ob, og)
+    assert torch.equal(ob, (of).to(BF))                                   # the f32 lane rounds the same sums
+    for _ in range(3):                                                    # run-to-run identical (a race in the ring would show up here first)
+        o2 = torch.empty_like(ob)
+        ops.gemm_nt(A, B, o2, bias=bias, tile_cfg=256, **kw)
+        assert torch.equal(ob, o2)
+    if not K2:
+        rows = torch.randperm(M, device=DEV)[:1000].to(torch.int32).contiguous()
+        ogat = torch.empty(1000, N, device=DEV, dtype=F32)
+        ops.gemm_nt(A, B, ogat, a_rows=rows, M=1000, tile_cfg=256)
+        assert torch.equal(ogat + bias, of[rows.long()]) or float((ogat + bias - of[rows.long()]).abs().max()) < 1e-5
+
+
 def test_gemm_nt_asymmetric_identity(ops):
     """A = I against an asymmetric B catches a transposed / permuted C write."""
     K = 128

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Evidence of a round's final state, one gpurun call: the bench line, rocprofv3 kernel-trace summaries (serial + shipped schedule), PMC passes of the
 # dominant kernel (-> roofline.traffic), the other BASELINE configurations.  Everything lands in gpurun_out/; what is judged is copied to profiles/.
-# usage: bash tools/profile_round.sh r04
+# usage: bash tools/profile_round.sh r05
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 for mode in serial overlap; do
   if [ $mode = serial ]; then export MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0; else export MART_OVERLAP_WGRAD=1 MART_TWO_STREAM=1; fi
@@ -39,7 +39,8 @@ run head2063 --entity-head 2063
 run pretrain --task pretrain --seq-len 96
 run pretrain_p49 --task pretrain --seq-len 96 --patch 32
 run flava --model flava --batch 128
-run cond --weights conditioned
+run plain --weights plain
+timeout 300 python tools/step_boundary.py 20 > gpurun_out/${TAG}_step_boundary.txt 2>&1
 python - <<PY
 import json
 d = json.load(open("gpurun_out/${TAG}_bench.json"))
