@@ -52,13 +52,13 @@ template <typename T> __device__ __forceinline__ T ld_stream(const T* p) {
 
 #ifdef MART_EXPERIMENTS
 // cycle stamps of ONE workgroup (tile_cfg 2567; tools/nt_harness stamp): [wave][0 loop start, 1 loop end, 2 epilogue start, 3..6 after block 0..3, 7 end]
-__device__ unsigned long long g_nt_stamps[8 * 8];
+__device__ unsigned long long g_nt_stamps[3 * 8 * 9];        // [tile iteration of the workgroup (persistent loop), < 3][wave][stamp]; stamp 8 = kernel entry / tile start
 __device__ __forceinline__ unsigned long long nt_memtime() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   return t;
 }
-#define NT_STAMP(k) do { if ((NT_DBG(p) & 8) && (int)blockIdx.x == 300 && lane == 0) g_nt_stamps[wave * 8 + (k)] = nt_memtime(); } while (0)
+#define NT_STAMP(k) do { if ((NT_DBG(p) & 8) && (int)blockIdx.x == 200 && lane == 0 && nt_tile_it < 3) g_nt_stamps[(nt_tile_it * 8 + wave) * 9 + (k)] = nt_memtime(); } while (0)
 #else
 #define NT_STAMP(k) do { } while (0)
 #endif
@@ -237,7 +237,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
   for (int j = 0; j < TN; ++j) rowB[j] = wn0 + j * 32 + l31;
 
   bool have0 = false;                  // K-tile 0 of the current tile is already in flight (persistent variant)
+#ifdef MART_EXPERIMENTS
+  int nt_tile_it = 0;
+#endif
   for (;;) {
+  NT_STAMP(8);
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -1016,6 +1020,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
   }
   if (!more) break;
   have0 = true;
+#ifdef MART_EXPERIMENTS
+  ++nt_tile_it;
+#endif
   }   // tile loop
 }
 
@@ -1053,7 +1060,7 @@ int launch(const Args& a, int batch, hipStream_t st) {
 
 #ifdef MART_EXPERIMENTS
 extern "C" int mart_debug_nt_stamps(unsigned long long* host_out) {        // 8 waves x 8 stamps of the last tile_cfg 2567 launch
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 3 * 8 * 9) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -1113,7 +1120,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (cfg == 2563 || cfg == 2564) { old_loop = true; cfg = cfg == 2563 ? 256 : 2561; }
   if (cfg == 2562) cfg = 256;                       // 2562: fast epilogue without the persistent loop (A/B)
   if (cfg == 2565 || cfg == 2566) { loop8 = true; cfg = cfg == 2565 ? 256 : 2561; }   // the 8-phase loop, fast / general epilogue (A/B against the 4-phase loop)
-  if (cfg == 2567) { a.dbg = 8; cfg = 256; }        // cycle stamps of workgroup 300 (mart_debug_nt_stamps)
+  bool stamp_persist = false;
+  if (cfg == 2567 || cfg == 2568) { a.dbg = 8; stamp_persist = cfg == 2568; cfg = 256; }   // cycle stamps of workgroup 200 (mart_debug_nt_stamps); 2568: persistent loop where the product uses it
   if (a.dbg & 7) loop8 = true;                      // the knock-out experiments are written into the older loops
 #endif
   MART_CHECK(!d->b_blocked || cfg == 256, "gemm_nt: b_blocked requires the 256x256 tile");
@@ -1173,7 +1181,11 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   if (aligned && fast_ok) {
     // persistent loop: +6-7 % where the epilogue is light (bf16 out); with the fp32 residual or two bf16 outputs it is
     // neutral at best (re-measured after the epilogue work: fc1 0.571 vs 0.572 ms, step +0.3 %) -> only for the light masks
-    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;     // (stamps: one tile per workgroup)
+#ifdef MART_EXPERIMENTS
+    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && (a.dbg == 0 || stamp_persist);
+#else
+    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;
+#endif
 #ifdef MART_EXPERIMENTS
 #define MART_FAST(M_, K_)                                                                   \
     if (dt == 0 && mask == (M_) && kind == (K_)) {                                                       \

@@ -174,22 +174,32 @@ int main(int argc, char** argv) {
     }
   }
   if (!strcmp(mode, "stamp")) {
-    // cycle stamps of workgroup 300 (tile_cfg 2567, -DMART_EXPERIMENTS library): K loop and epilogue of one tile, per wave
+    // cycle stamps of workgroup 200 (tile_cfg 2567: one tile per workgroup; 2568: the persistent loop where the product uses it; -DMART_EXPERIMENTS library)
     typedef int (*st_t)(unsigned long long*);
     st_t getst = (st_t)dlsym(RTLD_DEFAULT, "mart_debug_nt_stamps");
     if (!getst) { printf("library has no mart_debug_nt_stamps (build with -DMART_EXPERIMENTS)\n"); return 1; }
+    const int scfg = argc > 2 ? atoi(argv[2]) : 2567;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Case& c : timing) {
       mart_gemm_nt_desc d;
-      for (int w = 0; w < 4; ++w) { make_desc(d, c, b, w, 0, 2567); if (mart_gemm_nt(&d, st)) { printf("launch failed: %s\n", mart_last_error()); return 1; } }
-      CK(hipStreamSynchronize(st));
-      unsigned long long hs[64]; if (getst(hs)) { printf("stamp copy failed\n"); return 1; }
-      printf("stamp %-40s (cycles; workgroup 300)\n", c.name);
-      for (int w = 0; w < 8; w += 1) {
-        const unsigned long long* t = hs + w * 8;
-        printf("   wave %d: K loop %6lld (%5.0f / K-tile) | -> epilogue start %5lld | blocks %5lld %5lld %5lld %5lld | tail %4lld | epilogue total %6lld\n", w,
-               (long long)(t[1] - t[0]), (double)(t[1] - t[0]) / ((c.K + c.K2) / 64), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[4] - t[3]),
-               (long long)(t[5] - t[4]), (long long)(t[6] - t[5]), (long long)(t[7] - t[6]), (long long)(t[7] - t[2]));
-      }
+      for (int w = 0; w < 3; ++w) { make_desc(d, c, b, w, 0, scfg); if (mart_gemm_nt(&d, st)) { printf("launch failed: %s\n", mart_last_error()); return 1; } }
+      CK(hipEventRecord(e0, st));
+      make_desc(d, c, b, 3, 0, scfg); if (mart_gemm_nt(&d, st)) return 1;
+      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      unsigned long long hs[3 * 8 * 9]; if (getst(hs)) { printf("stamp copy failed\n"); return 1; }
+      const int tiles = ((c.M + 255) / 256) * ((c.N + 255) / 256);
+      printf("stamp %-40s cfg %d: launch %.4f ms, %d tiles = %.2f rounds -> %.0f ns per tile-round (cycles below; workgroup 200)\n", c.name, scfg, ms, tiles, tiles / 256.0, ms * 1e6 / (tiles / 256.0));
+      for (int it = 0; it < (scfg == 2568 ? 3 : 1); ++it)
+        for (int w = 0; w < 8; w += 4) {
+          const unsigned long long* t = hs + (it * 8 + w) * 9;
+          if (!t[1]) continue;
+          printf("   tile %d wave %d: entry -> loop start %6lld | K loop %6lld (%5.0f / K-tile) | -> epilogue start %5lld | blocks %5lld %5lld %5lld %5lld | tail %4lld | epilogue %6lld | tile total %6lld",
+                 it, w, (long long)(t[0] - t[8]), (long long)(t[1] - t[0]), (double)(t[1] - t[0]) / ((c.K + c.K2) / 64), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]),
+                 (long long)(t[4] - t[3]), (long long)(t[5] - t[4]), (long long)(t[6] - t[5]), (long long)(t[7] - t[6]), (long long)(t[7] - t[2]), (long long)(t[7] - t[8]));
+          if (it > 0) { const unsigned long long* q = hs + ((it - 1) * 8 + w) * 9; printf(" | since previous tile's end %5lld", (long long)(t[8] - q[7])); }
+          printf("\n");
+        }
     }
   }
   if (!strcmp(mode, "ab")) {
