@@ -64,7 +64,7 @@ typedef struct {
   int a_src_rows, b_src_rows;                                     /* with a_rows / b_rows: number of rows of the table the indices point into (the kernel forms 32-bit
                                                                      element offsets row * ld, so src_rows * ld must stay below 2^32; checked when stated, 0 = the caller
                                                                      vouches for it).  Without a gather the same check uses M * lda / N * ldb. */
-  int in_f16, c_f16;                                              /* in_f16: A, B (A2, B2) hold IEEE fp16 instead of bf16 (v_mfma_f32_32x32x16_f16, same rate, 11-bit
+  int in_f16, c_f16;                                              /* in_f16: A, B (A2, B2) hold IEEE fp16 instead of bf16 (v_mfma_f32_16x16x32_f16 / 32x32x16_f16, same rate, 11-bit
                                                                      significands): the forward linear layers of the text stream.  c_f16 (needs in_f16, 16-bit C): C is
                                                                      written as fp16 and C2, when given, is its bf16 copy (what the backward pass reads).  preact stays bf16. */
   int c_split3;                                                   /* C is bf16 [M, >= 3N]: the f32 result (after bias / activation) as the two-term split [hi | lo | hi]
