@@ -409,6 +409,7 @@ __global__ __launch_bounds__(NT) void gemm_tn8_kernel(Args2 p) {
 //     segments (end of R-S1: vmcnt(6) -> Xr(t) landed; end of R-S2: vmcnt(2) -> Xl, Yl, Yr of t+1 landed): RAW / WAR argument as in gemm_nt.hip.
 //   * accumulator quads: acc[i][j][4 q ..] = block (nx: ih = i >> 1, 16-column block xb = 2 (i & 1) + j; ny: 16-column block q); lane l holds
 //     ny = l & 15 and nx = 4 (l >> 4) + 0..3 of it.  Slab layout unchanged (fragment-major); tn_reduce4_k decodes this mapping.
+template <int PH>          // 4: two segments of 32 MFMAs per step (DMA from the clusters); 8: the shipped kernel's four quadrant phases of 16 MFMAs (DMA from the read segments)
 __global__ __launch_bounds__(NT) void gemm_tn4_kernel(Args2 p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -561,9 +562,69 @@ __global__ __launch_bounds__(NT) void gemm_tn4_kernel(Args2 p) {
   }
   bar();
   if (wr == 1) bar();                                 // the lower wave-row runs one barrier behind
+  auto readYj = [&](const char* st, auto J) {          // Y blocks 2 j, 2 j + 1 (the 32 columns of quadrant j)
+    constexpr int j = decltype(J)::value;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int yb = 2 * j; yb < 2 * j + 2; ++yb) yf[yb][kk] = frag(st + X_BYTES + (wq >> 1) * HALF_BYTES, (wq & 1) * 64 + yb * 16, kk);
+  };
+  auto mmaq = [&](auto IH, auto J) {                   // quadrant (ih, j): 4 x 2 blocks x 2 k-steps = 16 MFMAs
+    constexpr int ih = decltype(IH)::value, j = decltype(J)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int xb = 0; xb < 4; ++xb) {
+        f32x16& C = acc[2 * ih + (xb >> 1)][xb & 1];
+#pragma unroll
+        for (int yb = 2 * j; yb < 2 * j + 2; ++yb) {
+          f32x4 c = {C[4 * yb], C[4 * yb + 1], C[4 * yb + 2], C[4 * yb + 3]};
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[xb][kk], yf[yb][kk], c, 0, 0, 0);
+          C[4 * yb] = c[0]; C[4 * yb + 1] = c[1]; C[4 * yb + 2] = c[2]; C[4 * yb + 3] = c[3];
+        }
+      }
+    __builtin_amdgcn_s_setprio(0);
+  };
   for (int t = 0; t < nsteps; ++t) {
     const char* st = smem + (t & 1) * STAGE;
     const bool more1 = t + 1 < nsteps, more2 = t + 2 < nsteps;
+    if constexpr (PH == 8) {
+      // the shipped kernel's schedule (gemm_tn8_kernel) on 16x16x32 fragments
+      readX(st, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      readYj(st, I0{});
+      if (more1) issueX(t + 1, I1{});
+      asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the 16 X reads (issued first) are retired: Xl may be re-staged in P2
+      bar();
+      lgkm0();
+      mmaq(I0{}, I0{});
+      colsum_step(I0{});
+      bar();
+      readYj(st, I1{});
+      if (more2) issueX(t + 2, I0{});
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bar();
+      mmaq(I0{}, I1{});
+      bar();
+      readX(st, I1{});
+      if (more2) issueY(t + 2, I0{});
+      bar();
+      lgkm0();
+      mmaq(I1{}, I1{});
+      colsum_step(I1{});
+      bar();
+      if (more2) {
+        issueY(t + 2, I1{});
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      bar();
+      mmaq(I1{}, I0{});
+      bar();
+      continue;
+    }
     // R-S1
     readXY(st);
     if (more1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -714,7 +775,8 @@ extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
       if (!*set8) {
         if (hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess
 #ifdef MART_EXPERIMENTS
-            || hipFuncSetAttribute((const void*)gemm_tn4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess
+            || hipFuncSetAttribute((const void*)gemm_tn4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess
+            || hipFuncSetAttribute((const void*)gemm_tn4_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess
 #endif
         ) {
           mart_set_error("gemm_tn: hipFuncSetAttribute failed");
@@ -724,7 +786,7 @@ extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
       }
 #ifdef MART_EXPERIMENTS
       static const int loop_env = getenv("MART_TN_LOOP") ? atoi(getenv("MART_TN_LOOP")) : 8;
-      const bool loop4 = loop_env == 4 && (long long)64 * a.ldx * 2 < (1LL << 31) && (long long)64 * a.ldy * 2 < (1LL << 31);
+      const bool loop4 = (loop_env == 4 || loop_env == 816) && (long long)64 * a.ldx * 2 < (1LL << 31) && (long long)64 * a.ldy * 2 < (1LL << 31);   // 816: 8 phases on 16x16x32
 #else
       constexpr bool loop4 = false;
 #endif
@@ -734,7 +796,8 @@ extern "C" int mart_gemm_tn(const mart_gemm_tn_desc* d, void* stream) {
       b.tiles_y = tiles_y; b.ntile = tiles; b.alpha = a.alpha;
       b.ws = (float*)d->workspace; b.ws_col = b.ws + (size_t)sp * tiles * SLAB;
 #ifdef MART_EXPERIMENTS
-      if (loop4) hipLaunchKernelGGL(gemm_tn4_kernel, dim3(tiles, sp, 1), dim3(NT), LDS, (hipStream_t)stream, b);
+      if (loop4 && loop_env == 816) hipLaunchKernelGGL(gemm_tn4_kernel<8>, dim3(tiles, sp, 1), dim3(NT), LDS, (hipStream_t)stream, b);
+      else if (loop4) hipLaunchKernelGGL(gemm_tn4_kernel<4>, dim3(tiles, sp, 1), dim3(NT), LDS, (hipStream_t)stream, b);
       else
 #endif
       hipLaunchKernelGGL(gemm_tn8_kernel, dim3(tiles, sp, 1), dim3(NT), LDS, (hipStream_t)stream, b);
