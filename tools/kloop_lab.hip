@@ -55,7 +55,8 @@ __global__ __launch_bounds__(512, 1) void lab_kernel(P p) {
   const bool stamp_me = STAMP && (int)blockIdx.x == p.stamp_wg;
   const int grp = wave >> 2;
   constexpr bool ILV = (V != 2);
-  constexpr bool M16 = (V == 3 || V == 5);            // v_mfma_f32_16x16x32_bf16: 8 x 4 blocks of 16 x 16 per wave, 64 MFMAs of 16 cycles per K-tile
+  constexpr bool M16 = (V == 3 || V == 5 || V == 6);            // v_mfma_f32_16x16x32_bf16: 8 x 4 blocks of 16 x 16 per wave, 64 MFMAs of 16 cycles per K-tile
+  constexpr bool RSEG = (V == 6);                     // the LAGGING wave-row issues its LDS-DMA from the read segments (legal for it one segment earlier; its clusters are bare MFMAs)
   constexpr bool FINE = (V == 4 || V == 5);           // no blanket lgkmcnt(0) behind the barrier: the compiler's per-MFMA counted waits only
   auto ro = [](int i) constexpr { return ILV ? (i >> 1) * 128 + (i & 1) * 32 : i * 32; };
   const int wm0 = (wave / 4) * (ILV ? 64 : 128), wn0 = (wave % 4) * 64;
@@ -274,9 +275,11 @@ __global__ __launch_bounds__(512, 1) void lab_kernel(P p) {
         if constexpr (M16) { readAB16(sA, sB); } else { readA(sA, I0{}); SB(); readB(sB, I0{}); SB(); readB(sB, I1{}); }
         // outstanding here (newest first): Y(t-1) [6 if it was issued] | X(t-1) [2] -> X(t-1) landed.  (t = 0: prologue waited already)
         if (more1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool rs = RSEG && grp == 1;
+        if (rs && more1) issueA(t + 1, I1{});
         ST(0, 0);
         bar(); if constexpr (!FINE) lgkm0(); ST(0, 1);
-        if constexpr (M16) mma32x(I0{}, [&] { if (more1) issueA(t + 1, I1{}); }, nop, nop);
+        if constexpr (M16) mma32x(I0{}, [&] { if (more1 && !rs) issueA(t + 1, I1{}); }, nop, nop);
         else mma16(I0{}, I0{}, [&] { if (more1) issueA(t + 1, I1{}); }, nop, nop);
         ST(0, 2);
         bar(); ST(0, 3);
@@ -284,9 +287,10 @@ __global__ __launch_bounds__(512, 1) void lab_kernel(P p) {
         if constexpr (M16) readA16(sA, I1{}); else readA(sA, I1{});
         // outstanding: X(t) [2 if issued] | Y(t-1) -> Y(t-1) landed
         if (more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (rs && more2) { issueA(t + 2, I0{}); issueB(t + 2, I0{}); issueB(t + 2, I1{}); }
         ST(1, 0);
         bar(); if constexpr (!FINE) lgkm0(); ST(1, 1);
-        if constexpr (M16) mma32x(I1{}, [&] { if (more2) issueA(t + 2, I0{}); }, [&] { if (more2) issueB(t + 2, I0{}); }, [&] { if (more2) issueB(t + 2, I1{}); });
+        if constexpr (M16) mma32x(I1{}, [&] { if (more2 && !rs) issueA(t + 2, I0{}); }, [&] { if (more2 && !rs) issueB(t + 2, I0{}); }, [&] { if (more2 && !rs) issueB(t + 2, I1{}); });
         else mma16(I1{}, I1{}, [&] { if (more2) issueA(t + 2, I0{}); }, [&] { if (more2) issueB(t + 2, I0{}); }, [&] { if (more2) issueB(t + 2, I1{}); });
         ST(1, 2);
         bar(); ST(1, 3);
@@ -486,6 +490,7 @@ int main(int argc, char** argv) {
     {"V3 4-phase 16x16x32", lab_kernel<3, false>, lab_kernel<3, true>, -1},
     {"V4 = V1, counted lgkm", lab_kernel<4, false>, lab_kernel<4, true>, 0},
     {"V5 = V3, counted lgkm", lab_kernel<5, false>, lab_kernel<5, true>, 3},
+    {"V6 = V3, row 1 DMA in R", lab_kernel<6, false>, lab_kernel<6, true>, 3},
   };
   const int MV = 256 * 393;
   const size_t maxA = (size_t)MV * 3072;
