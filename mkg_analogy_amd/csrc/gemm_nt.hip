@@ -110,7 +110,9 @@ template <int DT> __device__ __forceinline__ f32x4 mm16(bf16x8 a, bf16x8 b, f32x
   else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
 // LDS-DMA, 16 B per lane, SADDR form: source = 64-bit scalar base + zero-extended 32-bit lane byte offset -- no per-issue vector address
-// arithmetic, and opaque to the compiler's waitcnt insertion (the loop that uses it counts vmcnt itself)
+// arithmetic, and opaque to the compiler's waitcnt insertion (the loop that uses it counts vmcnt itself).  The block overwrites M0 without telling
+// the compiler (hipcc rejects M0 in a clobber list as reserved): nothing else in a kernel that calls this may depend on M0 -- the PIPE 4 instantiations
+// issue no builtin LDS-DMA, no s_movrel, no GWS / interpolation instruction; LDS instructions do not read M0 on gfx9+
 __device__ __forceinline__ void dma16(unsigned lds_wave_base, unsigned voff, const void* sbase) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
 }
