@@ -78,6 +78,25 @@ def test_gemm_nt_4phase_loop_edges(ops, K, K2):
         assert torch.equal(ogat + bias, of[rows.long()]) or float((ogat + bias - of[rows.long()]).abs().max()) < 1e-5
 
 
+def test_gemm_nt_tile_blocked_weights_take_the_8_phase_kernel(ops):
+    """b_blocked (weights stored as contiguous 256 x 64 blocks, mart_block_table) is served by the 8-phase loop's general-epilogue kernel -- the only
+    product path that still runs it (the other one: operands beyond 2^31 elements): same product as the row-major call on the 4-phase loop, to the
+    rounding of a different summation order, with bias + f32 residual + bf16 copy through the general epilogue."""
+    M, N, K = 2000, 768, 768
+    A, W = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=0.05)
+    Wb = torch.empty_like(W)
+    table = torch.tensor([[0, 0, N, K]], dtype=torch.int64, device=DEV)
+    ops.block_table(W, Wb, table, 1)
+    assert torch.equal(Wb.view(-1), W.view(N // 256, 256, K // 64, 64).permute(0, 2, 1, 3).contiguous().view(-1))
+    bias, res = rnd(N, seed=33, dtype=F32), rnd(M, N, seed=34, dtype=F32)
+    o0, o1 = torch.empty(M, N, device=DEV, dtype=F32), torch.empty(M, N, device=DEV, dtype=F32)
+    c0, c1 = torch.empty(M, N, device=DEV, dtype=BF), torch.empty(M, N, device=DEV, dtype=BF)
+    ops.gemm_nt(A, W, o0, bias=bias, res_f32=res, C2=c0, tile_cfg=256)
+    ops.gemm_nt(A, Wb.view(N, K), o1, bias=bias, res_f32=res, C2=c1, tile_cfg=256, b_blocked=True)
+    close(o1, A.float() @ W.float().t() + bias + res, 2e-3, 2e-3, "blocked weights")
+    assert float((o0 - o1).abs().max()) < 1e-4 and float((c0.float() - c1.float()).abs().max()) < 2e-2
+
+
 def test_gemm_nt_asymmetric_identity(ops):
     """A = I against an asymmetric B catches a transposed / permuted C write."""
     K = 128
