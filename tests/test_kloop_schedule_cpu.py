@@ -1,0 +1,156 @@
+"""The synchronisation argument of gemm_nt's 4-phase K loop (csrc/gemm_nt.hip, PIPE 4), checked by simulation on the CPU.
+
+The loop keeps LDS-DMA half-tiles in flight across barriers behind COUNTED ``s_waitcnt vmcnt(n)`` waits; nothing but the issuing wave's wait
+plus a barrier orders a ``ds_read`` behind a DMA, and nothing but retired reads plus a barrier orders a DMA behind a ``ds_read``.  The two
+wave-rows run one barrier apart, so "before" has to hold for the slower row as well.  This file replays the per-wave instruction order of the
+kernel (same issue points, same counts) for both wave-rows and asserts, for every contraction length:
+
+* RAW -- a half-tile is read in barrier interval g only if EVERY wave-row retired its own share of that half-tile's DMA by a wait it executed
+  in an interval < g (i.e. before a barrier that precedes the read);
+* WAR -- a half-tile buffer is re-staged in interval g only if every wave-row's reads of the previous occupant retired (``lgkmcnt(0)`` right
+  behind the barrier that ends the reading interval) at least one full interval earlier;
+* every read sees the K-tile it expects.
+
+The 8-phase loop of rounds 2-4 (kept for tile-blocked weights) is replayed too: the checker flags its one-barrier-short wait for the lagging
+wave-row -- the finding that moved the waits of the new loop into the read segments."""
+from collections import deque
+
+import pytest
+
+HALVES = ("A0", "A1", "B0", "B1")
+
+
+class Row:
+    """One wave-row (its four waves execute the same stream): outstanding DMA queue with in-order retirement."""
+
+    def __init__(self, lag):
+        self.lag = lag                      # barrier intervals this row runs behind the leading one
+        self.q = deque()                    # outstanding (half, ktile), oldest first; one entry = the two instructions of a half-tile
+        self.retired_at = {}                # (half, ktile) -> interval in which the covering wait was executed
+        self.issued_at = {}                 # (half, ktile) -> interval of the issue
+        self.reads = []                     # (half, ktile, interval)
+
+    def issue(self, half, k, g):
+        self.q.append((half, k))
+        self.issued_at[(half, k)] = g
+
+    def wait(self, n_instr, g):             # s_waitcnt vmcnt(n): everything but the newest n INSTRUCTIONS (2 per half-tile) has landed
+        keep = n_instr // 2
+        while len(self.q) > keep:
+            self.retired_at[self.q.popleft()] = g
+
+    def read(self, half, k, g):
+        self.reads.append((half, k, g))
+
+
+def four_phase(nk):
+    """gemm_nt.hip PIPE 4: per K-tile  R-S1 | M-S1 | R-S2 | M-S2, one barrier between segments; row r runs r intervals behind."""
+    rows = [Row(0), Row(1)]
+    for r in rows:
+        g = 0                                                # prologue interval
+        for h in ("A0", "B0", "B1", "A1"):
+            r.issue(h, 0, g)
+        if nk > 1:
+            for h in ("A0", "B0", "B1"):
+                r.issue(h, 1, g)
+            r.wait(6, g)
+        else:
+            r.wait(0, g)
+        for t in range(nk):
+            more1, more2 = t + 1 < nk, t + 2 < nk
+            g = 1 + 4 * t + r.lag                            # R-S1
+            for h in ("A0", "B0", "B1"):
+                r.read(h, t, g)
+            r.wait(6 if more1 else 0, g)
+            g += 1                                           # M-S1
+            if more1:
+                r.issue("A1", t + 1, g)
+            g += 1                                           # R-S2
+            r.read("A1", t, g)
+            r.wait(2 if more1 else 0, g)
+            g += 1                                           # M-S2
+            if more2:
+                for h in ("A0", "B0", "B1"):
+                    r.issue(h, t + 2, g)
+    return rows
+
+
+def eight_phase(nk):
+    """The round 2-4 loop (PIPE 2): P1 reads A0 + B0/B1(j0) ... ; DMA from the MFMA clusters: P1 A1(t+1), P2 A0(t+2), P3 B0(t+2), P4 B1(t+2) and
+    ONE wait, vmcnt(6), at the end of P4's cluster.  Intervals: 8 per K-tile (read and cluster of each phase)."""
+    rows = [Row(0), Row(1)]
+    for r in rows:
+        g = 0
+        for h in ("A0", "B0", "B1", "A1"):
+            r.issue(h, 0, g)
+        if nk > 1:
+            for h in ("A0", "B0", "B1"):
+                r.issue(h, 1, g)
+            r.wait(6, g)
+        else:
+            r.wait(0, g)
+        for t in range(nk):
+            more1, more2 = t + 1 < nk, t + 2 < nk
+            g = 1 + 8 * t + r.lag                            # P1 read
+            r.read("A0", t, g); r.read("B0", t, g); r.read("B1", t, g)     # (each wave reads one of B0 / B1: both checked)
+            g += 1                                           # P1 cluster
+            if more1:
+                r.issue("A1", t + 1, g)
+            g += 1                                           # P2 read (B j1: same half-tile as j0 for a wave)
+            g += 1                                           # P2 cluster
+            if more2:
+                r.issue("A0", t + 2, g)
+            g += 1                                           # P3 read
+            r.read("A1", t, g)
+            g += 1                                           # P3 cluster
+            if more2:
+                r.issue("B0", t + 2, g)
+            g += 1                                           # P4 (no reads)
+            g += 1                                           # P4 cluster
+            if more2:
+                r.issue("B1", t + 2, g)
+            r.wait(6 if more2 else 0, g)
+    return rows
+
+
+def violations(rows):
+    bad = []
+    for r in rows:
+        for half, k, g in r.reads:
+            for o in rows:                                   # RAW: every row's share retired in an interval before the read's
+                ra = o.retired_at.get((half, k))
+                if ra is None or ra >= g:
+                    bad.append(("RAW", half, k, f"read by row {r.lag} in interval {g}", f"row {o.lag} retired its share in {ra}"))
+    for r in rows:
+        for (half, k), gi in r.issued_at.items():
+            if k < 2:
+                continue
+            for o in rows:                                   # WAR: reads of the previous occupant (k - 2) retire at the START of interval gr + 1
+                for h2, k2, gr in o.reads:
+                    if h2 == half and k2 == k - 2 and gi < gr + 2:
+                        bad.append(("WAR", half, k, f"issued by row {r.lag} in interval {gi}", f"row {o.lag} read {half}({k2}) in {gr}"))
+    return bad
+
+
+@pytest.mark.parametrize("nk", [1, 2, 3, 4, 5, 12, 48])
+def test_four_phase_loop_is_ordered(nk):
+    rows = four_phase(nk)
+    assert violations(rows) == []
+    for r in rows:                                           # every half-tile of every K-tile was read exactly once per row, nothing left in flight
+        assert sorted((h, k) for h, k, _ in r.reads) == sorted((h, k) for k in range(nk) for h in HALVES)
+        assert not r.q
+        # in flight across a barrier: at most three half-tiles (48 KB per CU) behind the counted waits
+    # landing time: every half-tile has at least two full intervals between its issue and the wait that retires it
+    for r in rows:
+        for key, gi in r.issued_at.items():
+            if gi > 0:
+                assert r.retired_at[key] - gi >= 2, (key, gi, r.retired_at[key])
+
+
+@pytest.mark.parametrize("nk", [3, 12])
+def test_the_checker_flags_the_eight_phase_loops_short_wait(nk):
+    bad = violations(eight_phase(nk))
+    raw = [b for b in bad if b[0] == "RAW"]
+    assert raw and all(b[1] in ("A0", "B0", "B1") for b in raw)          # the lagging row waits in the interval in which the leading row already reads
+    assert all("row 0" in b[3] and "row 1" in b[4] for b in raw)
+    assert not [b for b in bad if b[0] == "WAR"]
