@@ -338,9 +338,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
     //   (each issued from inside the phase's MFMA cluster, see mma())
     //   i.e. ONE counted wait per K-tile that leaves the three newest half-tiles (48 KB per CU) in flight across the
     //   barriers and never drains the queue; every half-tile has at least three phases to land.
-    //   RAW: the wait sits at the end of P4's MFMA cluster, before P4's second barrier; K-tile t+1 is first read in P1(t+1), and a
-    //        wave of the other (one barrier apart) wave-row starts those reads only behind a barrier that every wave passed
-    //        after its own wait.
+    //   RAW: the wait sits in front of P4's FIRST barrier (vmcnt(4): B0 / A0 of K-tile t+2 stay in flight, B1(t+2) is issued behind it); K-tile
+    //        t+1 is first read in P1(t+1), two barriers later for the leading wave-row and one for the lagging one: every wave has waited
+    //        before a barrier that precedes the first read by any wave.
     //   WAR: a half-tile is re-staged from the MFMA cluster of the phase AFTER its last read: every reader has retired those reads
     //        (lgkmcnt(0) behind the reading phase's first barrier) at least one barrier before any wave reaches that cluster.
     static_assert(BM == 256 && BN == 256 && WAVES_M == 2 && WAVES_N == 4, "the 8-phase loop is laid out for 256x256 tiles, 2x4 waves");
@@ -449,14 +449,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
       lgkm0();
       mma(I1{}, I1{}, [&] { if (more2) issueB(B_t2, t + 2, I0{}); });
       bar();
-      // P4
+      // P4 (no fragment reads).  The counted wait sits HERE, in front of P4's first barrier (round 5; rounds 2-4 had it at the end of P4's MFMA
+      // cluster, where the lagging wave-row executes it in the same interval in which the leading row already reads K-tile t+1 -- eight phases of
+      // slack, but not ordered: tests/test_kloop_schedule_cpu.py).  Outstanding, newest first: B0(t+2), A0(t+2) | A1(t+1), B1(t+1), ... -> vmcnt(4)
+      // retires K-tile t+1; B1(t+2) is issued behind it from the cluster.  Same sums, bit-identical results.
       const bf16* nA1 = tileA(min(t + 2, nk - 1));
       const bf16* nA2 = tileA(min(t + 3, nk - 1));
       const bf16* nB2 = tileB(min(t + 3, nk - 1));
+      if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       bar();
       mma(I1{}, I0{}, [&] { if (more2) issueB(B_t2, t + 2, I1{}); });
-      if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // everything but the three half-tiles of K-tile t+2: K-tile t+1 has landed
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       A_t1 = nA1; A_t2 = nA2; B_t2 = nB2;
       bar();
     }

@@ -11,8 +11,9 @@ kernel (same issue points, same counts) for both wave-rows and asserts, for ever
   behind the barrier that ends the reading interval) at least one full interval earlier;
 * every read sees the K-tile it expects.
 
-The 8-phase loop of rounds 2-4 (kept for tile-blocked weights) is replayed too: the checker flags its one-barrier-short wait for the lagging
-wave-row -- the finding that moved the waits of the new loop into the read segments."""
+The 8-phase loop (kept for tile-blocked weights and operands beyond 2^31 elements) is replayed too: with the wait where rounds 2-4 had it -- at
+the end of P4's MFMA cluster -- the checker flags a one-barrier-short wait for the lagging wave-row (the finding that put the new loop's waits into
+its read segments); with the wait in front of P4's first barrier (round 5) it is ordered as well."""
 from collections import deque
 
 import pytest
@@ -75,9 +76,10 @@ def four_phase(nk):
     return rows
 
 
-def eight_phase(nk):
-    """The round 2-4 loop (PIPE 2): P1 reads A0 + B0/B1(j0) ... ; DMA from the MFMA clusters: P1 A1(t+1), P2 A0(t+2), P3 B0(t+2), P4 B1(t+2) and
-    ONE wait, vmcnt(6), at the end of P4's cluster.  Intervals: 8 per K-tile (read and cluster of each phase)."""
+def eight_phase(nk, fixed):
+    """The 8-phase loop (PIPE 2): P1 reads A0 + B0/B1(j0) ... ; DMA from the MFMA clusters: P1 A1(t+1), P2 A0(t+2), P3 B0(t+2), P4 B1(t+2) and
+    ONE wait per K-tile -- rounds 2-4: vmcnt(6) at the end of P4's cluster; ``fixed`` (round 5): vmcnt(4) in front of P4's first barrier.
+    Intervals: 8 per K-tile (read and cluster of each phase)."""
     rows = [Row(0), Row(1)]
     for r in rows:
         g = 0
@@ -96,7 +98,8 @@ def eight_phase(nk):
             g += 1                                           # P1 cluster
             if more1:
                 r.issue("A1", t + 1, g)
-            g += 1                                           # P2 read (B j1: same half-tile as j0 for a wave)
+            g += 1                                           # P2 read: the second 32 columns of the wave's B half-tile
+            r.read("B0", t, g); r.read("B1", t, g)
             g += 1                                           # P2 cluster
             if more2:
                 r.issue("A0", t + 2, g)
@@ -106,10 +109,13 @@ def eight_phase(nk):
             if more2:
                 r.issue("B0", t + 2, g)
             g += 1                                           # P4 (no reads)
+            if fixed:
+                r.wait(4 if more2 else 0, g)
             g += 1                                           # P4 cluster
             if more2:
                 r.issue("B1", t + 2, g)
-            r.wait(6 if more2 else 0, g)
+            if not fixed:
+                r.wait(6 if more2 else 0, g)
     return rows
 
 
@@ -147,9 +153,17 @@ def test_four_phase_loop_is_ordered(nk):
                 assert r.retired_at[key] - gi >= 2, (key, gi, r.retired_at[key])
 
 
+@pytest.mark.parametrize("nk", [1, 2, 3, 4, 12, 36])
+def test_eight_phase_loop_with_the_wait_in_front_of_the_barrier_is_ordered(nk):
+    rows = eight_phase(nk, fixed=True)
+    assert violations(rows) == []
+    for r in rows:
+        assert {(h, k) for h, k, _ in r.reads} == {(h, k) for k in range(nk) for h in HALVES} and not r.q
+
+
 @pytest.mark.parametrize("nk", [3, 12])
-def test_the_checker_flags_the_eight_phase_loops_short_wait(nk):
-    bad = violations(eight_phase(nk))
+def test_the_checker_flags_the_round_2_to_4_wait_placement(nk):
+    bad = violations(eight_phase(nk, fixed=False))
     raw = [b for b in bad if b[0] == "RAW"]
     assert raw and all(b[1] in ("A0", "B0", "B1") for b in raw)          # the lagging row waits in the interval in which the leading row already reads
     assert all("row 0" in b[3] and "row 1" in b[4] for b in raw)
