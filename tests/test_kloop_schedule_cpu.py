@@ -40,8 +40,10 @@ class Row:
         while len(self.q) > keep:
             self.retired_at[self.q.popleft()] = g
 
-    def read(self, half, k, g):
-        self.reads.append((half, k, g))
+    def read(self, half, k, g, safe_from=None):
+        """``safe_from``: first interval in which another wave may overwrite the bytes -- g + 2 when the reader's lgkmcnt(0) sits BEHIND the barrier
+        that ends interval g (default), g' + 1 when it waits in interval g' in front of that interval's barrier."""
+        self.reads.append((half, k, g, g + 2 if safe_from is None else safe_from))
 
 
 def four_phase(nk):
@@ -119,10 +121,48 @@ def eight_phase(nk, fixed):
     return rows
 
 
+def tn_eight_phase(nk):
+    """gemm_tn8_kernel (csrc/gemm_tn.hip): the same four quadrant phases on transposed fragment reads, with the half-tiles named as in gemm_nt
+    (A0 / A1 = X left / right, B0 / B1 = Y left / right).  Here the DMA is issued from the READ segments -- P1: A1(t+1), P2: A0(t+2), P3: B0(t+2),
+    P4: B1(t+2) + vmcnt(6) -- and the reads of a half-tile that is re-staged one phase later are retired by an lgkmcnt wait IN FRONT of the barrier
+    of their own segment (P1: lgkmcnt(8) = the X reads; P2: lgkmcnt(0) = all Y reads)."""
+    rows = [Row(0), Row(1)]
+    for r in rows:
+        g = 0
+        for h in ("A0", "B0", "B1", "A1"):
+            r.issue(h, 0, g)
+        if nk > 1:
+            for h in ("A0", "B0", "B1"):
+                r.issue(h, 1, g)
+            r.wait(6, g)
+        else:
+            r.wait(0, g)
+        for t in range(nk):
+            more1, more2 = t + 1 < nk, t + 2 < nk
+            g = 1 + 8 * t + r.lag                            # P1 read: X left (retired here), Y (its first 32 columns)
+            r.read("A0", t, g, safe_from=g + 1)
+            r.read("B0", t, g, safe_from=g + 3); r.read("B1", t, g, safe_from=g + 3)      # retired by P2's lgkmcnt(0), two intervals on
+            if more1:
+                r.issue("A1", t + 1, g)
+            g += 2                                           # P2 read: Y second 32 columns, lgkmcnt(0) in front of the barrier
+            r.read("B0", t, g, safe_from=g + 1); r.read("B1", t, g, safe_from=g + 1)
+            if more2:
+                r.issue("A0", t + 2, g)
+            g += 2                                           # P3 read: X right (lgkmcnt(0) behind the barrier)
+            r.read("A1", t, g)
+            if more2:
+                r.issue("B0", t + 2, g)
+            g += 2                                           # P4 read segment: last issue + the counted wait
+            if more2:
+                r.issue("B1", t + 2, g)
+            r.wait(6 if more2 else 0, g)
+    return rows
+
+
 def violations(rows):
     bad = []
     for r in rows:
-        for half, k, g in r.reads:
+        for half, k, g, _ in r.reads:
             for o in rows:                                   # RAW: every row's share retired in an interval before the read's
                 ra = o.retired_at.get((half, k))
                 if ra is None or ra >= g:
@@ -131,9 +171,9 @@ def violations(rows):
         for (half, k), gi in r.issued_at.items():
             if k < 2:
                 continue
-            for o in rows:                                   # WAR: reads of the previous occupant (k - 2) retire at the START of interval gr + 1
-                for h2, k2, gr in o.reads:
-                    if h2 == half and k2 == k - 2 and gi < gr + 2:
+            for o in rows:                                   # WAR: every read of the previous occupant (k - 2) is retired AND a barrier lies in between
+                for h2, k2, gr, safe in o.reads:
+                    if h2 == half and k2 == k - 2 and gi < safe:
                         bad.append(("WAR", half, k, f"issued by row {r.lag} in interval {gi}", f"row {o.lag} read {half}({k2}) in {gr}"))
     return bad
 
@@ -143,7 +183,7 @@ def test_four_phase_loop_is_ordered(nk):
     rows = four_phase(nk)
     assert violations(rows) == []
     for r in rows:                                           # every half-tile of every K-tile was read exactly once per row, nothing left in flight
-        assert sorted((h, k) for h, k, _ in r.reads) == sorted((h, k) for k in range(nk) for h in HALVES)
+        assert sorted((h, k) for h, k, _, _ in r.reads) == sorted((h, k) for k in range(nk) for h in HALVES)
         assert not r.q
         # in flight across a barrier: at most three half-tiles (48 KB per CU) behind the counted waits
     # landing time: every half-tile has at least two full intervals between its issue and the wait that retires it
@@ -158,7 +198,15 @@ def test_eight_phase_loop_with_the_wait_in_front_of_the_barrier_is_ordered(nk):
     rows = eight_phase(nk, fixed=True)
     assert violations(rows) == []
     for r in rows:
-        assert {(h, k) for h, k, _ in r.reads} == {(h, k) for k in range(nk) for h in HALVES} and not r.q
+        assert {(h, k) for h, k, _, _ in r.reads} == {(h, k) for k in range(nk) for h in HALVES} and not r.q
+
+
+@pytest.mark.parametrize("nk", [1, 2, 3, 4, 12, 225])
+def test_weight_gradient_loop_is_ordered(nk):
+    rows = tn_eight_phase(nk)
+    assert violations(rows) == []
+    for r in rows:
+        assert {(h, k) for h, k, _, _ in r.reads} == {(h, k) for k in range(nk) for h in HALVES} and not r.q
 
 
 @pytest.mark.parametrize("nk", [3, 12])
