@@ -97,6 +97,38 @@ def test_gemm_nt_tile_blocked_weights_take_the_8_phase_kernel(ops):
     assert float((o0 - o1).abs().max()) < 1e-4 and float((c0.float() - c1.float()).abs().max()) < 2e-2
 
 
+def test_gemm_nt_bit_stable_under_memory_pressure(ops):
+    """The 4-phase loop's counted waits leave LDS-DMA half-tiles in flight across barriers; its ordering does not depend on how long a half-tile takes
+    to land (tests/test_kloop_schedule_cpu.py), so the product must be bit-identical when the memory system is saturated by another stream -- 100 runs of
+    a bench-shaped product (13.8 rounds of tiles, persistent lane) and of an f32-residual product against their quiet-machine results while a second
+    stream streams 1.2 GB copies through HBM."""
+    M, N, K = 256 * 393, 2304, 768
+    A, B = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=0.05)
+    bias = rnd(N, seed=43, dtype=F32)
+    res = rnd(M, 768, seed=44, dtype=F32)
+    ref = torch.empty(M, N, device=DEV, dtype=BF)
+    ref2 = torch.empty(M, 768, device=DEV, dtype=F32)
+    ops.gemm_nt(A, B, ref, bias=bias)
+    ops.gemm_nt(A, B[:768], ref2, bias=bias[:768], res_f32=res)
+    torch.cuda.synchronize()
+    src = torch.empty(300 * 1024 * 1024, device=DEV, dtype=torch.float32)
+    dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+    out, out2 = torch.empty_like(ref), torch.empty_like(ref2)
+    bad = 0
+    for it in range(100):
+        with torch.cuda.stream(side):
+            dst.copy_(src, non_blocking=True)
+            src.copy_(dst, non_blocking=True)
+        ops.gemm_nt(A, B, out, bias=bias)
+        ops.gemm_nt(A, B[:768], out2, bias=bias[:768], res_f32=res)
+        if it % 10 == 9:
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(out, ref)) + int(not torch.equal(out2, ref2))
+    torch.cuda.synchronize()
+    assert bad == 0
+
+
 def test_gemm_nt_asymmetric_identity(ops):
     """A = I against an asymmetric B catches a transposed / permuted C write."""
     K = 128
