@@ -449,6 +449,104 @@ __global__ __launch_bounds__(512, 1) void lab_kernel(P p) {
   }
 }
 
+// ---- V7: ONE wave per SIMD.  4 waves (2 x 2), wave tile 128 x 128 as 8 x 8 blocks of v_mfma_f32_16x16x32 (256 accumulator registers: the other half
+// of the register file that two waves per SIMD cannot use), so that a K-tile costs 128 KB of LDS fragment reads per CU instead of 192 KB.  No partner
+// wave hides anything: the fragment reads of k-step kk + 1 are interleaved with the MFMAs of k-step kk inside the wave (one ds_read_b128 per four
+// MFMAs), the LDS-DMA of K-tile t + 1 (16 instructions per wave) is spread over the MFMAs of K-tile t, ONE barrier per K-tile (double buffer: the wait
+// for K-tile t + 1 and the barrier sit at the end of K-tile t; the first fragments of t + 1 are requested behind it -- that bubble is not hidden).
+template <bool STAMP>
+__global__ __launch_bounds__(256, 1) void lab7_kernel(P p) {
+  constexpr int BM = 256, BN = 256, NT = 256, STAGE = 65536, A_BYTES = 32768;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+  const int nk = p.K / 64;
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned offA[8], offB[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int c = r * NT + tid, row = c >> 3, pc = c & 7, lc = pc ^ ((row >> 1) & 7);
+    offA[r] = ((unsigned)min(m0 + row, p.M - 1) * (unsigned)p.lda + lc * 8) * 2u;
+    offB[r] = ((unsigned)min(n0 + row, p.N - 1) * (unsigned)p.ldb + lc * 8) * 2u;
+  }
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)LDS_PTR(smem) + wave * 1024;
+  auto issue1 = [&](int t, int i) {                      // DMA instruction i (0..15) of K-tile t: 0..7 = A chunks, 8..15 = B chunks
+    const unsigned l = lds0 + (t & 1) * STAGE;
+    if (i < 8) dma16(l + i * NT * 16, offA[i], (const char*)p.A + (long long)t * 128);
+    else dma16(l + A_BYTES + (i - 8) * NT * 16, offB[i - 8], (const char*)p.B + (long long)t * 128);
+  };
+  const int colsw = (g4 ^ (l15 >> 1)) << 4;
+  const int rdA = (wr * 128 + l15) * 128 + colsw, rdB = A_BYTES + (wc * 128 + l15) * 128 + colsw;
+  // fragments are SINGLE-buffered and refreshed in place: A block mb is dead after its row of 8 MFMAs, B block nb after the last row -- the read of the
+  // next k-step's fragment goes out right behind the last MFMA that uses the old one (64 fragment registers instead of 128: with 256 accumulators
+  // the double-buffered form spilled through v_accvgpr moves, 900 of them per kernel)
+  bf16x8 fa[8], fb[8];
+  auto rA = [&](const char* s_, int kk, int mb) { fa[mb] = *(const bf16x8*)(s_ + ((rdA + mb * 2048) ^ (kk << 6))); };
+  auto rB = [&](const char* s_, int kk, int nb) { fb[nb] = *(const bf16x8*)(s_ + ((rdB + nb * 2048) ^ (kk << 6))); };
+#pragma unroll
+  for (int i = 0; i < 16; ++i) issue1(0, i);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SB(); __builtin_amdgcn_s_barrier(); SB();
+#pragma unroll
+  for (int x = 0; x < 8; ++x) { rB(smem, 0, x); rA(smem, 0, x); }
+  for (int t = 0; t < nk; ++t) {
+    const char* sT = smem + (t & 1) * STAGE;
+    const bool more = t + 1 < nk;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+          // accumulator placement by hand: rows 0-5 in AGPRs (192), rows 6-7 in VGPRs (64) -- with all 256 in AGPRs the compiler's allocator
+          // shuffled ~150 registers per K-tile between the two files (v_accvgpr moves); the constraint letters pin them
+          if (mb < 6) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mb][nb]) : "v"(fb[nb]), "v"(fa[mb]));
+          else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[mb][nb]) : "v"(fb[nb]), "v"(fa[mb]));
+          if (kk == 0 && mb == 7) { SB(); rB(sT, 1, nb); SB(); }          // last row of k-step 0: B block nb is dead, fetch its k-step 1 fragment
+        }
+        SB();
+        if (kk == 0) rA(sT, 1, mb);                                       // row done: A block mb of k-step 1
+        if (more) issue1(t + 1, kk * 8 + mb);                             // one of the 16 DMA instructions of K-tile t + 1 per row
+        SB();
+      }
+    }
+    if (more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // K-tile t + 1 (own share); its buffer was free: everybody finished K-tile t - 1 before the previous barrier
+      SB(); __builtin_amdgcn_s_barrier(); SB();
+      const char* sN = smem + ((t + 1) & 1) * STAGE;
+#pragma unroll
+      for (int x = 0; x < 8; ++x) { rB(sN, 0, x); rA(sN, 0, x); }
+    }
+  }
+  if (p.flags & 1) {
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (s == 12345.678f) p.C[tid] = (bf16)s;
+    return;
+  }
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    const int m = m0 + wr * 128 + mb * 16 + l15;
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const int n = n0 + wc * 128 + nb * 16 + 4 * g4;
+      if (m < p.M && n < p.N) *(bf16x4*)(p.C + (size_t)m * p.ldc + n) = f4_to_bf4(acc[mb][nb]);
+    }
+  }
+}
+
 __global__ void fill_bf16(uint16_t* p, size_t n, uint32_t seed, float scale) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     uint32_t x = (uint32_t)i * 2654435761u ^ seed; x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -466,16 +564,16 @@ __global__ void ref_nt(const uint16_t* A, const uint16_t* B, float* C, int M, in
 static float bf2f_h(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 typedef void (*kern_t)(P);
-struct Var { const char* name; kern_t k, ks; int same_as; };     // same_as: variant whose results this one must equal bit for bit (-1: naive check only)
+struct Var { const char* name; kern_t k, ks; int same_as; int threads = 512; };     // same_as: variant whose results this one must equal bit for bit (-1: naive check only)
 
-static void launch(kern_t k, const P& p, hipStream_t st) {
+static void launch(kern_t k, const P& p, hipStream_t st, int threads = 512) {
   static bool set[64] = {};
   static kern_t seen[64];
   int idx = -1;
   for (int i = 0; i < 64; ++i) { if (set[i] && seen[i] == k) { idx = i; break; } if (!set[i]) { idx = i; break; } }
   if (!set[idx]) { CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); set[idx] = true; seen[idx] = k; }
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  hipLaunchKernelGGL(k, dim3(tiles), dim3(512), 131072, st, p);
+  hipLaunchKernelGGL(k, dim3(tiles), dim3(threads), 131072, st, p);
 }
 
 int main(int argc, char** argv) {
@@ -491,6 +589,7 @@ int main(int argc, char** argv) {
     {"V4 = V1, counted lgkm", lab_kernel<4, false>, lab_kernel<4, true>, 0},
     {"V5 = V3, counted lgkm", lab_kernel<5, false>, lab_kernel<5, true>, 3},
     {"V6 = V3, row 1 DMA in R", lab_kernel<6, false>, lab_kernel<6, true>, 3},
+    {"V7 one wave per SIMD", lab7_kernel<false>, lab7_kernel<true>, 3, 256},
   };
   const int MV = 256 * 393;
   const size_t maxA = (size_t)MV * 3072;
@@ -514,7 +613,7 @@ int main(int argc, char** argv) {
       const size_t ob = (size_t)c.M * c.N * 2;
       std::vector<uint16_t> h0(ob / 2), h1(ob / 2), h2(ob / 2);
       CK(hipMemsetAsync(C[0], 0xff, ob, st));
-      launch(vars[0].k, mkp(c.M, c.N, c.K, 0, 0, 0, false), st);
+      launch(vars[0].k, mkp(c.M, c.N, c.K, 0, 0, 0, false), st, vars[0].threads);
       CK(hipStreamSynchronize(st)); CK(hipGetLastError());
       CK(hipMemcpy(h0.data(), C[0], ob, hipMemcpyDeviceToHost));
       // V0 vs naive
@@ -531,7 +630,7 @@ int main(int argc, char** argv) {
         int races = 0;
         for (int r = 0; r < 10; ++r) {
           CK(hipMemsetAsync(C[1], 0xff, ob, st));
-          launch(vars[v].k, mkp(c.M, c.N, c.K, 0, 1, 0, false), st);
+          launch(vars[v].k, mkp(c.M, c.N, c.K, 0, 1, 0, false), st, vars[v].threads);
           CK(hipStreamSynchronize(st)); CK(hipGetLastError());
           CK(hipMemcpy(r ? h2.data() : h1.data(), C[1], ob, hipMemcpyDeviceToHost));
           if (r && memcmp(h1.data(), h2.data(), ob)) ++races;
@@ -546,7 +645,7 @@ int main(int argc, char** argv) {
       // stamp builds compute the same numbers
       for (size_t v = 0; v < vars.size(); ++v) {
         CK(hipMemsetAsync(C[1], 0xff, ob, st));
-        launch(vars[v].ks, mkp(c.M, c.N, c.K, 0, 1, 0, false), st);
+        launch(vars[v].ks, mkp(c.M, c.N, c.K, 0, 1, 0, false), st, vars[v].threads);
         CK(hipStreamSynchronize(st)); CK(hipGetLastError());
         CK(hipMemcpy(h1.data(), C[1], ob, hipMemcpyDeviceToHost));
         if (memcmp(hv[v].data(), h1.data(), ob)) { printf("   %-24s STAMP build differs\n", vars[v].name); ++bad; }
@@ -562,11 +661,11 @@ int main(int argc, char** argv) {
       for (int noepi = 0; noepi < 2; ++noepi)
         for (auto& s : sh) {
           std::vector<std::vector<float>> ms(vars.size());
-          for (size_t v = 0; v < vars.size(); ++v) for (int w = 0; w < 2; ++w) launch(vars[v].k, mkp(s.M, s.N, s.K, w, 0, noepi, hot), st);
+          for (size_t v = 0; v < vars.size(); ++v) for (int w = 0; w < 2; ++w) launch(vars[v].k, mkp(s.M, s.N, s.K, w, 0, noepi, hot), st, vars[v].threads);
           for (int r = 0; r < rounds; ++r)
             for (size_t v = 0; v < vars.size(); ++v) {
               CK(hipEventRecord(e0, st));
-              for (int it = 0; it < NIT; ++it) launch(vars[v].k, mkp(s.M, s.N, s.K, it, 0, noepi, hot), st);
+              for (int it = 0; it < NIT; ++it) launch(vars[v].k, mkp(s.M, s.N, s.K, it, 0, noepi, hot), st, vars[v].threads);
               CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
               float t; CK(hipEventElapsedTime(&t, e0, e1)); ms[v].push_back(t / NIT);
             }
@@ -586,7 +685,7 @@ int main(int argc, char** argv) {
           const int nk = s.K / 64;
           for (int wg : {300}) {
             CK(hipMemsetAsync(stamps, 0, 512, st));
-            for (int w = 0; w < 3; ++w) { P p = mkp(s.M, s.N, s.K, w, 0, 1, hot); p.stamp_wg = wg; launch(vars[v].ks, p, st); }
+            for (int w = 0; w < 3; ++w) { P p = mkp(s.M, s.N, s.K, w, 0, 1, hot); p.stamp_wg = wg; launch(vars[v].ks, p, st, vars[v].threads); }
             CK(hipStreamSynchronize(st)); CK(hipGetLastError());
             CK(hipMemcpy(hs.data(), stamps, 512, hipMemcpyDeviceToHost));
             printf("stamp %-18s %s %-22s wg %3d (cycles per K-tile, s_memtime units)\n", s.name, hot ? "HOT " : "cold", vars[v].name, wg);
