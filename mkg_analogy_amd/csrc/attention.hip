@@ -10,6 +10,7 @@
 //  text   (BertSelfAttention, :317-377): scores/8 -> adaptive analogy reweight (:342-349) -> + (1-mask)*-1e4
 //          (:355,:55-56) -> softmax -> dropout(p) on the probabilities (:362)
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "mart_hip.h"
 
@@ -23,6 +24,19 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr int TILE_BYTES = 64 * 128;     // 64 rows x 64 bf16
 constexpr int STAGE_BYTES = 2 * TILE_BYTES + 512;   // two tiles + 2x64 floats (lse, delta)
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+
+// Cycle stamps of ONE workgroup (variant builds only: tools/build_variant.sh attention.hip <out.so> -DATTN_STAMPS; tools/attn_stamps.py): [kernel 0 fwd / 1 fused bwd][wave][stamp]
+#ifdef ATTN_STAMPS
+__device__ unsigned long long g_attn_stamps[2 * 8 * 32];
+__device__ __forceinline__ unsigned long long attn_memtime() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");   // the wait belongs INSIDE: the result lands asynchronously
+  return t;
+}
+#define ATTN_STAMP(kern, on, k) do { if ((on) && lane == 0 && (k) < 32) g_attn_stamps[((kern) * 8 + wave) * 32 + (k)] = attn_memtime(); } while (0)
+#else
+#define ATTN_STAMP(kern, on, k) do { } while (0)
+#endif
 
 struct Side {                            // a [rows, nh*64] bf16 view with an optional prefix block in front
   const bf16* own; int ld_own; int n_own;          // rows of this batch element: own[(b*n_own + j)*ld_own + h*64 + d]
@@ -41,14 +55,19 @@ __device__ __forceinline__ const bf16* side_row(const Side& s, int b, int h, int
 // 8 + j, 16 + j, ... of a group (same XCD, dispatched together) are the parts of ONE pair -- the second reader hits L2.
 struct WgId { int part, h, b; };
 __device__ __forceinline__ WgId wg_id(int nh, int B) {
+  // Division-free (round 5; the 64-bit quotient / remainder forms were ~320 scalar instructions at the head of every wave).  With
+  // P = y + nh z the pair index in launch order, L = x + G P, and x < G:  L / (8 G) = P >> 3 and L mod (8 G) = G (P & 7) + x.
   const int G = gridDim.x;
-  const long long L = blockIdx.x + (long long)G * (blockIdx.y + (long long)nh * blockIdx.z);
-  const long long pairs = (long long)nh * B;
-  if (G == 1 || (pairs & 7) != 0) return WgId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
-  const long long group = L / (8 * G);
-  const int r = (int)(L - group * (8 * G));
-  const long long pair = group * 8 + (r & 7);
-  return WgId{r >> 3, (int)(pair % nh), (int)(pair / nh)};
+  const int x = blockIdx.x, y = blockIdx.y, z = blockIdx.z;
+  const unsigned pairs = (unsigned)nh * (unsigned)B;
+  if (G == 1 || (pairs & 7u) != 0) return WgId{x, y, z};
+  const unsigned P = (unsigned)y + (unsigned)nh * (unsigned)z;
+  const int c = (int)(P & 7u), r = G * c + x;
+  // pair = 8 (P >> 3) + (r & 7) = P + ((r & 7) - c): the head / batch indices move by less than 8 positions from (y, z)
+  int hh = y + ((r & 7) - c), bb = z;
+  while (hh < 0) { hh += nh; --bb; }
+  while (hh >= nh) { hh -= nh; ++bb; }
+  return WgId{r >> 3, hh, bb};
 }
 
 // Loop-top barrier of the double-buffered tile loops.  The explicit vmcnt(0) is REQUIRED: the LDS-DMA of the tile about
@@ -144,6 +163,17 @@ __device__ __forceinline__ void stage_tile_fast(const Stager& g, int r0, char* l
         dma_saddr(g.own_b, (unsigned)(row * g.ld_own + lc * 8) * 2u, dst);
       }
     }
+  }
+}
+// A tile whose 64 rows all exist (every tile but possibly the last): both halves are wave-uniform, the prefix / own choice is a scalar select --
+// no branch per copy (the branchy general form above was ~100 scalar instructions and a dozen taken / not-taken branches per tile iteration).
+__device__ __forceinline__ void stage_tile_full(const Stager& g, int r0, char* lds, int wave) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int j0 = r0 + r * 32;
+    const bool pre = j0 < g.n_pre;                                                    // wave-uniform; n_pre is a multiple of 32
+    const bf16* base = pre ? g.pre_b + (long long)j0 * g.ld_pre : g.own_b + (long long)(j0 - g.n_pre) * g.ld_own;
+    dma_saddr(base, pre ? g.voff_pre : g.voff_own, lds + (r * NTH + wave * 64) * 16);
   }
 }
 // Per-lane byte offsets of the fragment reads inside a 64x64 tile -- loop invariant, computed once per kernel so the
@@ -254,8 +284,13 @@ __device__ __forceinline__ float mask_add(uint64_t mb_lane, int c) { return ((mb
 // no staging instruction in the tile loop.  Same 128 VGPRs / four waves per SIMD as the ring kernel.  LDS: 16 KB per 64 keys (112 KB at 393 keys,
 // 128 KB at 457: one workgroup per CU).
 constexpr int RES_NTH = 1024;
+#ifndef FWD_NW
+#define FWD_NW 4                         // waves per workgroup of the vision ring kernel (one query tile each); waves 0-3 stage the K / V tiles
+#endif
+constexpr int fwd_waves(bool text, int tpw, bool res) { return (!text && tpw == 1 && !res) ? FWD_NW : 4; }
 template <bool TEXT, int TPW, bool RES = false>
-__global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2)) void attn_fwd_k(mart_attn_fwd_desc p) {
+__global__ __launch_bounds__(RES ? RES_NTH : 64 * fwd_waves(TEXT, TPW, RES), RES ? 1 : ((TPW == 1 && !TEXT) ? ATTN_FWD_MINW1 : 2)) void attn_fwd_k(mart_attn_fwd_desc p) {
+  constexpr int NWV = fwd_waves(TEXT, TPW, RES);
   static_assert(!RES || (TPW == 1 && !TEXT), "the resident form is the vision kernel, one query tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -267,6 +302,8 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
   const TextCtl ctl = make_ctl(p, b, p.Sk);
   constexpr bool text = TEXT;          // vision instantiation: no mask / reweight / dropout code at all
+  const bool stamp_on = !TEXT && !RES && b == p.B / 2 && h == 5 && wg.part == 1;
+  ATTN_STAMP(0, stamp_on, 0);
   const LaneOffs lo = make_offs(lane);
 
   int q0[TPW], qi[TPW];
@@ -276,7 +313,7 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
   float m_run[TPW], l_run[TPW];
 #pragma unroll
   for (int u = 0; u < TPW; ++u) {
-    q0[u] = RES ? wave * 32 : wg.part * (128 * TPW) + (wave * TPW + u) * 32;
+    q0[u] = RES ? wave * 32 : wg.part * (32 * NWV * TPW) + (wave * TPW + u) * 32;
     qi[u] = q0[u] + l31;
     active[u] = q0[u] < p.Sq;                          // wave-uniform
     const bf16* qp = (const bf16*)p.q + ((long long)b * p.Sq + min(qi[u], p.Sq - 1)) * p.ldq + h * 64;
@@ -292,11 +329,19 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
   Stager gK, gV;
   if constexpr (!TEXT) { gK = make_stager(K, b, h, tid); gV = make_stager(V, b, h, tid); }
   // vision: uniform-pointer staging (the host routes prefix lengths that are not multiples of 32 to the general instantiation)
+#ifndef FWD_STAGE_FULL
+#define FWD_STAGE_FULL 1
+#endif
 #define stage_kv(r0_, buf_)                                                                           \
   do {                                                                                                 \
     if constexpr (!TEXT) {                                                                             \
-      stage_tile_fast(gK, (r0_), (buf_), tid, wave);                                                   \
-      stage_tile_fast(gV, (r0_), (buf_) + TILE_BYTES, tid, wave);                                      \
+      if (FWD_STAGE_FULL && (r0_) + 64 <= Stot) {                                                      \
+        stage_tile_full(gK, (r0_), (buf_), wave);                                                      \
+        stage_tile_full(gV, (r0_), (buf_) + TILE_BYTES, wave);                                         \
+      } else {                                                                                         \
+        stage_tile_fast(gK, (r0_), (buf_), tid, wave);                                                 \
+        stage_tile_fast(gV, (r0_), (buf_) + TILE_BYTES, tid, wave);                                    \
+      }                                                                                                \
     } else {                                                                                           \
       stage_tile(K, b, h, (r0_), (buf_), tid, wave);                                                   \
       stage_tile(V, b, h, (r0_), (buf_) + TILE_BYTES, tid, wave);                                      \
@@ -310,21 +355,28 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
     for (int kt = 0; kt < ntiles; ++kt) glds16(side_row(S, b, h, kt * 64 + row) + lc * 8, img + kt * TILE_BYTES);   // rows past the last key: clamped copies (finite)
     tile_barrier();
   } else {
-    stage_kv(0, smem);
+    if (NWV == 4 || wave < 4) stage_kv(0, smem);
   }
   // The Q fragments (plain global loads, above) are first USED inside the loop, so the compiler put its own s_waitcnt vmcnt(3..0) for them in front
   // of the first four MFMAs of EVERY iteration -- and the hardware counter also counts the LDS-DMA of the next tile, issued (as opaque assembly) at the
   // top of the iteration: every S phase waited for the prefetch it had just started, i.e. the ring never ran ahead.  A compiler-visible wait here
   // retires the Q loads before the loop; the tile loop then carries no vmcnt wait but the one in tile_barrier().
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), expcnt / lgkmcnt untouched
-  for (int kt = 0; kt < ntiles; ++kt) {
-    if constexpr (!RES) {
-      tile_barrier();
-      if (kt + 1 < ntiles) stage_kv((kt + 1) * 64, smem + ((kt + 1) & 1) * STAGE_BYTES);
-    }
+  ATTN_STAMP(0, stamp_on, 1);
+#ifndef FWD_HALF_TAIL
+#define FWD_HALF_TAIL 1
+#endif
+#ifndef FWD_PEEL
+#define FWD_PEEL 1                                       // the last key tile peeled out of the loop (vision ring kernel)
+#endif
+  // One tile.  LAST (compile time, vision ring kernel with FWD_PEEL): the tile that may be cut by the last key -- the only one that carries the partial-tile
+  // mask and the block guard NT (32-key blocks that hold keys: the last tile of the vision shapes, 393 = 6 x 64 + 9 and 457 = 7 x 64 + 9 keys, runs
+  // as ONE block: half the MFMAs and exponentials of a tile that was 86 % padding).  The loop body proper is straight-line.
+  auto tile = [&](const int kt, auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;
+    const int NT = (LAST && FWD_HALF_TAIL && (!TEXT && !RES) && kt * 64 + 32 >= Stot) ? 1 : 2;      // wave-uniform
     const char* sK = RES ? smem + kt * TILE_BYTES : smem + (kt & 1) * STAGE_BYTES;
     const char* sV = RES ? smem + (ntiles + kt) * TILE_BYTES : sK + TILE_BYTES;
-    if (!active[0]) continue;                         // wave past the last query row: only stages tiles and keeps the barriers
     // S^T[key][q] = K q^T
     f32x16 st[TPW][2];
     float pv[TPW][2][16];
@@ -333,7 +385,7 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
     for (int u = 0; u < TPW; ++u) {
       if (u > 0 && !active[u]) continue;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < 2; ++t) if (t < NT) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[u][t][r] = 0.f;
 #pragma unroll
@@ -346,19 +398,19 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
       // online softmax in the log2 domain: m_run, the saved statistic and every exponent are base-2 (one v_exp_f32 each)
       float rs = 0.f;
       if constexpr (!TEXT) {                            // vision: fma, exp2, add per score (packed two at a time)
-        if (kt * 64 + 64 > Stot) {
+        if (LAST && kt * 64 + 64 > Stot) {
           // last (partial) key tile -- one in seven at 393 keys: mask in place (compare + select per score), then the
           // same fast path; -1e30 * c2 - m underflows exp2 to exactly 0
           const int lim = Stot - kt * 64;
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t) if (t < NT)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               if (t * 32 + mfma_row(r, hh) >= lim) st[u][t][r] = -1.0e30f;
         }
         float mx = st[u][0][0];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) if (t < NT)
 #pragma unroll
           for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
@@ -376,7 +428,7 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
         f32x2 rs2 = {0.f, 0.f};
         const f32x2 c22 = {c2, c2}, mn2 = {m_new, m_new};
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) if (t < NT)
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const f32x2 x = f32x2{st[u][t][r], st[u][t][r + 1]} * c22 - mn2;
@@ -389,7 +441,7 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
         float rsa = 0.f, rsb = 0.f;
         const float nm = -m_new;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) if (t < NT)
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][t][r], c2, nm));
@@ -405,7 +457,7 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
         const uint64_t mb = mask_bits(ctl, kt, Stot, lane) >> (4 * hh);   // this lane's keys: bit (t*32 + (r&3) + 8*(r>>2))
         const QueryRw qr = make_qrw(ctl, qi[u]);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) if (t < NT)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kj = kt * 64 + t * 32 + mfma_row(r, hh);
@@ -426,7 +478,7 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
         // adjacent keys, so with an even Stot they share one hash (common.h)
         const uint32_t rowbase = (uint32_t)(((uint32_t)b * p.nh + h) * p.Sq + (uint32_t)qi[u]) * (uint32_t)Stot;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) if (t < NT)
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const float e0 = __builtin_amdgcn_exp2f(pv[u][t][r] - m_new), e1 = __builtin_amdgcn_exp2f(pv[u][t][r + 1] - m_new);
@@ -456,7 +508,7 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
     }
     // O^T[d][q] += V^T P^T   (the transposed V fragments are shared by the wave's tiles)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) if (t < NT)
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         bf16x8 vf[2];
@@ -470,6 +522,21 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
           for (int dt = 0; dt < 2; ++dt) ot[u][dt] = mfma32(vf[dt], pf, ot[u][dt]);
         }
       }
+  };
+  constexpr bool PEEL = FWD_PEEL && !TEXT && !RES;
+  for (int kt = 0; kt < ntiles - (PEEL ? 1 : 0); ++kt) {
+    if constexpr (!RES) {
+      tile_barrier();
+      ATTN_STAMP(0, stamp_on, 2 + kt);
+      if (kt + 1 < ntiles && (NWV == 4 || wave < 4)) stage_kv((kt + 1) * 64, smem + ((kt + 1) & 1) * STAGE_BYTES);
+    }
+    if (!active[0]) continue;                         // wave past the last query row: only stages tiles and keeps the barriers
+    if constexpr (PEEL) tile(kt, std::false_type{}); else tile(kt, std::true_type{});
+  }
+  if constexpr (PEEL) {
+    tile_barrier();
+    ATTN_STAMP(0, stamp_on, 1 + ntiles);
+    if (active[0]) tile(ntiles - 1, std::true_type{});
   }
 #ifndef FWD_LDS_EPI
 #define FWD_LDS_EPI 1
@@ -478,7 +545,9 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
     // The output tile has "lane = query, registers = 4 consecutive head dims": stored from registers, an instruction writes 8 bytes into each of 32
     // rows that lie 2 * ld bytes apart (32 partial cache lines).  Each wave stages its 32 rows in its own 4 KB of the (now dead) K / V ring and
     // stores them as 16-byte chunks, eight lanes per 128-byte row segment.
+    ATTN_STAMP(0, stamp_on, 2 + ntiles);
     __syncthreads();                                       // every wave is through its last K / V tile
+    ATTN_STAMP(0, stamp_on, 3 + ntiles);
     char* so = smem + wave * 4096;
     if (active[0]) {
       const float inv = 1.f / l_run[0];
@@ -519,6 +588,7 @@ __global__ __launch_bounds__(RES ? RES_NTH : NTH, RES ? 1 : ((TPW == 1 && !TEXT)
         }
       }
     }
+    ATTN_STAMP(0, stamp_on, 4 + ntiles);
     return;
   }
 #pragma unroll
@@ -924,6 +994,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
   const int Stot = p.Lp + p.Sk;
   const Side K{(const bf16*)p.k, p.ldk, p.Sk, (const bf16*)p.pk, p.ldp, p.Lp};
   const Side V{(const bf16*)p.v, p.ldv, p.Sk, (const bf16*)p.pv, p.ldp, p.Lp};
+  const bool stamp_on = b == p.B / 2 && h == 5;
+  ATTN_STAMP(1, stamp_on, 0);
   const LaneOffs lo = make_offs(lane);
   char* sK = smem;
   float* sLse = (float*)(smem + F_OFF_STAT);
@@ -932,9 +1004,29 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
   // ---- prologue: K image, lse / delta of every query row, first Q / dO tile
   const int nkrows = 512;                            // ALL 512 image rows (rows past the last key: clamped copies, finite): the dQ
                                                      // contraction multiplies them by the zero rows of the dS image, and 0 x garbage could be NaN
-  for (int r0 = 0; r0 < nkrows; r0 += 64) {
-    const int row = r0 + (tid >> 3), pc = tid & 7, lc = pc ^ swz_key(row);
-    glds16(side_row(K, b, h, row) + lc * 8, sK + (size_t)(r0 * 8 + wave * 64) * 16);
+#ifndef FUSED_PRO_FAST
+#define FUSED_PRO_FAST 1
+#endif
+  {
+    // A wave-instruction copies the 8 rows j0 .. j0 + 7, j0 = r0 + 8 wave.  Where they all exist and lie on one side of the prefix boundary (prefix
+    // length a multiple of 8) the source is a WAVE-UNIFORM pointer plus one loop-invariant lane offset (saddr form; swz_key(row) depends on the row
+    // only through (row >> 1) & 7 = (4 wave + (lane >> 4)) & 7): no per-lane clamp / select / 64-bit multiply (8 copies x ~30 VALU in rounds 2-4).
+    const int rl = lane >> 3, pc = tid & 7, lcw = pc ^ swz_key(wave * 8 + rl);
+    const unsigned voff_own = (unsigned)(rl * p.ldk + lcw * 8) * 2u, voff_pre = (unsigned)(rl * p.ldp + lcw * 8) * 2u;
+    const bf16* own_b = (const bf16*)p.k + ((long long)b * p.Sk) * p.ldk + h * 64;
+    const bf16* pre_b = p.Lp ? (const bf16*)p.pk + ((long long)b * p.Lp) * p.ldp + h * 64 : own_b;
+    const bool fast = FUSED_PRO_FAST && (p.Lp & 7) == 0;
+    for (int r0 = 0; r0 < nkrows; r0 += 64) {
+      const int j0 = r0 + wave * 8;
+      char* dst = sK + (size_t)(r0 * 8 + wave * 64) * 16;
+      if (fast && j0 + 8 <= Stot) {
+        if (j0 < p.Lp) dma_saddr(pre_b + (long long)j0 * p.ldp, voff_pre, dst);
+        else dma_saddr(own_b + (long long)(j0 - p.Lp) * p.ldk, voff_own, dst);
+      } else {
+        const int row = r0 + (tid >> 3), lc = pc ^ swz_key(row);
+        glds16(side_row(K, b, h, row) + lc * 8, dst);
+      }
+    }
   }
   auto stage_q = [&](int t, int buf) {               // waves 0-3: Q tile, waves 4-7: dO tile (one 16-byte chunk per thread)
     const int c = tid & 255, row = c >> 3, pc = c & 7, lc = pc ^ swz_key(row);
@@ -969,7 +1061,8 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
       const int q = 64 * i + (tid >> 3);
       float dsum = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dsum += (float)ov[i][e] * (float)gv[i][e];
+      for (int e = 0; e < 8; e += 2)                     // v_dot2c_f32_bf16: two products per instruction, f32 accumulate (16 unpacks + 8 fma per chunk before)
+        dsum = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{ov[i][e], ov[i][e + 1]}, bf16x2{gv[i][e], gv[i][e + 1]}, dsum, false);
       dsum += dpp_f32<0xB1>(dsum);                     // lanes ^1, ^2 (quad permutes), then the other quad of the 8-lane group (row_half_mirror)
       dsum += dpp_f32<0x4E>(dsum);
       dsum += dpp_f32<0x141>(dsum);
@@ -1012,7 +1105,9 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
   // dQ sub-block of this wave: d rows db*16.., q columns qb*16..
   const int db = wave & 3, qb = wave >> 2;
   const int g16 = lane >> 4, p16 = lane & 15;
+  ATTN_STAMP(1, stamp_on, 1);
   tile_barrier();
+  ATTN_STAMP(1, stamp_on, 2);
 
   // dQ of one tile: contraction over 16 chunks of 32 keys, four chunks (16 transposed reads, then 4 MFMAs) at a time so that one
   // LDS latency is exposed per group instead of per chunk; chunks past the last key multiply zeros (dS image zero-filled once).
@@ -1024,35 +1119,44 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
   const int kchunk = db * 2 + ((p16 & 3) >> 1), kbo = (p16 & 1) * 8, dchunk = qb * 4 + (p16 & 3);
   const int ka1 = rb * 128 + ((kchunk ^ swz_key(rb)) << 4) + kbo, ka2 = (rb + 16) * 128 + ((kchunk ^ swz_key(rb + 16)) << 4) + kbo;
   const int da1 = rb * 64 + ((dchunk ^ ds_swz(rb)) << 3), da2 = (rb + 16) * 64 + ((dchunk ^ ds_swz(rb + 16)) << 3);
-  auto dq_tile = [&](int tq) {
+#ifndef FUSED_DQ_DEPTH
+#define FUSED_DQ_DEPTH 3                                   // 32-key chunks whose reads are in flight ahead of the MFMA that consumes them
+#endif
+  // STRAIGHT-LINE software pipeline over NCH 32-key chunks (14 covers the 393 keys of a prefix-free layer, 16 everything up to 512; chunks past the
+  // last key multiply the zero rows of the dS image): the four transposed reads of chunks c + 1 .. c + DQD are in flight under the MFMA of chunk c
+  // (DQD + 1 register slots of 8 VGPRs).  Rounds 2-4 read in groups of two chunks, ONE group ahead, behind a runtime group count (a branch per
+  // group): the phase was eight exposed LDS latencies long -- 1300-1400 cycles per tile and wave for 256 cycles of matrix work (tools/attn_stamps.py).
+  auto dq_tile_n = [&](int tq, auto nch_c) {
+    constexpr int NCH = decltype(nch_c)::value;
+    constexpr int DQD = FUSED_DQ_DEPTH;
     const char* sD = smem + F_OFF_DS + (tq & 1) * F_DS;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;       // two accumulation chains (even / odd chunks)
-    const int ngrp = (nkc + 1) >> 1;                      // groups of two 32-key chunks
-    bf16x8 af[2][2], bfv[2][2];
-    auto load = [&](int g, int slot) {
-      const char* kg = sK + g * (2 * 32 * 128);
-      const char* dg = sD + g * (2 * 32 * 64);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        af[slot][u] = join_tr(lds_tr_read(kg + u * 4096 + ka1), lds_tr_read(kg + u * 4096 + ka2));
-        bfv[slot][u] = join_tr(lds_tr_read(dg + u * 2048 + da1), lds_tr_read(dg + u * 2048 + da2));
-      }
+    bf16x8 af[DQD + 1], bfv[DQD + 1];
+    auto load = [&](int c, int slot) {
+      af[slot] = join_tr(lds_tr_read(sK + c * 4096 + ka1), lds_tr_read(sK + c * 4096 + ka2));
+      bfv[slot] = join_tr(lds_tr_read(sD + c * 2048 + da1), lds_tr_read(sD + c * 2048 + da2));
     };
-    load(0, 0);                                            // software pipeline: the reads of group g + 1 are in flight under the MFMAs of group g
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g < ngrp) {
-        if (g + 1 < ngrp) load(g + 1, (g + 1) & 1);
-        acc0 = mfma16(af[g & 1][0], bfv[g & 1][0], acc0);
-        acc1 = mfma16(af[g & 1][1], bfv[g & 1][1], acc1);
-      }
+    for (int c = 0; c < DQD; ++c) load(c, c % (DQD + 1));
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // the scheduling barriers pin the order (left alone, the compiler re-sorts the reads to save registers and waits with ~1 chunk of slack)
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + DQD < NCH) load(c + DQD, (c + DQD) % (DQD + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      if (c & 1) acc1 = mfma16(af[c % (DQD + 1)], bfv[c % (DQD + 1)], acc1);
+      else acc0 = mfma16(af[c % (DQD + 1)], bfv[c % (DQD + 1)], acc0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     const f32x4 acc = acc0 + acc1;
     const int q = tq * FQ + qb * 16 + p16;
     if (q < p.Sq) {
       bf16* op = (bf16*)pb.dq + ((long long)b * p.Sq + q) * pb.lddq + h * 64 + db * 16 + 4 * g16;
       *(bf16x4*)op = f4_to_bf4(f32x4{acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale});
     }
+  };
+  auto dq_tile = [&](int tq) {
+    if (nkc <= 14) dq_tile_n(tq, std::integral_constant<int, 14>{}); else dq_tile_n(tq, std::integral_constant<int, 16>{});
   };
   // S, P, dS of tile t for the wave's key blocks; dV, dK accumulate; dS goes to the image of tile t
   auto s_tile = [&](int t) {
@@ -1086,6 +1190,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
         st = mfma32(tile_frag(sQ, 0, ks, lo), kf, st);
         dp = mfma32(tile_frag(sG, 0, ks, lo), vf[kb][ks], dp);
       }
+      ATTN_STAMP(1, stamp_on && t == 5, 23 + 3 * kb);
       if (nval[kb] < 32) {                           // partially valid block: masked keys get p = 0, dS = 0
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -1137,20 +1242,27 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
           dv[kb][dt] = mfma32(tile_frag_tr(sG, 16 * a, dt, lo), pf, dv[kb][dt]);
           dk[kb][dt] = mfma32(tile_frag_tr(sQ, 16 * a, dt, lo), df, dk[kb][dt]);
         }
+        ATTN_STAMP(1, stamp_on && t == 5, 24 + 3 * kb + a);
       }
     }
   };
   // Iteration t: the dQ of tile t-1 (LDS-read heavy) and the S / dV / dK work of tile t (MFMA + exp heavy) are independent, so
   // the two waves of a SIMD (w and w + 4) run them in OPPOSITE order: one reads while the other computes.
   for (int t = 0; t <= ntiles; ++t) {
+    ATTN_STAMP(1, stamp_on && t == 5, 20);
     if (t + 1 < ntiles) stage_q(t + 1, (t + 1) & 1);
+    ATTN_STAMP(1, stamp_on && t == 5, 21);
 #ifndef FUSED_KO
 #define FUSED_KO 0
 #endif
     if (wave < 4 && t > 0 && !(FUSED_KO & 1)) dq_tile(t - 1);
+    ATTN_STAMP(1, stamp_on && t == 5, 22);
     if (t < ntiles && !(FUSED_KO & 2)) s_tile(t);
+    ATTN_STAMP(1, stamp_on && t == 5, 29);
     if (wave >= 4 && t > 0 && !(FUSED_KO & 1)) dq_tile(t - 1);
+    ATTN_STAMP(1, stamp_on && t == 5, 30);
     tile_barrier();                                    // dS image of tile t complete, Q / dO tile t+1 landed, tile t's buffers free
+    ATTN_STAMP(1, stamp_on, 3 + t);
   }
 
   // ---- dK, dV of the wave's keys.  From registers ("lane = key, registers = 4 consecutive head dims") a store instruction writes 8 bytes into each
@@ -1177,6 +1289,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
         }
     }
     __syncthreads();
+    ATTN_STAMP(1, stamp_on, 4 + ntiles);
     const int pc = tid & 7;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1194,6 +1307,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
       *(bf16x8*)(okp + lc * 8) = *(const bf16x8*)(sK + row * 128 + pc * 16);
       *(bf16x8*)(ovp + lc * 8) = *(const bf16x8*)(sV2 + row * 128 + pc * 16);
     }
+    ATTN_STAMP(1, stamp_on, 5 + ntiles);
     return;
   }
 #pragma unroll
@@ -1737,6 +1851,11 @@ int mart_attn_split_launch(const mart_attn_f32_desc* d, void* stream) {
   return 0;
 }
 
+#ifdef ATTN_STAMPS
+extern "C" int mart_debug_attn_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 2 * 8 * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 extern "C" int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream) {
   if (int rc = check_fwd(d)) return rc;
   if (int rc = set_attrs()) return rc;
@@ -1754,7 +1873,7 @@ extern "C" int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream) {
 #endif
   if (text) hipLaunchKernelGGL((attn_fwd_k<true, 1>), dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
   else if (tpw == 2 && d->Sq > 128) hipLaunchKernelGGL((attn_fwd_k<false, 2>), dim3((d->Sq + 255) / 256, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
-  else hipLaunchKernelGGL((attn_fwd_k<false, 1>), dim3((d->Sq + 127) / 128, d->nh, d->B), dim3(NTH), LDS_BYTES, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL((attn_fwd_k<false, 1>), dim3((d->Sq + 32 * FWD_NW - 1) / (32 * FWD_NW), d->nh, d->B), dim3(64 * FWD_NW), LDS_BYTES, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();
   return 0;
 }
