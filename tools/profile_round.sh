@@ -20,6 +20,8 @@ CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing -
 bash tools/pmc.sh "gemm_nt_kernel<256" gpurun_out/${TAG}_pmc_gemm_nt.txt -- $CMD > /dev/null 2>&1
 python tools/pmc_to_json.py gpurun_out/${TAG}_pmc_gemm_nt.txt gpurun_out/${TAG}_pmc_gemm_nt.json "MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0 rocprofv3 --pmc <group> -- $CMD (one pass per counter group: tools/pmc.sh)" | cut -c1-300
 bash tools/pmc.sh "gemm_tn8" gpurun_out/${TAG}_pmc_gemm_tn.txt -- $CMD > /dev/null 2>&1
+bash tools/pmc.sh "attn_fwd_k<false" gpurun_out/${TAG}_pmc_attn_fwd.txt -- $CMD > /dev/null 2>&1
+bash tools/pmc.sh "attn_bwd_fused" gpurun_out/${TAG}_pmc_attn_bwd_fused.txt -- $CMD > /dev/null 2>&1
 unset MART_OVERLAP_WGRAD MART_TWO_STREAM
 # the bench line last of the three, so that its roofline.traffic is THIS run's PMC file (bench.py reads profiles/<TAG>_pmc_gemm_nt.json and checks the source hash)
 cp gpurun_out/${TAG}_pmc_gemm_nt.json profiles/${TAG}_pmc_gemm_nt.json
