@@ -216,3 +216,51 @@ def test_the_checker_flags_the_round_2_to_4_wait_placement(nk):
     assert raw and all(b[1] in ("A0", "B0", "B1") for b in raw)          # the lagging row waits in the interval in which the leading row already reads
     assert all("row 0" in b[3] and "row 1" in b[4] for b in raw)
     assert not [b for b in bad if b[0] == "WAR"]
+
+
+# ---- the attention kernels' workgroup -> (part, head, batch) map (csrc/attention.hip: wg_id), restated: the division-free form of round 5 against the
+# quotient / remainder form of rounds 1-4.  Workgroups are dealt to the 8 XCDs round-robin by linear id L = x + G (y + nh z); in groups of 8 G ids the
+# parts of ONE (batch, head) pair are the ids j, 8 + j, 16 + j, ... (same XCD): part = r >> 3, pair = 8 group + (r & 7), r = L mod 8 G.
+def _wg_id_div(x, y, z, G, nh, B):
+    L, pairs = x + G * (y + nh * z), nh * B
+    if G == 1 or pairs & 7:
+        return (x, y, z)
+    group = L // (8 * G)
+    r = L - group * 8 * G
+    pair = group * 8 + (r & 7)
+    return (r >> 3, pair % nh, pair // nh)
+
+
+def _wg_id_nodiv(x, y, z, G, nh, B):
+    if G == 1 or (nh * B) & 7:
+        return (x, y, z)
+    P = y + nh * z
+    c = P & 7
+    r = G * c + x                      # = L mod 8 G, because x < G; L div 8 G = P >> 3
+    hh, bb = y + ((r & 7) - c), z      # pair = P + ((r & 7) - c): fewer than 8 positions away from (y, z)
+    while hh < 0:
+        hh, bb = hh + nh, bb - 1
+    while hh >= nh:
+        hh, bb = hh - nh, bb + 1
+    return (r >> 3, hh, bb)
+
+
+@pytest.mark.parametrize("G,nh,B", [(4, 12, 256), (4, 12, 8), (2, 12, 8), (3, 4, 6), (4, 2, 4), (5, 1, 8), (7, 3, 8), (4, 12, 2), (2, 16, 3), (1, 12, 8), (4, 12, 3)])
+def test_attention_workgroup_map_without_division_is_the_old_map_and_a_bijection(G, nh, B):
+    seen = set()
+    for z in range(B):
+        for y in range(nh):
+            for x in range(G):
+                a, b = _wg_id_div(x, y, z, G, nh, B), _wg_id_nodiv(x, y, z, G, nh, B)
+                assert a == b, (x, y, z, a, b)
+                assert 0 <= b[0] < G and 0 <= b[1] < nh and 0 <= b[2] < B
+                seen.add(b)
+    assert len(seen) == G * nh * B
+    if G > 1 and (nh * B) % 8 == 0:      # the point of the map: the G parts of a pair have linear ids 8 apart, i.e. land on one XCD
+        by_pair = {}
+        for z in range(B):
+            for y in range(nh):
+                for x in range(G):
+                    part, h, b = _wg_id_nodiv(x, y, z, G, nh, B)
+                    by_pair.setdefault((h, b), set()).add((x + G * (y + nh * z)) % 8)
+        assert all(len(v) == 1 for v in by_pair.values())
