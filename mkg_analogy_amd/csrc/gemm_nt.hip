@@ -1086,6 +1086,40 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   MART_CHECK(!d->b_blocked || (d->N % 256 == 0 && !d->b_rows && (d->batch <= 1 || d->stride_b == 0)), "gemm_nt: b_blocked needs N % 256 == 0, no b_rows, shared B");
   MART_CHECK((long long)(d->a_rows ? d->a_src_rows : d->M) * d->lda < (1LL << 32) && (long long)(d->b_rows ? d->b_src_rows : d->N) * d->ldb < (1LL << 32),
              "gemm_nt: operand (or the table a row gather indexes: a_src_rows / b_src_rows) too large for 32-bit element offsets");
+#ifndef NT_SPLIT_ROUNDS
+#define NT_SPLIT_ROUNDS 0
+#endif
+  // Tile quantisation experiment (round 5; variant builds with -DNT_SPLIT_ROUNDS=1): a product of 1.0-1.6 rounds of 256x256 tiles on the 256 CUs -- the
+  // five N = 768 products per layer at the reference's default geometry, M = 25 344: 297 tiles -- pays two rounds when it runs alone.  Here it runs as
+  // ONE full round of large tiles over the first rows and 128x128 tiles (two workgroups per CU) over the rest: two launches on the same stream, every
+  // row-indexed operand advanced by the rows of the first part.  Alone: the eight products of a layer 0.888 -> 0.824 ms (-7 %, tools/bench_nt_p49.py).
+  // In the step: 34.61 / 34.63 ms against 34.55 / 34.64 without it (same box, alternating) -- NOTHING: the weight-gradient and text queues already
+  // run in the CUs a second round leaves idle.  Not shipped.
+  if (NT_SPLIT_ROUNDS && d->tile_cfg == 0 && d->batch <= 1 && !d->a_rows && !d->b_blocked && !d->c_split3 && d->N % 256 == 0 && d->M > 256) {
+    const int tn = d->N / 256, t256s = ((d->M + 255) / 256) * tn;
+    const int rows_big = (256 / tn) * 256;
+    if (t256s > 256 && t256s <= 410 && rows_big > 0 && rows_big < d->M) {
+      if (d->K + d->K2 <= 1024) {                      // short contractions (12 K-tiles): the small tile alone fills the chip better than one round + a tail
+        mart_gemm_nt_desc ds = *d;                     // (out-proj forward at M = 25 344: 0.053 ms against 0.060 split and 0.069 on 256x256 tiles)
+        ds.tile_cfg = 128;
+        return mart_gemm_nt(&ds, stream);
+      }
+      mart_gemm_nt_desc d1 = *d, d2 = *d;
+      d1.M = rows_big; d1.tile_cfg = 256;
+      const long long r = rows_big;
+      const int ldres = d->ldres ? d->ldres : d->ldc, ldc2 = d->ldc2 ? d->ldc2 : d->ldc;
+      auto adv = [](const void* ptr, long long bytes) -> const void* { return ptr ? (const void*)((const char*)ptr + bytes) : nullptr; };
+      d2.M = d->M - rows_big; d2.tile_cfg = 128;
+      d2.A = adv(d->A, r * d->lda * 2); d2.A2 = adv(d->A2, r * d->lda * 2);
+      d2.preact = (void*)adv(d->preact, r * d->ldc * 2);
+      d2.mulz = adv(d->mulz, r * ldres * 2);
+      d2.res_f32 = (const float*)adv(d->res_f32, r * ldres * 4); d2.res_bf16 = adv(d->res_bf16, r * ldres * 2);
+      d2.C = (void*)adv(d->C, r * d->ldc * (d->c_f32 ? 4 : 2));
+      d2.C2 = (void*)adv(d->C2, r * ldc2 * 2);
+      const int rc = mart_gemm_nt(&d1, stream);
+      return rc ? rc : mart_gemm_nt(&d2, stream);
+    }
+  }
   Args a;
   a.A = (const bf16*)d->A; a.B = (const bf16*)d->B; a.A2 = (const bf16*)d->A2; a.B2 = (const bf16*)d->B2;
   a.lda = d->lda; a.ldb = d->ldb; a.M = d->M; a.N = d->N; a.K = d->K; a.K2 = d->K2;
