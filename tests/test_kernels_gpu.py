@@ -414,7 +414,8 @@ def _heads(x, B, S, nh):          # [B*S, nh*64] -> [B,nh,S,64]
                                         # round 5: the peeled last key tile runs ONE 32-key block when it holds <= 32 keys (key counts 1 / 31 / 32 / 33 past a multiple
                                         # of 64, with and without a prefix), and the fused backward's dQ pipeline is compiled for 14 or 16 chunks of 32 keys
                                         (1, 2, 65, 0), (1, 2, 95, 0), (1, 2, 96, 0), (1, 2, 97, 0), (2, 2, 129, 32), (2, 2, 128, 32), (1, 2, 393, 0),
-                                        (1, 2, 448, 0), (1, 1, 449, 0), (1, 2, 448, 64), (1, 2, 416, 32)])
+                                        (1, 2, 448, 0), (1, 1, 449, 0), (1, 2, 448, 64), (1, 2, 416, 32),
+                                        (1, 2, 130, 20)])       # a prefix that is no multiple of 8: per-lane K staging in the fused backward, general forward instantiation
 def test_attention_vision(ops, B, nh, S, Lp):
     H = nh * 64
     qkv = rnd(B * S, 3 * H, seed=1, scale=1.0)
