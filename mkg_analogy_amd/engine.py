@@ -712,6 +712,9 @@ class UnimoEngine:
             self._ln_bwd(dy_bf16=dh1, s=s["x"], mean=s["m1"], rstd=s["r1"], gamma=st.m(v + "layer_norm1.weight"), M=Mv, H=H, add_f32=dx1,
                        add2_f32=side_next, ds_f32=dxv, ds_bf16=dxvb, bf16_total=True, dgamma=st.g(v + "layer_norm1.weight"),
                        dbeta=st.g(v + "layer_norm1.bias"))
+            if early:
+                T["A_side"][l - 1] = True                              # consumed: keep the "a side buffer existed" mark, drop the [Mv, H] f32 tensor
+                del side_next
             T["ev_vdone"] = self._main_record()
             if l > 0 and not early:
                 text_A(l - 1)                                          # (in-place form: its fusion backward adds into the dxv written just above)
