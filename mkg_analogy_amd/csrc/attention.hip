@@ -1288,12 +1288,18 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
           *(bf16x4*)(sV2 + off) = f4_to_bf4(f32x4{dv[kb][dt][4 * qd], dv[kb][dt][4 * qd + 1], dv[kb][dt][4 * qd + 2], dv[kb][dt][4 * qd + 3]});
         }
     }
-    __syncthreads();
+#ifndef FUSED_EPI_WAVE
+#define FUSED_EPI_WAVE 1
+#endif
+    // FUSED_EPI_WAVE: every wave stores the 64 rows it staged itself -- the images were dead for ALL waves at the loop's last barrier, so the round trip
+    // is wave-private and needs no workgroup barrier (rounds 3-4: rows dealt across the workgroup behind a __syncthreads)
+    if (FUSED_EPI_WAVE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
     ATTN_STAMP(1, stamp_on, 4 + ntiles);
     const int pc = tid & 7;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int row = 64 * i + (tid >> 3);
+      const int row = FUSED_EPI_WAVE ? wave * 64 + 8 * i + (lane >> 3) : 64 * i + (tid >> 3);
       if (row >= Stot) continue;
       const int lc = pc ^ swz_key(row);
       bf16 *okp, *ovp;
