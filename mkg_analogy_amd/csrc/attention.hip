@@ -1041,9 +1041,15 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
   };
   stage_q(0, 0);
   {
-    f32x4* z = (f32x4*)(smem + F_OFF_DS);            // dS images start as zeros: key chunks past the last key contribute nothing to dQ
+    // dS images: the rows of key blocks past the last key are never written and must read as zeros in the dQ contraction (every row of a block that
+    // holds a key is rewritten each tile, masked keys as zeros).  A wave-instruction covers 16 image rows: skipped when all of them get written.
+    f32x4* z = (f32x4*)(smem + F_OFF_DS);
+    const int first_dead = 32 * ((Stot + 31) / 32);
 #pragma unroll
-    for (int i = 0; i < (2 * F_DS / 16) / 512; ++i) z[i * 512 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < (2 * F_DS / 16) / 512; ++i) {
+      const int row_hi = (((i * 512 + wave * 64 + 63) * 16) & (F_DS - 1)) >> 6;      // last row this wave-instruction touches (wave-uniform)
+      if (row_hi >= first_dead) z[i * 512 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
   {
     // row statistics.  delta = rowsum(dO * O): EIGHT lanes per query row, one 16-byte chunk of O and dO each, so that a load instruction reads whole
@@ -1078,7 +1084,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
     }
     {
       const float l = tid < p.Sq ? p.lse[((long long)b * p.nh + h) * p.Sq + tid] : 1.0e30f;   // rows past Sq: p = exp2(x - 1e30) = 0, they contribute nothing
-      sLse[tid] = FUSED_CINIT ? -l / (p.scale * LOG2E) : l;
+      sLse[tid] = FUSED_CINIT ? -l * (1.0f / (p.scale * LOG2E)) : l;
     }
   }
   // own keys: V fragments in registers, validity
@@ -1297,21 +1303,21 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_k(mart_attn_bwd_desc pb) {
     else __syncthreads();
     ATTN_STAMP(1, stamp_on, 4 + ntiles);
     const int pc = tid & 7;
+    // destinations = (batch, head) base pointers (64-bit, once) + 32-bit element offsets per row (the row-by-row 64-bit products were ~130 VALU per wave here)
+    bf16* const dk_b = (bf16*)pb.dk + ((long long)b * p.Sk) * pb.lddk + h * 64;
+    bf16* const dv_b = (bf16*)pb.dv + ((long long)b * p.Sk) * pb.lddv + h * 64;
+    bf16* const dpk_b = p.Lp ? (bf16*)pb.dpk + ((long long)b * p.Lp) * pb.lddp + h * 64 : dk_b;
+    bf16* const dpv_b = p.Lp ? (bf16*)pb.dpv + ((long long)b * p.Lp) * pb.lddp + h * 64 : dv_b;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = FUSED_EPI_WAVE ? wave * 64 + 8 * i + (lane >> 3) : 64 * i + (tid >> 3);
       if (row >= Stot) continue;
       const int lc = pc ^ swz_key(row);
-      bf16 *okp, *ovp;
-      if (row < p.Lp) {
-        okp = (bf16*)pb.dpk + ((long long)b * p.Lp + row) * pb.lddp + h * 64;
-        ovp = (bf16*)pb.dpv + ((long long)b * p.Lp + row) * pb.lddp + h * 64;
-      } else {
-        okp = (bf16*)pb.dk + ((long long)b * p.Sk + (row - p.Lp)) * pb.lddk + h * 64;
-        ovp = (bf16*)pb.dv + ((long long)b * p.Sk + (row - p.Lp)) * pb.lddv + h * 64;
-      }
-      *(bf16x8*)(okp + lc * 8) = *(const bf16x8*)(sK + row * 128 + pc * 16);
-      *(bf16x8*)(ovp + lc * 8) = *(const bf16x8*)(sV2 + row * 128 + pc * 16);
+      const bool pre = row < p.Lp;
+      const unsigned ok_off = pre ? (unsigned)(row * pb.lddp + lc * 8) : (unsigned)((row - p.Lp) * pb.lddk + lc * 8);
+      const unsigned ov_off = pre ? ok_off : (unsigned)((row - p.Lp) * pb.lddv + lc * 8);
+      *(bf16x8*)((pre ? dpk_b : dk_b) + ok_off) = *(const bf16x8*)(sK + row * 128 + pc * 16);
+      *(bf16x8*)((pre ? dpv_b : dv_b) + ov_off) = *(const bf16x8*)(sV2 + row * 128 + pc * 16);
     }
     ATTN_STAMP(1, stamp_on, 5 + ntiles);
     return;
