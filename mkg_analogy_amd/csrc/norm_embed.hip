@@ -111,7 +111,7 @@ __global__ __launch_bounds__(TPB) void ln_fwd_k(mart_ln_fwd_desc p) {
 // multiplied by 0), every wave runs the same trip count, and the waits are counted: two rows are really in flight per wave.
 template <int VMAX, int OUT = 0>      // OUT: 0 = bf16 output, 1 = fp16 output (out_h), 2 = both (the fp16 forward operand and the bf16 one the backward pass reads)
 __global__ __launch_bounds__(TPB) void ln_fwd_fast_k(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                     int M, bf16* __restrict__ out, float* __restrict__ mean_o, float* __restrict__ rstd_o, bf16* __restrict__ out_h = nullptr) {
+                                                     int M, bf16* __restrict__ out, float* __restrict__ mean_o, float* __restrict__ rstd_o, bf16* __restrict__ out_h = nullptr, int rev = 0) {
   constexpr int H = VMAX * 256;
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(TPB) void ln_fwd_fast_k(const float* __restrict__ x
   for (int v = 0; v < VMAX; ++v) { gam[v] = *(const f32x4*)(gamma + (v * 64 + lane) * 4); bet[v] = *(const f32x4*)(beta + (v * 64 + lane) * 4); }
   const int iters = (M + nwaves - 1) / nwaves;
   float keep_mean = 0.f, keep_rstd = 0.f;                 // lane k keeps the statistics of the wave's k-th row (written after the loop: no store under a lane predicate inside it)
-  auto row_of = [&](int k) { return min(wave_g + k * nwaves, M - 1); };
+  // rev: the sweep runs from the LAST row to the first -- the rows the producing kernel wrote last are the ones the memory-side cache still holds
+  auto row_of = [&](int k) { const int r = min(wave_g + k * nwaves, M - 1); return rev ? M - 1 - r : r; };
   auto fetch = [&](int k, f32x4 (&r)[VMAX]) {
     const float* src = x + (long long)row_of(k) * H + lane * 4;
 #pragma unroll
@@ -158,7 +159,10 @@ __global__ __launch_bounds__(TPB) void ln_fwd_fast_k(const float* __restrict__ x
     fetch(k + 2, ra);
     process(k + 1, rb);
   }
-  if (lane < iters && wave_g + lane * nwaves < M) { mean_o[wave_g + lane * nwaves] = keep_mean; rstd_o[wave_g + lane * nwaves] = keep_rstd; }   // iters <= 64 (launcher)
+  if (lane < iters && wave_g + lane * nwaves < M) {                                      // iters <= 64 (launcher)
+    const int r = wave_g + lane * nwaves, m = rev ? M - 1 - r : r;
+    mean_o[m] = keep_mean; rstd_o[m] = keep_rstd;
+  }
 }
 
 // ------------------------------------------------------------------ LayerNorm backward
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
 template <int VMAX, bool ADD2 = false>     // ADD2: a second f32 residual operand (the fusion op's d(visual) side buffer, engine.backward)
 __global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma, int M, float* __restrict__ ds_f32, bf16* __restrict__ ds_bf16,
-                                                     float* __restrict__ ws, const float* __restrict__ add2 = nullptr) {
+                                                     float* __restrict__ ws, const float* __restrict__ add2 = nullptr, int rev = 0) {
   constexpr int H = VMAX * 256;
   __shared__ float red[WPB][2][VMAX * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy
   for (int v = 0; v < VMAX; ++v) { dg[v] = f32x4{0.f, 0.f, 0.f, 0.f}; db[v] = dg[v]; gam[v] = *(const f32x4*)(gamma + (v * 64 + lane) * 4); }
   const int iters = (M + nwaves - 1) / nwaves;
   struct Row { f32x4 a[VMAX], a2[ADD2 ? VMAX : 1], s[VMAX]; bf16x4 d[VMAX]; float mean, rstd; };
-  auto row_of = [&](int k) { return min(wave_g + k * nwaves, M - 1); };
+  auto row_of = [&](int k) { const int r = min(wave_g + k * nwaves, M - 1); return rev ? M - 1 - r : r; };     // rev: last row first (see ln_fwd_fast_k)
   auto fetch = [&](int k, Row& r) {
     const int m = row_of(k);
     const long long o = (long long)m * H + lane * 4;
@@ -792,7 +796,8 @@ extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
     const int gmin = (d->M + WPB * 64 - 1) / (WPB * 64);          // at most 64 rows per wave (their statistics live in one register across the lanes)
     if (g < gmin) g = gmin;
     const int ov = d->out_f16 ? (d->out_bf16 ? 2 : 1) : 0;
-#define LN_FAST(V_, O_) hipLaunchKernelGGL((ln_fwd_fast_k<V_, O_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, d->x_f32, d->gamma, d->beta, d->eps, d->M, (bf16*)d->out_bf16, d->mean, d->rstd, (bf16*)d->out_f16)
+    const int rev = getenv("MART_LN_REV") ? atoi(getenv("MART_LN_REV")) & 1 : 0;
+#define LN_FAST(V_, O_) hipLaunchKernelGGL((ln_fwd_fast_k<V_, O_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, d->x_f32, d->gamma, d->beta, d->eps, d->M, (bf16*)d->out_bf16, d->mean, d->rstd, (bf16*)d->out_f16, rev)
     if (d->H == 768) { if (ov == 0) LN_FAST(3, 0); else if (ov == 1) LN_FAST(3, 1); else LN_FAST(3, 2); }
     else { if (ov == 0) LN_FAST(4, 0); else if (ov == 1) LN_FAST(4, 1); else LN_FAST(4, 2); }
 #undef LN_FAST
@@ -820,8 +825,9 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
                           d->add_f32 != d->ds_f32 && d->s != d->ds_f32 && d->dy_bf16 != d->ds_bf16 && d->add2_f32 != d->ds_f32;   // clamped duplicate rows re-read their inputs: no in-place operands
   const int cap = cap_env ? cap_env : 512;      // two workgroups per CU in one round: 6.1 TB/s for the straight-line kernel (768: 5.9, 384: 5.6, 256: 5.0), 5.66 for the general one
   if (g > cap) g = cap;
+  const int revb = getenv("MART_LN_REV") ? (atoi(getenv("MART_LN_REV")) >> 1) & 1 : 0;
   MART_CHECK(!d->ws || d->ws_bytes >= (long long)g * 2 * d->H * (long long)sizeof(float), "ln_bwd: workspace too small (768 * 2 * H floats always suffice)");
-#define LNB_FAST(V_, A_) hipLaunchKernelGGL((ln_bwd_fast_k<V_, A_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws, d->add2_f32)
+#define LNB_FAST(V_, A_) hipLaunchKernelGGL((ln_bwd_fast_k<V_, A_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws, d->add2_f32, revb)
   if (fast_shape && d->H == 768) { if (d->add2_f32) LNB_FAST(3, true); else LNB_FAST(3, false); }
   else if (fast_shape) { if (d->add2_f32) LNB_FAST(4, true); else LNB_FAST(4, false); }
 #undef LNB_FAST

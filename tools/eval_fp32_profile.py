@@ -18,7 +18,7 @@ model, lit, cfg = bench.build(16, seed=0, device=dev, entity_head=D.N_ENT)
 batch = D.make_batch(256, 64, seed=1234, device=dev, n_labels=D.N_ENT)
 tr = Trainer(max_epochs=1, max_steps=10)
 tr._setup(lit, [None] * 10)
-for prec in ("bf16", "fp32"):
+for prec in os.environ.get("EVAL_PRECS", "bf16,fp32").split(","):       # EVAL_PRECS=fp32: a trace of the fp32-accurate passes only
     lit.args.eval_precision = prec
     tr.validate(lit, [batch])
     torch.cuda.synchronize()
