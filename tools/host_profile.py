@@ -8,7 +8,7 @@ from mkg_analogy_amd.trainer import Trainer
 ops.require_gpu()
 dev = torch.device("cuda", 0)
 B = int(os.environ.get("B", 256))
-model, lit, cfg = bench.build(16, seed=0, device=dev, backbone="mkgformer")
+model, lit, cfg = bench.build(int(os.environ.get("PATCH", 16)), seed=0, device=dev, backbone="mkgformer")     # PATCH=32: the 49-patch geometry
 batch = D.make_batch(B, 64, seed=1234, device=dev)
 tr = Trainer(max_epochs=1, max_steps=1000, world_size=1)
 tr._setup(lit, [None] * 1000)
