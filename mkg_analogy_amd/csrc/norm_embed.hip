@@ -796,7 +796,7 @@ extern "C" int mart_ln_fwd(const mart_ln_fwd_desc* d, void* stream) {
     const int gmin = (d->M + WPB * 64 - 1) / (WPB * 64);          // at most 64 rows per wave (their statistics live in one register across the lanes)
     if (g < gmin) g = gmin;
     const int ov = d->out_f16 ? (d->out_bf16 ? 2 : 1) : 0;
-    const int rev = getenv("MART_LN_REV") ? atoi(getenv("MART_LN_REV")) & 1 : 0;
+    static const int rev = getenv("MART_LN_REV") ? atoi(getenv("MART_LN_REV")) & 1 : 0;       // sweep from the last row (tools/mall_probe.py: neutral, off)
 #define LN_FAST(V_, O_) hipLaunchKernelGGL((ln_fwd_fast_k<V_, O_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, d->x_f32, d->gamma, d->beta, d->eps, d->M, (bf16*)d->out_bf16, d->mean, d->rstd, (bf16*)d->out_f16, rev)
     if (d->H == 768) { if (ov == 0) LN_FAST(3, 0); else if (ov == 1) LN_FAST(3, 1); else LN_FAST(3, 2); }
     else { if (ov == 0) LN_FAST(4, 0); else if (ov == 1) LN_FAST(4, 1); else LN_FAST(4, 2); }
@@ -825,7 +825,7 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
                           d->add_f32 != d->ds_f32 && d->s != d->ds_f32 && d->dy_bf16 != d->ds_bf16 && d->add2_f32 != d->ds_f32;   // clamped duplicate rows re-read their inputs: no in-place operands
   const int cap = cap_env ? cap_env : 512;      // two workgroups per CU in one round: 6.1 TB/s for the straight-line kernel (768: 5.9, 384: 5.6, 256: 5.0), 5.66 for the general one
   if (g > cap) g = cap;
-  const int revb = getenv("MART_LN_REV") ? (atoi(getenv("MART_LN_REV")) >> 1) & 1 : 0;
+  static const int revb = getenv("MART_LN_REV") ? (atoi(getenv("MART_LN_REV")) >> 1) & 1 : 0;
   MART_CHECK(!d->ws || d->ws_bytes >= (long long)g * 2 * d->H * (long long)sizeof(float), "ln_bwd: workspace too small (768 * 2 * H floats always suffice)");
 #define LNB_FAST(V_, A_) hipLaunchKernelGGL((ln_bwd_fast_k<V_, A_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws, d->add2_f32, revb)
   if (fast_shape && d->H == 768) { if (d->add2_f32) LNB_FAST(3, true); else LNB_FAST(3, false); }

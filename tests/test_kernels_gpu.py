@@ -367,6 +367,17 @@ def test_layernorm_vision_stream_shapes(ops, M):
     assert torch.equal(dg, dg3) and torch.equal(db, db3) and torch.equal(ds, ds3) and torch.equal(dsb, dsb3), "run-to-run"
 
 
+def test_layernorm_reversed_sweep_knob():
+    """MART_LN_REV=3 (last row first in both straight-line LayerNorm kernels; read once per process, hence the child process): the
+    ragged-shape test above passes unchanged -- rows, statistics and the clamped duplicate rows map back to the same addresses."""
+    import os, subprocess, sys
+    if os.environ.get("MART_LN_REV"):
+        pytest.skip("already running under the knob")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k", "test_layernorm_vision_stream_shapes"],
+                       env=dict(os.environ, MART_LN_REV="3"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_dropout_add_layernorm(ops):
     M, H, p, seed = 300, 768, 0.1, 1234567
     res = rnd(M, H, seed=1, dtype=F32)
