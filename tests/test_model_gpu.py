@@ -64,8 +64,9 @@ def _stats(name, got, ref):
     return err, rel
 
 
-@pytest.mark.parametrize("patch,B,conditioned", [(32, 4, True), (16, 2, True), (32, 4, False)])
-def test_forward_backward_vs_oracle(patch, B, conditioned):
+@pytest.mark.parametrize("patch,B,conditioned,L", [(32, 4, True, 64), (16, 2, True, 64), (32, 4, False, 64),
+                                                    (32, 3, True, 37), (32, 1, True, 40)])    # ragged: odd batch, L no multiple of 8 / 32 (general fusion and attention paths)
+def test_forward_backward_vs_oracle(patch, B, conditioned, L):
     from mkg_analogy_amd import data_synth as D
     model, lit, cfg, vc = _product(patch, seed=3, conditioned=conditioned)
     sd = _oracle_sd(vc, 3, cfg["analogy_relation_ids"], conditioned)
@@ -75,7 +76,7 @@ def test_forward_backward_vs_oracle(patch, B, conditioned):
     assert w.shape[0] == D.VOCAB
     np.testing.assert_allclose(w[-1].detach().cpu().numpy(), sd["unimo.text_embeddings.word_embeddings.weight"][-1].numpy(), atol=1e-6)
 
-    batch = D.make_batch(B, 64, seed=11)
+    batch = D.make_batch(B, L, seed=11)
     ids = torch.tensor(cfg["analogy_entity_ids"])
     # ---------------- oracle (fp32, CPU)
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
