@@ -159,7 +159,12 @@ def test_forward_backward_vs_oracle(patch, B, conditioned, L):
         worst = max(worst, rel)
         flag = "" if rel < gtol else "   <-- CHECK"
         print(f"   grad {n}: rel-L2 {rel:.3e} cos {cos:.5f} |ref| {r.norm().item():.3e}{flag}")
-        if conditioned:
+        if conditioned and g.numel() == 1:
+            # scalar parameters (the adaptive attention weights): the gradient is ONE sum of B * heads * L * L signed terms, and with B = 1 it
+            # can cancel to 2e-5 where its neighbours are 5e-3 -- the bf16 noise of the sum (1e-5 .. 4e-5 absolute at every layer and batch
+            # size) is then a large fraction of the value; cosine similarity says nothing for one number.  Relative gate + that noise floor.
+            assert abs(float(g) - float(r)) < 0.12 * abs(float(r)) + 5e-5, (n, float(g), float(r))
+        elif conditioned:
             assert cos > 0.99 and rel < 0.12, n
         # (chaotic regime: gradients are printed for information only -- the map itself is not Lipschitz-stable under bf16)
     # tensors that get no gradient in the reference stay at zero
