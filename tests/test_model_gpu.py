@@ -65,7 +65,7 @@ def _stats(name, got, ref):
 
 
 @pytest.mark.parametrize("patch,B,conditioned,L", [(32, 4, True, 64), (16, 2, True, 64), (32, 4, False, 64),
-                                                    (32, 3, True, 37), (32, 1, True, 40)])    # ragged: odd batch, L no multiple of 8 / 32 (general fusion and attention paths)
+                                                    (32, 3, True, 37), (32, 1, True, 40), (32, 2, True, 160)])    # ragged: odd batch, L no multiple of 8 / 32 (general fusion and attention paths); L = 160: the long-stream two-pass text attention backward
 def test_forward_backward_vs_oracle(patch, B, conditioned, L):
     from mkg_analogy_amd import data_synth as D
     model, lit, cfg, vc = _product(patch, seed=3, conditioned=conditioned)
