@@ -12,7 +12,8 @@ from oracle import flava_oracle as FO  # noqa: E402
 from oracle import mkgformer_oracle as O  # noqa: E402
 
 
-def test_flava_forward_backward_vs_oracle():
+@pytest.mark.parametrize("B,L", [(2, 64), (3, 37)])        # (3, 37): odd batch, 431 multimodal tokens (no multiple of 8), general attention paths
+def test_flava_forward_backward_vs_oracle(B, L):
     from mkg_analogy_amd import data_synth as D
     from mkg_analogy_amd.lit_models import TransformerLitModel
     from mkg_analogy_amd.models import FlavaKGC, flava_config
@@ -32,8 +33,7 @@ def test_flava_forward_backward_vs_oracle():
     sd["flava.text_model.embeddings.word_embeddings.weight"] = torch.cat([W, W[torch.tensor(cfg["analogy_relation_ids"])].mean(0, keepdim=True)], 0)
     sd["cls.bias"] = torch.cat([sd0["cls.bias"], torch.zeros(1)])
     c = FO.FlavaCfg(vocab_size=D.VOCAB)
-    B = 2
-    batch = D.make_batch(B, 64, seed=17)
+    batch = D.make_batch(B, L, seed=17)
     ids = torch.tensor(cfg["analogy_entity_ids"])
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     trans_ref = FO.forward(sdg, c, batch["input_ids"], batch["attention_mask"], batch["token_type_ids"], batch["pixel_values"], batch["sep_idx"])
