@@ -206,8 +206,11 @@ class FlavaForMaskedLM(nn.Module):
         self.tie_weights()
 
     def finalize(self, device=None) -> FlatStore:
+        if self._store is not None and self._store.still_bound():
+            return self._store
         named = dict(self.named_parameters())
         if self._store is not None and self._store.owns(named):
+            self._store.bind(self)
             return self._store
         ops.require_gpu()
         if device is None:
@@ -225,6 +228,7 @@ class FlavaForMaskedLM(nn.Module):
             self.base_seed = 0x5EED      # dropout stream; distributed.GradSync hashes the rank into it
         if not hasattr(self, "precision"):
             self.precision = "bf16"
+        self._store.bind(self)
         return self._store
 
     @property

@@ -236,8 +236,11 @@ class UnimoForMaskedLM(nn.Module):
 
     def finalize(self, device=None) -> FlatStore:
         """Move the parameters into the flat fp32/bf16 buffers the kernels use (idempotent)."""
+        if self._store is not None and self._store.still_bound():
+            return self._store
         named = self._named()
         if self._store is not None and self._store.owns(named):
+            self._store.bind(self)
             return self._store
         ops.require_gpu()
         if device is None:
@@ -251,6 +254,7 @@ class UnimoForMaskedLM(nn.Module):
             m._buffers[name] = m._buffers[name].to(device)
         self._engine = UnimoEngine(self._store, self.vision_config, self.config)
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self._store.bind(self)
         return self._store
 
     @property

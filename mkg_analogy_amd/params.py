@@ -223,6 +223,32 @@ class FlatStore:
                 return False
         return len(named_params) == len(self.slots)
 
+    def bind(self, model: torch.nn.Module) -> None:
+        """Remember where every stored parameter hangs in ``model`` (module._parameters dict, key, object, address), so that the per-call
+        ownership check (:meth:`still_bound`) is 450 dict lookups instead of a ``named_parameters()`` walk of the module tree (0.4-1 ms, eight
+        times per training step)."""
+        by_id = {id(p): n for n, p in model.named_parameters(remove_duplicate=False) if n in self.slots}
+        base = self.master.data_ptr()
+        bound = []
+        for mod in model.modules():
+            for key, p in mod._parameters.items():
+                n = by_id.get(id(p)) if p is not None else None
+                if n is not None:
+                    bound.append((mod._parameters, key, p, base + 4 * self.slots[n].offset))
+        self._bound = bound
+
+    def still_bound(self) -> bool:
+        """True while every parameter object recorded by :meth:`bind` is still the one its module holds and still lives at its slot of the flat
+        buffer (a ``.to()`` / ``.float()`` / ``.data =`` or a re-assigned ``nn.Parameter`` fails this; the caller then falls back to the
+        full walk and, if needed, rebuilds the store).  Parameters ADDED to the model later are not part of the path this engine computes."""
+        b = getattr(self, "_bound", None)
+        if not b:
+            return False
+        for d, key, p, ptr in b:
+            if d.get(key) is not p or p.data_ptr() != ptr:
+                return False
+        return True
+
     def refresh_shadows(self) -> None:
         """master -> bf16 shadow and W^T shadow (after loading weights; AdamW keeps the first one fresh itself)."""
         from . import ops

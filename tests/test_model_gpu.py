@@ -498,3 +498,34 @@ def test_async_step_boundary_equals_in_order():
         res.append((st.master.clone(), st.shadow.clone(), st.shadow_t.clone(), tr.optimizer.m.clone(), tr.optimizer.v.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_store_ownership_fast_path_and_rebuild():
+    """``model.store`` / ``model.engine`` are touched eight times per step: the ownership check is FlatStore.still_bound() (dict lookups + addresses),
+    the named_parameters() walk only runs when that fails -- and it does fail, and the store is rebuilt, when the parameters move (.cpu() / .cuda())
+    or a Parameter object is re-assigned."""
+    from mkg_analogy_amd import data_synth as D
+    model, lit, cfg, vc = _product(32, seed=5, conditioned=True)
+    st = model.store
+    assert st.still_bound() and model.store is st and model.engine is model.engine
+    gb = {k: v.cuda() for k, v in D.make_batch(2, 64, seed=3).items()}
+    model.eval()
+    kw = dict(input_ids=gb["input_ids"], attention_mask=gb["attention_mask"], token_type_ids=gb["token_type_ids"], pixel_values=gb["pixel_values"],
+              sep_idx=gb["sep_idx"], return_dict=True)
+    with torch.no_grad():
+        _, t0 = model(**kw)
+    model.cpu(); model.cuda()                                     # every parameter leaves the flat buffer
+    assert not st.still_bound()
+    st2 = model.store
+    assert st2 is not st and st2.still_bound()
+    with torch.no_grad():
+        _, t1 = model(**kw)
+    assert torch.equal(t0, t1)
+    b = model.cls.predictions.transform.LayerNorm.bias
+    model.cls.predictions.transform.LayerNorm.bias = torch.nn.Parameter(b.detach().clone() + 1.0)      # a re-assigned Parameter object
+    assert not st2.still_bound()
+    st3 = model.store
+    assert st3 is not st2
+    with torch.no_grad():
+        _, t2 = model(**kw)
+    assert not torch.equal(t1, t2)                                 # the new bias is the one the kernels read
