@@ -70,6 +70,13 @@ typedef struct {
   int c_split3;                                                   /* C is bf16 [M, >= 3N]: the f32 result (after bias / activation) as the two-term split [hi | lo | hi]
                                                                      (mart_split_bf16x3 role 0) -- the A operand of the next GEMM of the fp32-accurate path, written by
                                                                      the epilogue instead of an f32 C plus a split pass.  256 x 256 tiles, N % 256 == 0, no other outputs */
+  /* LayerNorm folded into the product that consumes it (nn.LayerNorm -> nn.Linear: modeling_unimo.py:509 -> :223-225 and :518 -> :284-286), for forward
+   * passes that keep nothing for a backward pass:  LN(x) W^T + b = rstd (x (gamma o W)^T - mean s) + b'  (mart_ln_fold_prep makes gamma o W, s, b').
+   * row_stats (producer: f32 C + res_f32 + C2, N % 64 == 0): float [M][N / 64][2], per row and 64-column slice the (sum, sum of squares) of the f32 values
+   * written; mart_ln_stats_finalize turns them into mean / rstd.  ln_mean / ln_rstd [M], ln_colsum [N] (consumer: 16-bit C, plain or activation-only
+   * epilogue): A is the producer's C2, B the folded weight, bias the folded bias; the epilogue applies (acc - mean[m] s[n]) rstd[m] + bias[n]. */
+  float* row_stats;
+  const float* ln_mean; const float* ln_rstd; const float* ln_colsum;
 } mart_gemm_nt_desc;
 int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream);
 
@@ -138,6 +145,12 @@ int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream);
 int mart_ln_bwd_partials(int M);
 /* dgamma[c] += sum_g ws[g][0][c], dbeta[c] += sum_g ws[g][1][c] in a fixed order: the second half of mart_ln_bwd's deterministic path */
 int mart_ln_dgb_reduce(const float* ws, int partials, int H, float* dgamma, float* dbeta, void* stream);
+/* LayerNorm fold (mart_gemm_nt_desc.row_stats / ln_*; nn.LayerNorm -> nn.Linear, modeling_unimo.py:509 -> :223-225, :518 -> :284-286):
+ * mart_ln_fold_prep: from the f32 weight W [N, K], its bias (may be NULL) and the LayerNorm's gamma / beta [K]:  Wf = bf16(gamma o W),
+ * s[n] = sum_k Wf[n][k], bf[n] = bias[n] + sum_k beta[k] W[n][k].  mart_ln_stats_finalize: the [M][H / 64][2] partial sums a row_stats epilogue
+ * wrote -> mean [M], rstd [M] = 1 / sqrt(var + eps). */
+int mart_ln_fold_prep(const float* W, const float* bias, const float* gamma, const float* beta, void* Wf, float* s, float* bf, int N, int K, void* stream);
+int mart_ln_stats_finalize(const float* partials, int M, int H, float eps, float* mean, float* rstd, void* stream);
 
 /* ---------------------------------------------------------------- embeddings
  * pixels f32 [B,2,3,S,S] -> bf16 patch matrix [B*2*P, 3*p*p] (k = c*p*p + ky*p + kx): the im2col-free

@@ -25,7 +25,8 @@ class GemmNT(C.Structure):
                 ("bias", vp), ("bias2", vp), ("bias_by_brow", i32), ("act", i32), ("preact", vp),
                 ("mulz", vp), ("mul_act", i32), ("res_f32", vp), ("res_bf16", vp), ("ldres", i32),
                 ("alpha", f32), ("C", vp), ("ldc", i32), ("c_f32", i32), ("C2", vp), ("ldc2", i32), ("tile_cfg", i32), ("preact_grad", i32), ("b_blocked", i32), ("a_src_rows", i32), ("b_src_rows", i32),
-                ("in_f16", i32), ("c_f16", i32), ("c_split3", i32)]
+                ("in_f16", i32), ("c_f16", i32), ("c_split3", i32),
+                ("row_stats", vp), ("ln_mean", vp), ("ln_rstd", vp), ("ln_colsum", vp)]
 
 
 class GemmTN(C.Structure):
@@ -108,6 +109,8 @@ _SIGS = {
     "mart_ln_bwd": (i32, [C.POINTER(LnBwd), vp]),
     "mart_ln_bwd_partials": (i32, [i32]),
     "mart_ln_dgb_reduce": (i32, [vp, i32, i32, vp, vp, vp]),
+    "mart_ln_fold_prep": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "mart_ln_stats_finalize": (i32, [vp, i32, i32, f32, vp, vp, vp]),
     "mart_patchify": (i32, [vp, vp, i32, i32, i32, vp]),
     "mart_patchify_gather": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "mart_gather_images": (i32, [vp, vp, vp, i32, i32, vp]),
@@ -161,7 +164,7 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
-EXPECTED_ABI = 8            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
+EXPECTED_ABI = 9            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
 _lib = None
 
 

@@ -78,6 +78,8 @@ struct Args {
   void* C; int ldc; int c_f32;
   bf16* C2; int ldc2;
   int b_blocked;
+  float* row_stats;                  // F_STATS: [M][N / 64][2] partial (sum, sum of squares) of the f32 rows this epilogue writes
+  const float* ln_mean; const float* ln_rstd; const float* ln_colsum;   // F_LNFOLD: row statistics [M] and s[n] = sum_k B'[n][k] of the folded weight
   int stagger_ticks;                 // >0: first-wave workgroups start g*ticks (100 MHz) late, g = 0..7
   int dbg;                           // 1: skip the LDS-DMA after the first tile (timing experiment only)
 };
@@ -85,7 +87,12 @@ struct Args {
 // Epilogue feature mask of the specialised ("fast") instantiations.  EPI < 0 = the general epilogue (tails, gathers,
 // bf16 residual, unaligned rows).  Every large product of the step maps to one of the fast masks; their epilogues are a few
 // hundred bytes of straight-line vector code (the general one made the kernel 200 KB and instruction-fetch bound).
-enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32, F_PGRAD = 64, F_SPLIT3 = 128 };   // F_PGRAD: preact holds act'(z)
+enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32, F_PGRAD = 64, F_SPLIT3 = 128, F_STATS = 256, F_LNFOLD = 512 };   // F_PGRAD: preact holds act'(z)
+// LayerNorm folded into the product that consumes it (modeling_unimo.py:509 -> 223-225, :518 -> 284-286; forward passes that keep nothing for a
+// backward pass):  LN(x) W^T + b = rstd (x (gamma o W)^T - mean s) + b',  s[n] = sum_k (gamma o W)[n][k],  b' = b + W beta.
+// F_STATS (f32 residual epilogue: the PRODUCER of x): per row and 64-column wave slice, (sum, sum of squares) of the f32 values written -> row_stats;
+// mart_ln_stats_finalize turns the N / 64 partials of a row into mean / rstd.  F_LNFOLD (packed 16-bit epilogue: the CONSUMER): A is the bf16 copy of x
+// (the producer's C2), B the folded weight gamma o W, bias b'; the epilogue applies (acc - mean[m] s[n]) rstd[m] + b'[n] in MFMA layout.
 // F_SPLIT3 (with F_PREACT | F_C2, bf16): the three 16-bit outputs are the two-term split [hi | lo | hi] of the f32 result (mart_gemm_nt_desc.c_split3)
 
 // PERSIST: one workgroup per CU slot walks over its tiles; the first K-tile of the NEXT tile is put in flight before the
@@ -100,6 +107,15 @@ enum { F_RES = 1, F_MULZ = 2, F_PREACT = 4, F_ACT = 8, F_CF32 = 16, F_C2 = 32, F
 #ifndef GLDS_AUX_B
 #define GLDS_AUX_B 0
 #endif
+// sum over the 16 lanes of a DPP row (quad swaps, then the two mirrors), result in every lane
+__device__ __forceinline__ float row16_sum(float x) {
+  auto sh = [](float v, auto CTRL) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(CTRL)::value, 0xF, 0xF, true)); };
+  x += sh(x, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+  x += sh(x, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+  x += sh(x, std::integral_constant<int, 0x141>{});     // row_half_mirror
+  x += sh(x, std::integral_constant<int, 0x140>{});     // row_mirror
+  return x;
+}
 template <int DT> __device__ __forceinline__ f32x16 mm(bf16x8 a, bf16x8 b, f32x16 c) {
   if constexpr (DT == 0) return mfma32(a, b, c); else return mfma32h(a, b, c);
 }
@@ -738,14 +754,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
     const unsigned loff = ((unsigned)rr * (unsigned)p.ldc + (unsigned)rc) * 2u;
     const unsigned loff2 = ((unsigned)rr * (unsigned)p.ldc2 + (unsigned)rc) * 2u;
     const int mrem = p.M - (em0 + wm0);                            // rows of this sub-tile inside the matrix (wave-uniform)
+    f32x4 sq[TN][4];                                               // F_LNFOLD: s[n] of this lane's column quads
+    if constexpr ((EPI & F_LNFOLD) != 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sq[j][q] = *(const f32x4*)(p.ln_colsum + en0 + wn0 + ecol(j, q));
+    }
     auto run = [&](auto guard) {                                  // two straight-line arms, one wave-uniform row-guard test per sub-tile
     constexpr bool GUARD = decltype(guard)::value;
     auto block = [&](const int i, const f32x16 (&ai)[TN]) {
+      float lmean[TN], lrstd[TN];                                  // F_LNFOLD: statistics of the row this lane holds in acc[i][j] (rows past M: those of row M - 1, never stored)
+      if constexpr ((EPI & F_LNFOLD) != 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int m = em0 + wm0 + min(ro(i) + erow(j), mrem - 1);
+          lmean[j] = p.ln_mean[m]; lrstd[j] = p.ln_rstd[m];
+        }
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f32x4 v = f32x4{ai[j][4 * q], ai[j][4 * q + 1], ai[j][4 * q + 2], ai[j][4 * q + 3]} * p.alpha + bq[j][q];
+          f32x4 v = f32x4{ai[j][4 * q], ai[j][4 * q + 1], ai[j][4 * q + 2], ai[j][4 * q + 3]} * p.alpha;
+          if constexpr ((EPI & F_LNFOLD) != 0) v = (v - sq[j][q] * lmean[j]) * lrstd[j] + bq[j][q];
+          else v += bq[j][q];
           char* dst = epb + erow(j) * RS + ecol(j, q) * 2;
           if constexpr ((EPI & F_PGRAD) != 0) {
             f32x2 a0, a1, g0, g1;
@@ -885,6 +918,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
             for (int e = 0; e < 4; ++e) v[e] *= act_grad(z[e], ACTK);
           }
           if constexpr ((EPI & F_RES) != 0) v += pr[i % NPRE][it];
+          if constexpr ((EPI & F_STATS) != 0) {
+            static_assert(LPR == 16, "the row reduction below runs over the 16 lanes of a DPP row");
+            const float s1 = row16_sum((v[0] + v[1]) + (v[2] + v[3]));
+            const float s2 = row16_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+            // lanes 0 / 1 of the row's 16 write sum / sum of squares: one predicated 4-byte store per quad of rows
+            const int mrow = GUARD ? min(g + er, mrem - 1) : g + er;
+            float* sp = p.row_stats + ((long long)(em0 + wm0 + mrow) * (p.N >> 6) + ((en0 + wn0) >> 6)) * 2 + (lane & 1);
+            if ((lane & 14) == 0 && ok) *sp = (lane & 1) ? s2 : s1;
+          }
           if (ok) {
             if constexpr ((EPI & F_CF32) != 0) st_stream((f32x4*)adr(cbase, g, p.ldc, 4, lo_c), v);
             else st_stream((bf16x4*)adr(cbase, g, p.ldc, 2, lo_c), cvt_c<DT>(v));
@@ -1116,6 +1158,8 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
       d2.res_f32 = (const float*)adv(d->res_f32, r * ldres * 4); d2.res_bf16 = adv(d->res_bf16, r * ldres * 2);
       d2.C = (void*)adv(d->C, r * d->ldc * (d->c_f32 ? 4 : 2));
       d2.C2 = (void*)adv(d->C2, r * ldc2 * 2);
+      d2.row_stats = (float*)adv(d->row_stats, r * (d->N / 64) * 8);
+      d2.ln_mean = (const float*)adv(d->ln_mean, r * 4); d2.ln_rstd = (const float*)adv(d->ln_rstd, r * 4);
       const int rc = mart_gemm_nt(&d1, stream);
       return rc ? rc : mart_gemm_nt(&d2, stream);
     }
@@ -1142,6 +1186,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   a.dbg = 0;
   a.stagger_ticks = 0;
   a.b_blocked = d->b_blocked;
+  a.row_stats = d->row_stats; a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_colsum = d->ln_colsum;
 #ifdef MART_EXPERIMENTS
   if (cfg == 999) { a.dbg = 1; cfg = 256; }
   if (cfg >= 70000 && cfg < 80000) { a.stagger_ticks = cfg - 70000; cfg = 256; }
@@ -1211,7 +1256,9 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
     return L256(F_PREACT | F_C2 | F_SPLIT3, ACT_NONE);
   }
   const int mask = (two_acts ? (1 << 20) : 0) | (d->res_f32 ? F_RES : 0) | (d->mulz ? F_MULZ : 0) | (d->preact ? F_PREACT : 0) | (d->preact_grad ? F_PGRAD : 0) | (d->act != ACT_NONE ? F_ACT : 0) |
-                   (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0);
+                   (d->c_f32 ? F_CF32 : 0) | (d->C2 ? F_C2 : 0) | (d->row_stats ? F_STATS : 0) | (d->ln_mean ? F_LNFOLD : 0);
+  MART_CHECK(!d->ln_mean || (d->ln_rstd && d->ln_colsum && d->bias && !d->bias2 && !d->bias_by_brow), "gemm_nt: the LayerNorm fold needs ln_mean, ln_rstd, ln_colsum and the folded bias");
+  MART_CHECK(!d->row_stats || (d->c_f32 && d->res_f32 && d->C2 && d->N % 64 == 0 && batch == 1), "gemm_nt: row_stats is an option of the f32 + residual + bf16-copy epilogue (N a multiple of 64)");
   // Start stagger for the f32-residual epilogues (out-proj, fc2: 512 KB of HBM traffic per tile against a 12-48 K-tile loop):
   // every CU runs the same loop, so all 256 reach their epilogue together and the memory side sees a 134 MB burst per round
   // while the matrix cores idle.  Groups of workgroups that share an A panel start 3 us apart (8 phases): +15 % on the
@@ -1223,7 +1270,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
 #ifdef MART_EXPERIMENTS
     const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && (a.dbg == 0 || stamp_persist);
 #else
-    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ) && a.dbg == 0;
+    const bool persist = d->tile_cfg != 2562 && (mask == 0 || mask == F_MULZ || mask == F_LNFOLD) && a.dbg == 0;
 #endif
 #ifdef MART_EXPERIMENTS
 #define MART_FAST(M_, K_)                                                                   \
@@ -1251,6 +1298,9 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
     MART_FAST(F_MULZ, ACT_QGELU)
     MART_FAST(F_CF32 | F_ACT, ACT_GELU)           // head transform / precise-path GELU (f32 out)
     MART_FAST(F_CF32 | F_ACT, ACT_QGELU)
+    MART_FAST(F_CF32 | F_RES | F_C2 | F_STATS, ACT_NONE)   // LayerNorm fold, producer: residual stream + its bf16 copy + per-row partial sums
+    MART_FAST(F_LNFOLD, ACT_NONE)                  // LayerNorm fold, consumer: QKV on the bf16 copy of x and the folded weight
+    MART_FAST(F_ACT | F_LNFOLD, ACT_QGELU)         // ... fc1 (forward passes that keep nothing for a backward pass)
 #undef MART_FAST
     // fp16 operands: the forward linear layers of the text stream (engine.text_f16)
 #define MART_FAST_H(M_, K_, DT_, P_)                                                           \
@@ -1265,6 +1315,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
     MART_FAST_H(F_ACT, ACT_GELU, 2, false)                            // ... under no_grad
 #undef MART_FAST_H
   }
+  MART_CHECK((mask & (F_STATS | F_LNFOLD)) == 0, "gemm_nt: row_stats / the LayerNorm fold exist for full-width, 16-byte aligned bf16 products only (out-proj / fc2 -> QKV / fc1 of the vision stream)");
   // general epilogue: both loops exist in every build
 #define G256(DT_) (loop8 ? launch<256, 256, 2, 4, 2, -1, 0, false, (DT_)>(a, batch, st) : launch<256, 256, 2, 4, 4, -1, 0, false, (DT_)>(a, batch, st))
   if (dt == 1) return (cfg == 256 || cfg == 2561) ? G256(1) : launch<128, 128, 2, 2, 0, -1, 0, false, 1>(a, batch, st);

@@ -386,6 +386,41 @@ __global__ __launch_bounds__(1024) void ln_dgb_reduce_k(const float* __restrict_
   }
 }
 
+// ------------------------------------------------------------------ LayerNorm folded into the consuming product (gemm_nt F_STATS / F_LNFOLD)
+// Operands of the fold, from the f32 master weights: Wf = bf16(gamma o W) [N, K], s[n] = sum_k Wf[n][k] (of the ROUNDED values: the mean term of
+// x Wf^T then cancels against exactly what the matrix pipe summed), bf[n] = b[n] + sum_k beta[k] W[n][k].  One wave per output row.
+__global__ __launch_bounds__(TPB) void ln_fold_prep_k(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16* __restrict__ Wf, float* __restrict__ s, float* __restrict__ bf, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * WPB + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float ssum = 0.f, bsum = 0.f;
+  for (int k = lane * 4; k < K; k += 256) {
+    const f32x4 w = *(const f32x4*)(W + (long long)n * K + k), g = *(const f32x4*)(gamma + k), b = *(const f32x4*)(beta + k);
+    const bf16x4 wf = f4_to_bf4(w * g);
+    *(bf16x4*)(Wf + (long long)n * K + k) = wf;
+    const f32x4 r = bf4_to_f4(wf);
+    ssum += (r[0] + r[1]) + (r[2] + r[3]);
+    bsum += (w[0] * b[0] + w[1] * b[1]) + (w[2] * b[2] + w[3] * b[3]);
+  }
+  ssum = wave_sum(ssum); bsum = wave_sum(bsum);
+  if (lane == 0) { s[n] = ssum; bf[n] = (bias ? bias[n] : 0.f) + bsum; }
+}
+// mean / rstd of every row from the S = H / 64 partial (sum, sum of squares) pairs the producing epilogue wrote.  One thread per row.
+__global__ __launch_bounds__(256) void ln_stats_finalize_k(const float* __restrict__ part, int M, int S, float inv_h, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const float* p = part + (long long)m * S * 2;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < S; i += 2) {                                 // S is even (H % 128 == 0, launcher): 16-byte loads
+    const f32x4 v = *(const f32x4*)(p + 2 * i);
+    s1 += v[0] + v[2]; s2 += v[1] + v[3];
+  }
+  const float mu = s1 * inv_h;
+  const float var = fmaxf(s2 * inv_h - mu * mu, 0.f);
+  mean[m] = mu; rstd[m] = rsqrtf(var + eps);
+}
+
 // ------------------------------------------------------------------ text embeddings (gather + LN + dropout)
 __global__ __launch_bounds__(TPB) void text_embed_k(mart_text_embed_desc p) {
   constexpr int VMAX = VMAX_ALL;
@@ -849,6 +884,18 @@ extern "C" int mart_ln_bwd_partials(int M) {           // the grid rule of mart_
 extern "C" int mart_ln_dgb_reduce(const float* ws, int partials, int H, float* dgamma, float* dbeta, void* stream) {
   MART_CHECK(ws && partials > 0 && H > 0 && H % 256 == 0 && (dgamma || dbeta), "ln_dgb_reduce: bad args");
   hipLaunchKernelGGL(ln_dgb_reduce_k, dim3(2 * H / 64), dim3(1024), 0, (hipStream_t)stream, ws, partials, H, dgamma, dbeta);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_ln_fold_prep(const float* W, const float* bias, const float* gamma, const float* beta, void* Wf, float* s, float* bf, int N, int K, void* stream) {
+  MART_CHECK(W && gamma && beta && Wf && s && bf && N > 0 && K > 0 && K % 4 == 0, "ln_fold_prep: bad args (K must be a multiple of 4)");
+  hipLaunchKernelGGL(ln_fold_prep_k, dim3((N + WPB - 1) / WPB), dim3(TPB), 0, (hipStream_t)stream, W, bias, gamma, beta, (bf16*)Wf, s, bf, N, K);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_ln_stats_finalize(const float* partials, int M, int H, float eps, float* mean, float* rstd, void* stream) {
+  MART_CHECK(partials && mean && rstd && M > 0 && H > 0 && H % 128 == 0, "ln_stats_finalize: bad args (H must be a multiple of 128)");
+  hipLaunchKernelGGL(ln_stats_finalize_k, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, partials, M, H / 64, 1.f / (float)H, eps, mean, rstd);
   MART_LAUNCH_CHECK();
   return 0;
 }

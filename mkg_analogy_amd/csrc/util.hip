@@ -9,7 +9,7 @@ extern "C" void mart_set_error(const char* msg) {
   g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* mart_last_error(void) { return g_err; }
-extern "C" int mart_abi_version(void) { return 8; }   // round 4: fp16 forward operands (gemm_nt in_f16 / c_f16, *_f16 outputs, adamw shadow_f16), row-subset helpers
+extern "C" int mart_abi_version(void) { return 9; }   // round 5: LayerNorm fold (gemm_nt row_stats / ln_*, mart_ln_fold_prep, mart_ln_stats_finalize); 8 = round 4: fp16 forward operands (gemm_nt in_f16 / c_f16, *_f16 outputs, adamw shadow_f16), row-subset helpers
 extern "C" int mart_check_device(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { mart_set_error("no HIP device"); return -2; }

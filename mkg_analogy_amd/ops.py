@@ -40,7 +40,7 @@ def _rows2d(t: torch.Tensor):
 def gemm_nt(A, B, out, *, A2=None, B2=None, a_rows=None, b_rows=None, M=None, N=None, bias=None, bias2=None,
             bias_by_brow=False, act=ACT_NONE, preact=None, mulz=None, mul_act=ACT_NONE, res_f32=None, res_bf16=None,
             C2=None, alpha=1.0, batch=1, stride_a=0, stride_b=0, stride_c=0, stride_aux=0, tile_cfg=0, b_blocked=False,
-            preact_grad=False, c_split3=False):
+            preact_grad=False, c_split3=False, row_stats=None, ln_mean=None, ln_rstd=None, ln_colsum=None):
     """out[M,N] = epi(A[M,K] @ B[N,K]^T (+ A2 @ B2^T)).  A/B are 2-D (row stride = ld) bf16 -- or fp16, all of them (the forward
     products of the text stream); out bf16 or f32, or fp16 with fp16 operands (C2 is then its bf16 copy).  ``c_split3``: out is bf16
     [M, 3N] and receives the f32 result as the two-term split [hi | lo | hi] (the A operand of the next GEMM of the fp32-accurate path)."""
@@ -73,6 +73,7 @@ def gemm_nt(A, B, out, *, A2=None, B2=None, a_rows=None, b_rows=None, M=None, N=
     d.tile_cfg = tile_cfg
     d.preact_grad = int(preact_grad)
     d.b_blocked = int(b_blocked)
+    d.row_stats, d.ln_mean, d.ln_rstd, d.ln_colsum = _p(row_stats), _p(ln_mean), _p(ln_rstd), _p(ln_colsum)      # LayerNorm fold (mart_hip.h)
     L.check(L.lib().mart_gemm_nt(C.byref(d), _stream()), "mart_gemm_nt")
     return out
 
@@ -133,6 +134,16 @@ def ln_bwd(*, dy_f32=None, dy_bf16=None, s, mean, rstd, gamma, M, H, add_f32=Non
     d.defer_reduce = int(defer)
     L.check(L.lib().mart_ln_bwd(C.byref(d), _stream()), "mart_ln_bwd")
     return (ws, int(L.lib().mart_ln_bwd_partials(M))) if defer else None
+
+
+def ln_fold_prep(W, bias, gamma, beta, Wf, s, bf):
+    """Operands of the LayerNorm fold: Wf = bf16(gamma o W), s[n] = sum_k Wf[n, k], bf = bias + W beta (f32 W [N, K])."""
+    N, K = W.shape
+    L.check(L.lib().mart_ln_fold_prep(_p(W), _p(bias), _p(gamma), _p(beta), _p(Wf), _p(s), _p(bf), N, K, _stream()), "mart_ln_fold_prep")
+
+
+def ln_stats_finalize(partials, M, H, eps, mean, rstd):
+    L.check(L.lib().mart_ln_stats_finalize(_p(partials), M, H, eps, _p(mean), _p(rstd), _stream()), "mart_ln_stats_finalize")
 
 
 def ln_dgb_reduce(ws, partials, H, dgamma, dbeta):
