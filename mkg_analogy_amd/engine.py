@@ -88,6 +88,14 @@ class UnimoEngine:
         # fill each other's tails), so the in-place form stays the default; the switch and its test keep the schedule available.
         self.fusion_side = os.environ.get("MART_FUSION_SIDE", "0") == "1"
         self._w3cache: Dict[str, tuple] = {}
+        # ln_fold: in forward passes that keep nothing for a backward pass (torch.no_grad(): validation / test / serving in the bf16 configuration) the
+        # vision stream's LayerNorms are folded into the products that consume them -- LN(x) W^T + b = rstd (x (gamma o W)^T - mean s) + b'
+        # (modeling_unimo.py:509 -> :223-225, :518 -> :284-286): the out-proj / fc2 epilogue that writes the f32 residual stream also writes its bf16 copy
+        # and per-row partial sums, a 9.6 MB finalise launch makes mean / rstd, and the Q/K/V / fc1 product applies them in its epilogue.  The 24
+        # `ln_fwd_fast_k` passes (309 MB f32 in, 155 MB out each) disappear from those passes.  A training step keeps the LayerNorm pass: the
+        # weight-gradient GEMM needs the normalised activations as its operand.  MART_LN_FOLD=0: every pass unfused.
+        self.ln_fold = os.environ.get("MART_LN_FOLD", "1") == "1"
+        self._foldcache: Dict[str, tuple] = {}
 
     # ------------------------------------------------------------------ helpers
     def _lin(self, name):
@@ -103,6 +111,20 @@ class UnimoEngine:
             hit = (ver, ops.split_bf16x3(W.view(W.shape[0], -1), 1))
             self._w3cache[names[0]] = hit
         return hit[1]
+
+    def _folded(self, wnames, bnames, ln: str):
+        """(gamma o W as bf16, s[n] = its row sums, b' = b + W beta) of the linear layer(s) ``wnames`` behind LayerNorm ``ln``; cached until the weights change."""
+        st = self.st
+        hit = self._foldcache.get(wnames[0])
+        if hit is None or hit[0] != st.version:
+            W = st.fused(list(wnames), st.master)
+            b = st.fused(list(bnames), st.master)
+            Wf = torch.empty(W.shape, device=W.device, dtype=BF)
+            s_, bf_ = torch.empty(W.shape[0], device=W.device, dtype=F32), torch.empty(W.shape[0], device=W.device, dtype=F32)
+            ops.ln_fold_prep(W, b, st.m(ln + ".weight"), st.m(ln + ".bias"), Wf, s_, bf_)
+            hit = (st.version, Wf, s_, bf_)
+            self._foldcache[wnames[0]] = hit
+        return hit[1], hit[2], hit[3]
 
     def _wgrad(self, X, Y, wname, bname=None, NX=None):
         """dW[wname] += X^T Y ; db[bname] += colsum(X)."""
@@ -288,15 +310,24 @@ class UnimoEngine:
 
         t_qkv_prev = None
         ev_tqkv = ev_vis = None
+        fold = self.ln_fold and not keep and self.taps is None and self.inject is None and H % 128 == 0
+        xv_b = xv_stats = None                                         # bf16 copy / per-row partial sums of xv, when the previous layer's fc2 epilogue wrote them
         for l in range(self.n_layers):
             # ================= vision layer l (CLIPEncoderLayer.forward, modeling_unimo.py:490-527)
             v = f"unimo.encoder.vision_layers.{l}."
-            h1, m1, r1 = _e((Mv, H), BF, dev), _e((Mv,), F32, dev), _e((Mv,), F32, dev)
-            ops.ln_fwd(x_f32=xv, gamma=st.m(v + "layer_norm1.weight"), beta=st.m(v + "layer_norm1.bias"), eps=self.eps_v, M=Mv, H=H,
-                       mean=m1, rstd=r1, out_bf16=h1)
+            m1, r1 = _e((Mv,), F32, dev), _e((Mv,), F32, dev)
             qkv = _e((Mv, 3 * H), BF, dev)
             names = [v + f"self_attn.{n}" for n in ("q_proj", "k_proj", "v_proj")]
-            ops.gemm_nt(h1, st.fused([n + ".weight" for n in names]), qkv, bias=st.fused([n + ".bias" for n in names], st.master))
+            if fold and xv_stats is not None:                          # layer_norm1 folded into Q/K/V: xv_b / xv_stats come from the fc2 epilogue of layer l - 1
+                h1 = None
+                ops.ln_stats_finalize(xv_stats, Mv, H, self.eps_v, m1, r1)
+                Wf, cs, bfold = self._folded([n + ".weight" for n in names], [n + ".bias" for n in names], v + "layer_norm1")
+                ops.gemm_nt(xv_b, Wf, qkv, bias=bfold, ln_mean=m1, ln_rstd=r1, ln_colsum=cs)
+            else:
+                h1 = _e((Mv, H), BF, dev)
+                ops.ln_fwd(x_f32=xv, gamma=st.m(v + "layer_norm1.weight"), beta=st.m(v + "layer_norm1.bias"), eps=self.eps_v, M=Mv, H=H,
+                           mean=m1, rstd=r1, out_bf16=h1)
+                ops.gemm_nt(h1, st.fused([n + ".weight" for n in names]), qkv, bias=st.fused([n + ".bias" for n in names], st.master))
             ctx, lse = _e((Mv, H), BF, dev), _e((B, nh, Nv), F32, dev)
             pre = t_qkv_prev if l >= self.fuse_from else None
             if pre is not None:
@@ -307,18 +338,31 @@ class UnimoEngine:
             ops.attn_fwd(**akw)
             x1 = _e((Mv, H), F32, dev)
             w, b = self._lin(v + "self_attn.out_proj")
-            ops.gemm_nt(ctx, w, x1, bias=b, res_f32=xv)
-            h2, m2, r2 = _e((Mv, H), BF, dev), _e((Mv,), F32, dev), _e((Mv,), F32, dev)
-            ops.ln_fwd(x_f32=x1, gamma=st.m(v + "layer_norm2.weight"), beta=st.m(v + "layer_norm2.bias"), eps=self.eps_v, M=Mv, H=H,
-                       mean=m2, rstd=r2, out_bf16=h2)
+            m2, r2 = _e((Mv,), F32, dev), _e((Mv,), F32, dev)
             # z holds act'(fc1 output) (the only thing the backward pass needs of it); nothing is written under no_grad
             z, f = (_e((Mv, I), BF, dev) if keep else None), _e((Mv, I), BF, dev)
-            w, b = self._lin(v + "mlp.fc1")
-            ops.gemm_nt(h2, w, f, bias=b, act=ops.ACT_QGELU, preact=z, preact_grad=keep)
+            if fold:                                                   # layer_norm2 folded into fc1
+                h2 = None
+                x1b, part = _e((Mv, H), BF, dev), _e((Mv, H // 64, 2), F32, dev)
+                ops.gemm_nt(ctx, w, x1, bias=b, res_f32=xv, C2=x1b, row_stats=part)
+                ops.ln_stats_finalize(part, Mv, H, self.eps_v, m2, r2)
+                Wf, cs, bfold = self._folded([v + "mlp.fc1.weight"], [v + "mlp.fc1.bias"], v + "layer_norm2")
+                ops.gemm_nt(x1b, Wf, f, bias=bfold, act=ops.ACT_QGELU, ln_mean=m2, ln_rstd=r2, ln_colsum=cs)
+                del x1b, part
+            else:
+                ops.gemm_nt(ctx, w, x1, bias=b, res_f32=xv)
+                h2 = _e((Mv, H), BF, dev)
+                ops.ln_fwd(x_f32=x1, gamma=st.m(v + "layer_norm2.weight"), beta=st.m(v + "layer_norm2.bias"), eps=self.eps_v, M=Mv, H=H,
+                           mean=m2, rstd=r2, out_bf16=h2)
+                w, b = self._lin(v + "mlp.fc1")
+                ops.gemm_nt(h2, w, f, bias=b, act=ops.ACT_QGELU, preact=z, preact_grad=keep)
             x2 = _e((Mv, H), F32, dev)
-            x2b = _e((Mv, H), BF, dev) if l >= self.fuse_from else None
+            nxt = fold and l + 1 < self.n_layers                      # the next layer's layer_norm1 is folded: it reads the bf16 copy and the partial sums
+            x2b = _e((Mv, H), BF, dev) if (l >= self.fuse_from or nxt) else None
+            xv_stats = _e((Mv, H // 64, 2), F32, dev) if nxt else None
             w, b = self._lin(v + "mlp.fc2")
-            ops.gemm_nt(f, w, x2, bias=b, res_f32=x1, C2=x2b)
+            ops.gemm_nt(f, w, x2, bias=b, res_f32=x1, C2=x2b, row_stats=xv_stats)
+            xv_b = x2b
             sv[f"v{l}"] = dict(x=xv, m1=m1, r1=r1, h1=h1, qkv=qkv, ctx=ctx, lse=lse, x1=x1, m2=m2, r2=r2, h2=h2, z=z, f=f, pre=pre)
             xv = x2
 
