@@ -254,14 +254,15 @@ def reference_parity(model, lit, batch, cfg, dev, timed_weights: str):
                     "top10_entity_indices_identical": f"{int((order(lg)[:, :10] == order(ref)[:, :10]).all(1).sum())}/{B0}"}
         row = {"logit_abs_max": round(float(np.abs(ref).max()), 3), "n_logits": int(ref.size),
                "timed_weights": bool((timed_weights == "conditioned") == cond and timed_weights in ("conditioned", "g7plain"))}
-        # bf16 twice: with the forward pass of the TIMED training step (LayerNorm as its own pass: engine.ln_fold off), and as a no_grad pass runs by
-        # default (vision LayerNorms folded into Q/K/V and fc1: engine.ln_fold)
+        # bf16 twice: with the forward pass of the TIMED training step (LayerNorm as its own pass; also what a no_grad pass runs by default), and with the
+        # opt-in fold of the vision LayerNorms into Q/K/V and fc1 (engine.ln_fold: no_grad passes only)
         fold0 = getattr(model.engine, "ln_fold", False)
-        for prec, fold, key in (("bf16", False, "bf16_timed_path"), ("bf16", True, "bf16_no_grad_path_ln_fold"), ("fp32", fold0, "fp32_path_evaluation_default")):
-            if prec == "bf16" and fold and not fold0:
+        for prec, fold, key in (("bf16", False, "bf16_timed_path"), ("bf16", True, "bf16_no_grad_path_with_ln_fold_opt_in"), ("fp32", fold0, "fp32_path_evaluation_default")):
+            if fold and not hasattr(model.engine, "ln_fold"):
                 continue
             model.set_precision(prec)
-            model.engine.ln_fold = fold
+            if hasattr(model.engine, "ln_fold"):
+                model.engine.ln_fold = fold
             try:
                 with torch.no_grad():
                     pos = (batch["input_ids"][:B0] == D.MASK).int().argmax(1)
@@ -270,7 +271,8 @@ def reference_parity(model, lit, batch, cfg, dev, timed_weights: str):
                     lg = o.logits.mask_rows(batch["input_ids"][:B0], D.MASK)[:, ids].float().cpu().numpy()
             finally:
                 model.set_precision("bf16")
-                model.engine.ln_fold = fold0
+                if hasattr(model.engine, "ln_fold"):
+                    model.engine.ln_fold = fold0
             r = against_reference(lg)
             r["meets_north_star_logit_tol"] = bool(r["max_abs_dlogit"] < (1e-2 if prec == "bf16" else 1e-3))
             row[key] = r
@@ -455,14 +457,14 @@ def main():
             finally:
                 lit.args.eval_precision = None
         evalb = {"what": "validation pass over the timed batch: forward, scoring head, device-side rank of the label",
-                 "bf16": time_eval("bf16"),                              # the training configuration (text stream on fp16 operands, split-precision head); vision LayerNorms folded into Q/K/V and fc1 (engine.ln_fold)
+                 "bf16": time_eval("bf16"),                              # the training configuration (text stream on fp16 operands, split-precision head)
                  "fp32": time_eval("fp32")}
-        if getattr(model.engine, "ln_fold", False):                       # the same bf16 pass with the LayerNorms as their own kernels (what the fold removes)
-            model.engine.ln_fold = False
+        if hasattr(model.engine, "ln_fold") and not model.engine.ln_fold:   # the bf16 pass with the vision LayerNorms folded into Q/K/V and fc1 (opt-in, MART_LN_FOLD=1)
+            model.engine.ln_fold = True
             try:
-                evalb["bf16_ln_unfused"] = time_eval("bf16")
+                evalb["bf16_ln_fold"] = time_eval("bf16")
             finally:
-                model.engine.ln_fold = True
+                model.engine.ln_fold = False
         evalb["eval_examples_per_s"] = evalb["fp32"]["examples_per_s"]      # the default of validation / test passes (TransformerLitModel._eval_at)
         evalb["eval_precision"] = "fp32"
     tsplit = None

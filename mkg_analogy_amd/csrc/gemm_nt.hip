@@ -761,23 +761,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, PIPE == 3 ? 2 : 1) void gem
 #pragma unroll
         for (int q = 0; q < 4; ++q) sq[j][q] = *(const f32x4*)(p.ln_colsum + en0 + wn0 + ecol(j, q));
     }
-    auto run = [&](auto guard) {                                  // two straight-line arms, one wave-uniform row-guard test per sub-tile
-    constexpr bool GUARD = decltype(guard)::value;
-    auto block = [&](const int i, const f32x16 (&ai)[TN]) {
-      float lmean[TN], lrstd[TN];                                  // F_LNFOLD: statistics of the row this lane holds in acc[i][j] (rows past M: those of row M - 1, never stored)
-      if constexpr ((EPI & F_LNFOLD) != 0) {
+    // F_LNFOLD: statistics of the rows this lane holds in acc[i][j] (rows past M: those of row M - 1, never stored), all requested before the first block
+    float lmean[(EPI & F_LNFOLD) != 0 ? TM : 1][TN], lrstd[(EPI & F_LNFOLD) != 0 ? TM : 1][TN];
+    if constexpr ((EPI & F_LNFOLD) != 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int m = em0 + wm0 + min(ro(i) + erow(j), mrem - 1);
-          lmean[j] = p.ln_mean[m]; lrstd[j] = p.ln_rstd[m];
+          lmean[i][j] = p.ln_mean[m]; lrstd[i][j] = p.ln_rstd[m];
         }
-      }
+    }
+    auto run = [&](auto guard) {                                  // two straight-line arms, one wave-uniform row-guard test per sub-tile
+    constexpr bool GUARD = decltype(guard)::value;
+    auto block = [&](const int i, const f32x16 (&ai)[TN]) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 v = f32x4{ai[j][4 * q], ai[j][4 * q + 1], ai[j][4 * q + 2], ai[j][4 * q + 3]} * p.alpha;
-          if constexpr ((EPI & F_LNFOLD) != 0) v = (v - sq[j][q] * lmean[j]) * lrstd[j] + bq[j][q];
+          if constexpr ((EPI & F_LNFOLD) != 0) v = (v - sq[j][q] * lmean[i][j]) * lrstd[i][j] + bq[j][q];
           else v += bq[j][q];
           char* dst = epb + erow(j) * RS + ecol(j, q) * 2;
           if constexpr ((EPI & F_PGRAD) != 0) {

@@ -27,7 +27,8 @@ def test_folded_eval_pass_vs_oracle_and_unfused(patch, B, L):
               sep_idx=gb["sep_idx"], return_dict=True)
     _, mi = (gb["input_ids"] == 103).nonzero(as_tuple=True)
     eng = model.engine
-    assert eng.ln_fold, "the fold is the default of no_grad passes"
+    assert not eng.ln_fold, "opt-in: by default a no_grad pass is bit-identical to the forward pass of a training step"
+    eng.ln_fold = True
     calls = []
     from mkg_analogy_amd import ops
     real = ops.ln_stats_finalize
@@ -42,11 +43,9 @@ def test_folded_eval_pass_vs_oracle_and_unfused(patch, B, L):
         ops.ln_stats_finalize = real
     assert n_fold == 2 * eng.n_layers - 1                  # every vision LayerNorm but layer 0's layer_norm1 (its input comes from the embedding kernels)
     eng.ln_fold = False
-    try:
-        with torch.no_grad():
-            out_u, trans_u = model(**kw)
-    finally:
-        eng.ln_fold = True
+    with torch.no_grad():
+        out_u, trans_u = model(**kw)
+    eng.ln_fold = True
     assert torch.equal(trans_u, trans_g.detach()), "no_grad without the fold == the forward pass of a training step"
     rows = torch.arange(B, device="cuda")
     ml_f, ml_u = out_f.logits[rows, mi][:, ids.cuda()].float().cpu(), out_u.logits[rows, mi][:, ids.cuda()].float().cpu()
@@ -60,3 +59,4 @@ def test_folded_eval_pass_vs_oracle_and_unfused(patch, B, L):
     ranks_ref = O.ranks_double_sort(ml_ref, batch["label"])
     amb = ((ml_ref - ml_ref[torch.arange(B), batch["label"]][:, None]).abs() < 2 * e_f).sum(1).numpy() - 1
     assert np.all(np.abs(ev["entity_ranks"] - ranks_ref) <= amb)
+    eng.ln_fold = False
