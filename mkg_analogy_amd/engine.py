@@ -93,7 +93,7 @@ class UnimoEngine:
         # LN(x) W^T + b = rstd (x (gamma o W)^T - mean s) + b'  (modeling_unimo.py:509 -> :223-225, :518 -> :284-286): the out-proj / fc2 epilogue that writes
         # the f32 residual stream also writes its bf16 copy and per-row partial sums, a 9.6 MB finalise launch makes mean / rstd, and the Q/K/V / fc1
         # product applies them in its epilogue; 23 of the 24 `ln_fwd_fast_k` passes (309 MB f32 in, 155 MB out each) disappear.  As accurate as the
-        # unfused pass (tests/test_ln_fold_model_gpu.py) and +0.3-1.1 % on the bf16 evaluation pass (27.7-28.0 against 28.0-28.1 ms: the producers'
+        # unfused pass (tests/test_ln_fold_model_gpu.py) and +0.2-2.7 % (mean +1.3 %) on the bf16 evaluation pass (28.34 against 28.71 ms over five alternations: the producers'
         # extra 155 MB and the consumers' heavier epilogues eat most of the 1.75 ms) -- NOT the default, because with it a no_grad pass and the forward
         # pass of a training step stop being bit-identical (test_text_fp16_forward_vs_plain_bf16_text_stream) for that 1 %.  A training step cannot
         # use it at all: the weight-gradient GEMM needs the normalised activations as its operand.
