@@ -316,7 +316,10 @@ def test_text_fp16_forward_vs_plain_bf16_text_stream():
     eng.text_f16 = False
     plain = logits(False)
     eng.text_f16 = True
-    assert torch.equal(ev, tr), "evaluation and training forward passes are one configuration"
+    if eng.ln_fold:       # MART_LN_FOLD=1 (opt-in): no_grad passes fold the vision LayerNorms into Q/K/V and fc1 -- rounding-level differences from the training forward
+        assert float((ev - tr).abs().max()) < 6e-3
+    else:
+        assert torch.equal(ev, tr), "evaluation and training forward passes are one configuration"
     stat = lambda x: (float((x - ref).abs().max()), float((x - ref).pow(2).mean().sqrt()))
     (e_h, r_h), (e_p, r_p) = stat(ev), stat(plain)
     print(f"\ntext stream fp16 operands: max|dlogit| {e_h:.3e} rms {r_h:.3e};  plain bf16 text stream: {e_p:.3e} / {r_p:.3e}")
