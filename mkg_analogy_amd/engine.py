@@ -99,6 +99,11 @@ class UnimoEngine:
         # use it at all: the weight-gradient GEMM needs the normalised activations as its operand.
         self.ln_fold = os.environ.get("MART_LN_FOLD", "0") == "1"
         self._foldcache: Dict[str, tuple] = {}
+        # wgrad_lag: the backward pass of a vision layer does not wait for the weight-gradient stream before its LayerNorm-1 backward rewrites the bf16
+        # gradient buffer the fc2 weight-gradient GEMM reads -- it writes a fresh buffer instead, and the weight-gradient queue may lag behind the main
+        # queue by more than one layer (joined at the end of the pass).  Same kernels, same operands, bit-identical gradients; 85.2 -> 84.1 ms per step at
+        # 196 patches (three alternations, profiles/r05_wgrad_lag_ab.txt), neutral at 49.  MART_WGRAD_LAG=0: the per-layer join of rounds 1-4.
+        self.wgrad_lag = os.environ.get("MART_WGRAD_LAG", "1") == "1"
 
     # ------------------------------------------------------------------ helpers
     def _lin(self, name):
@@ -755,7 +760,13 @@ class UnimoEngine:
                 side_next = T["A_side"][l - 1]
                 self._main_wait(T["ev_tfus"][l - 1])
                 side_next.record_stream(torch.cuda.current_stream())   # allocated on the text stream, read here
-            self._join()                                               # dxvb (read by the fc2 weight-gradient GEMM) is rewritten next
+            if self.wgrad_lag and self.overlap_wgrad:
+                # a fresh bf16 buffer for the gradient this LayerNorm writes instead of a join: the fc2 weight-gradient GEMM of this layer may still
+                # be reading the old one on the weight-gradient stream (the caching allocator keeps it until that stream has passed it: record_stream
+                # in _tn), and the main queue goes on while the weight-gradient queue lags behind by more than one layer
+                dxvb = _e((Mv, H), BF, dev)
+            else:
+                self._join()                                           # dxvb (read by the fc2 weight-gradient GEMM) is rewritten next
             self._ln_bwd(dy_bf16=dh1, s=s["x"], mean=s["m1"], rstd=s["r1"], gamma=st.m(v + "layer_norm1.weight"), M=Mv, H=H, add_f32=dx1,
                        add2_f32=side_next, ds_f32=dxv, ds_bf16=dxvb, bf16_total=True, dgamma=st.g(v + "layer_norm1.weight"),
                        dbeta=st.g(v + "layer_norm1.bias"))
