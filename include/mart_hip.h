@@ -265,12 +265,24 @@ int mart_softmax_bwd(const void* probs_bf16, int ldp, const float* dprobs, int l
 int mart_transpose_bf16(const void* in, int ldi, long long stride_i, void* out, int Rp, long long stride_o, int R, int C, int batch, void* stream);
 
 /* ---------------------------------------------------------------- scoring head / loss / ranking
- * LabelSmoothSoftmaxCEV1.forward (lit_models/utils.py:42-66): per-row loss and lse over C classes */
-int mart_lsce_fwd(const float* logits, int ld, const int64_t* label, float eps, float* loss_rows, float* lse, int R, int C, void* stream);
-/* dlogits = gscale[0] * rowscale * (softmax * sum(target) - target), bf16 (zero padded to ldo) and/or f32 */
-int mart_lsce_bwd(const float* logits, int ld, const int64_t* label, const float* lse, float eps, const float* gscale, float rowscale,
-                  void* dlogits_bf16, int ldo, float* dlogits_f32, int R, int C, void* stream);
-/* rank = 1 + #(logit > logit[label])  == argsort(argsort(-logits))[label]+1 without ties (lit_models/transformer.py:162-164) */
+ * LabelSmoothSoftmaxCEV1.forward (lit_models/utils.py:42-66): per-row loss and lse over C classes.
+ * ignore_index (utils.py:37,49-52,58): rows with that label have loss 0, are not counted in n_valid and get a zero gradient row.
+ * Any other label outside [0, C) -- where the reference's scatter_ raises -- is never used as an index: the row's loss (and gradient
+ * row) is NaN and status[0] (device int32, may be NULL; the caller zeroes it once and polls it when it likes) is set to 1.
+ * reduction: MART_REDUCE_NONE (loss_rows only), MART_REDUCE_MEAN (loss_out[0] = sum / n_valid, utils.py:59-60), MART_REDUCE_SUM (:61-62);
+ * loss_out is float[2] on the device: {loss, n_valid}. */
+#define MART_REDUCE_NONE 0
+#define MART_REDUCE_MEAN 1
+#define MART_REDUCE_SUM 2
+int mart_lsce_fwd(const float* logits, int ld, const int64_t* label, long long ignore_index, float eps, float* loss_rows, float* lse,
+                  float* loss_out, int reduction, int* status, int R, int C, void* stream);
+/* dlogits = g * (softmax * sum(target) - target), g = gscale[gscale_per_row ? row : 0] * rowscale / (n_valid ? n_valid[0] : 1); ignored rows 0;
+ * bf16 (zero padded to ldo) and/or f32 */
+int mart_lsce_bwd(const float* logits, int ld, const int64_t* label, long long ignore_index, const float* lse, float eps, const float* gscale,
+                  int gscale_per_row, float rowscale, const float* n_valid, void* dlogits_bf16, int ldo, float* dlogits_f32, int R, int C,
+                  void* stream);
+/* rank = 1 + #(logit > logit[label])  == argsort(argsort(-logits))[label]+1 without ties (lit_models/transformer.py:162-164);
+ * a label outside [0, C) gives rank 0 */
 int mart_rank(const float* logits, int ld, const int64_t* label, int64_t* rank, int R, int C, void* stream);
 /* relaxation loss rows (lit_models/transformer.py:103-108): relu(cos(q,a)) + 1 - cos(r0,r1) on rows of trans [B,L,H] */
 int mart_simloss_fwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, float* loss_rows,
@@ -280,8 +292,10 @@ int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, const int64_t* 
                      float rowscale, float* dtrans, int B, int L, int H, void* stream);
 
 /* ---------------------------------------------------------------- small utilities
- * [MASK] position per row: (input_ids == mask_id).nonzero() without the host sync of lit_models/transformer.py:94 */
-int mart_find_token(const int64_t* ids, int B, int L, int64_t token, int32_t* pos_out, int32_t* row_out, void* stream);
+ * [MASK] position per row: (input_ids == mask_id).nonzero() without the host sync of lit_models/transformer.py:94
+ * pos_out[b] = first position (-1: absent), row_out[b] (may be NULL) = b*L + max(pos, 0); status (device int32, may be NULL): bit 1 (value 2) is
+ * OR-ed in when some example does not contain the token (the reference's fancy index raises a shape error there) */
+int mart_find_token(const int64_t* ids, int B, int L, int64_t token, int32_t* pos_out, int32_t* row_out, int32_t* status, void* stream);
 int mart_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
 int mart_cast_bf16_f32(const void* src, float* dst, long long n, void* stream);
 int mart_cast_f32_f16(const float* src, void* dst_f16, long long n, void* stream);   /* fp16 shadow of the text-stream weights */

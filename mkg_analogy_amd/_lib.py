@@ -129,12 +129,12 @@ _SIGS = {
     "mart_softmax_fwd": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "mart_softmax_bwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp]),
     "mart_transpose_bf16": (i32, [vp, i32, i64, vp, i32, i64, i32, i32, i32, vp]),
-    "mart_lsce_fwd": (i32, [vp, i32, vp, f32, vp, vp, i32, i32, vp]),
-    "mart_lsce_bwd": (i32, [vp, i32, vp, vp, f32, vp, f32, vp, i32, vp, i32, i32, vp]),
+    "mart_lsce_fwd": (i32, [vp, i32, vp, i64, f32, vp, vp, vp, i32, vp, i32, i32, vp]),
+    "mart_lsce_bwd": (i32, [vp, i32, vp, i64, vp, f32, vp, i32, f32, vp, vp, i32, vp, i32, i32, vp]),
     "mart_rank": (i32, [vp, i32, vp, vp, i32, i32, vp]),
     "mart_simloss_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "mart_simloss_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
-    "mart_find_token": (i32, [vp, i32, i32, i64, vp, vp, vp]),
+    "mart_find_token": (i32, [vp, i32, i32, i64, vp, vp, vp, vp]),
     "mart_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "mart_cast_bf16_f32": (i32, [vp, vp, i64, vp]),
     "mart_cast_f32_f16": (i32, [vp, vp, i64, vp]),
@@ -164,7 +164,7 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
-EXPECTED_ABI = 9            # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
+EXPECTED_ABI = 10           # the layout the ctypes structures above were written for (mart_abi_version() of the library must match)
 _lib = None
 
 

@@ -26,10 +26,15 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
   return t;
 }
 
-// LabelSmoothSoftmaxCEV1 (lit_models/utils.py:49-62): target = eps/C everywhere, 1-eps at the label.
+// LabelSmoothSoftmaxCEV1 (lit_models/utils.py:42-66): target = eps/C everywhere, 1-eps at the label.
 // loss_row = -(sum_c t_c * logp_c) = lse*T - (eps/C)*sum_c x_c - (1-eps-eps/C)*x_label ,  T = 1-eps + eps*(C-1)/C
-__global__ void lsce_fwd_k(const float* __restrict__ lg, int ld, const int64_t* __restrict__ label, float eps, float* loss_rows,
-                           float* lse_out, int R, int C) {
+// Rows whose label == ignore (utils.py:49-52, 58): loss 0, not counted in n_valid, zero gradient.  A label outside [0, C) that is not
+// ``ignore`` (the reference's scatter_ raises there): the row's loss is NaN, nothing is read out of bounds, status[0] is set.
+__device__ __forceinline__ int label_class(long long lab, long long ignore, int C) {      // 0: scored, 1: ignored, 2: out of range
+  return lab == ignore ? 1 : ((lab < 0 || lab >= (long long)C) ? 2 : 0);
+}
+__global__ void lsce_fwd_k(const float* __restrict__ lg, int ld, const int64_t* __restrict__ label, long long ignore, float eps, float* loss_rows,
+                           float* lse_out, int* status, int R, int C) {
   __shared__ float sh[8];
   const int r = blockIdx.x;
   const float* x = lg + (long long)r * ld;
@@ -44,32 +49,58 @@ __global__ void lsce_fwd_k(const float* __restrict__ lg, int ld, const int64_t* 
     const float lse = mx + __logf(se);
     const float neg = eps / (float)C, pos = 1.f - eps;
     const float T = pos + neg * (float)(C - 1);
-    const float xl = x[label[r]];
-    loss_rows[r] = lse * T - neg * (sx - xl) - pos * xl;
+    const long long lab = label[r];
+    const int cls = label_class(lab, ignore, C);
+    float loss = 0.f;
+    if (cls == 0) {
+      const float xl = x[lab];
+      loss = lse * T - neg * (sx - xl) - pos * xl;
+    } else if (cls == 2) {
+      loss = __builtin_nanf("");
+      if (status) atomicOr(status, 1);
+    }
+    loss_rows[r] = loss;
     lse_out[r] = lse;
   }
 }
-__global__ void lsce_bwd_k(const float* __restrict__ lg, int ld, const int64_t* __restrict__ label, const float* __restrict__ lse, float eps,
-                           const float* __restrict__ gscale, float rowscale, bf16* ob, int ldo, float* of, int R, int C) {
+// reduction over the rows (deterministic: one workgroup, fixed order): out[0] = sum(rows) / n_valid ('mean', utils.py:59-60; 0/0 = NaN as the
+// reference when every row is ignored) or sum(rows) ('sum', :61-62); out[1] = n_valid (read by the backward pass)
+__global__ void lsce_reduce_k(const float* __restrict__ loss_rows, const int64_t* __restrict__ label, long long ignore, int mean, float* out, int R) {
+  __shared__ float sh[8];
+  float s = 0.f, n = 0.f;
+  for (int r = threadIdx.x; r < R; r += TPB) { s += loss_rows[r]; n += (label[r] != ignore) ? 1.f : 0.f; }
+  s = block_sum(s, sh);
+  n = block_sum(n, sh);
+  if (threadIdx.x == 0) { out[0] = mean ? s / n : s; out[1] = n; }
+}
+__global__ void lsce_bwd_k(const float* __restrict__ lg, int ld, const int64_t* __restrict__ label, long long ignore, const float* __restrict__ lse, float eps,
+                           const float* __restrict__ gscale, int g_per_row, float rowscale, const float* __restrict__ nvalid, bf16* ob, int ldo, float* of,
+                           int R, int C) {
   const int r = blockIdx.x;
   const float* x = lg + (long long)r * ld;
-  const float g = (gscale ? gscale[0] : 1.f) * rowscale;
+  float g = (gscale ? gscale[g_per_row ? r : 0] : 1.f) * rowscale;
+  if (nvalid) g /= nvalid[0];
   const float neg = eps / (float)C, pos = 1.f - eps;
   const float T = pos + neg * (float)(C - 1);
   const float l = lse[r];
-  const int lab = (int)label[r];
+  const long long lab = label[r];
+  const int cls = label_class(lab, ignore, C);
   for (int c = threadIdx.x; c < ldo; c += TPB) {
     float v = 0.f;
-    if (c < C) v = g * (__expf(x[c] - l) * T - (c == lab ? pos : neg));
+    if (c < C && cls == 0) v = g * (__expf(x[c] - l) * T - ((long long)c == lab ? pos : neg));
+    if (c < C && cls == 2) v = __builtin_nanf("");
     if (ob) ob[(long long)r * ldo + c] = f2bf(v);
     if (of && c < C) of[(long long)r * C + c] = v;
   }
 }
+// rank = 1 + #(logit > logit[label]); a label outside [0, C): rank 0 (never a valid rank), nothing read out of bounds
 __global__ void rank_k(const float* __restrict__ lg, int ld, const int64_t* __restrict__ label, int64_t* rank, int R, int C) {
   __shared__ float sh[8];
   const int r = blockIdx.x;
   const float* x = lg + (long long)r * ld;
-  const float xl = x[label[r]];
+  const long long lab = label[r];
+  if (lab < 0 || lab >= (long long)C) { if (threadIdx.x == 0) rank[r] = 0; return; }
+  const float xl = x[lab];
   float cnt = 0.f;
   for (int c = threadIdx.x; c < C; c += TPB) cnt += (x[c] > xl) ? 1.f : 0.f;
   cnt = block_sum(cnt, sh);
@@ -174,17 +205,25 @@ __global__ __launch_bounds__(TPB) void adamw_k(mart_adamw_desc p) {
 }
 }  // namespace
 
-extern "C" int mart_lsce_fwd(const float* logits, int ld, const int64_t* label, float eps, float* loss_rows, float* lse, int R, int C, void* stream) {
+extern "C" int mart_lsce_fwd(const float* logits, int ld, const int64_t* label, long long ignore_index, float eps, float* loss_rows, float* lse,
+                             float* loss_out, int reduction, int* status, int R, int C, void* stream) {
   MART_CHECK(logits && label && loss_rows && lse && R > 0 && C > 0 && ld >= C, "lsce_fwd: bad args");
-  hipLaunchKernelGGL(lsce_fwd_k, dim3(R), dim3(TPB), 0, (hipStream_t)stream, logits, ld, label, eps, loss_rows, lse, R, C);
+  MART_CHECK(reduction == MART_REDUCE_NONE || ((reduction == MART_REDUCE_MEAN || reduction == MART_REDUCE_SUM) && loss_out), "lsce_fwd: reduction / loss_out");
+  hipLaunchKernelGGL(lsce_fwd_k, dim3(R), dim3(TPB), 0, (hipStream_t)stream, logits, ld, label, ignore_index, eps, loss_rows, lse, status, R, C);
   MART_LAUNCH_CHECK();
+  if (reduction != MART_REDUCE_NONE) {
+    hipLaunchKernelGGL(lsce_reduce_k, dim3(1), dim3(TPB), 0, (hipStream_t)stream, loss_rows, label, ignore_index, reduction == MART_REDUCE_MEAN ? 1 : 0, loss_out, R);
+    MART_LAUNCH_CHECK();
+  }
   return 0;
 }
-extern "C" int mart_lsce_bwd(const float* logits, int ld, const int64_t* label, const float* lse, float eps, const float* gscale, float rowscale,
-                             void* dlogits_bf16, int ldo, float* dlogits_f32, int R, int C, void* stream) {
+extern "C" int mart_lsce_bwd(const float* logits, int ld, const int64_t* label, long long ignore_index, const float* lse, float eps, const float* gscale,
+                             int gscale_per_row, float rowscale, const float* n_valid, void* dlogits_bf16, int ldo, float* dlogits_f32, int R, int C,
+                             void* stream) {
   MART_CHECK(logits && label && lse && (dlogits_bf16 || dlogits_f32) && R > 0 && C > 0 && ld >= C && ldo >= C, "lsce_bwd: bad args");
-  hipLaunchKernelGGL(lsce_bwd_k, dim3(R), dim3(TPB), 0, (hipStream_t)stream, logits, ld, label, lse, eps, gscale, rowscale, (bf16*)dlogits_bf16, ldo,
-                     dlogits_f32, R, C);
+  MART_CHECK(!gscale_per_row || gscale, "lsce_bwd: gscale_per_row needs gscale");
+  hipLaunchKernelGGL(lsce_bwd_k, dim3(R), dim3(TPB), 0, (hipStream_t)stream, logits, ld, label, ignore_index, lse, eps, gscale, gscale_per_row, rowscale,
+                     n_valid, (bf16*)dlogits_bf16, ldo, dlogits_f32, R, C);
   MART_LAUNCH_CHECK();
   return 0;
 }

@@ -9,7 +9,7 @@ extern "C" void mart_set_error(const char* msg) {
   g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* mart_last_error(void) { return g_err; }
-extern "C" int mart_abi_version(void) { return 9; }   // round 5: LayerNorm fold (gemm_nt row_stats / ln_*, mart_ln_fold_prep, mart_ln_stats_finalize); 8 = round 4: fp16 forward operands (gemm_nt in_f16 / c_f16, *_f16 outputs, adamw shadow_f16), row-subset helpers
+extern "C" int mart_abi_version(void) { return 10; }   // round 6: mart_lsce_* ignore_index / reduction / status; 9 = round 5: LayerNorm fold (gemm_nt row_stats / ln_*, mart_ln_fold_prep, mart_ln_stats_finalize); 8 = round 4: fp16 forward operands (gemm_nt in_f16 / c_f16, *_f16 outputs, adamw shadow_f16), row-subset helpers
 extern "C" int mart_check_device(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { mart_set_error("no HIP device"); return -2; }
@@ -117,12 +117,13 @@ __global__ void dropout_bwd_k(const float* __restrict__ a, const bf16* __restric
     o[i] = (p > 0.f) ? (dropout_keep(seed, (uint64_t)i, p) ? v * sc : 0.f) : v;
   }
 }
-__global__ void find_token_k(const int64_t* ids, int B, int L, int64_t tok, int32_t* pos, int32_t* row) {
+__global__ void find_token_k(const int64_t* ids, int B, int L, int64_t tok, int32_t* pos, int32_t* row, int32_t* status) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int found = -1;
   for (int j = 0; j < L; ++j) if (ids[(long long)b * L + j] == tok) { found = j; break; }
   pos[b] = found;
+  if (found < 0 && status) atomicOr(status, 2);       // an example without the token (the reference raises there): pos -1, row b*L+0, status bit 1
   if (row) row[b] = b * L + (found < 0 ? 0 : found);
 }
 __global__ void gather_rows_k(const float* __restrict__ src, int ld, const int32_t* __restrict__ rows, float* __restrict__ dst, int R, int H) {
@@ -221,9 +222,9 @@ extern "C" int mart_dropout_bwd_f32(const float* dy_f32, const void* dy_bf16, fl
   MART_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int mart_find_token(const int64_t* ids, int B, int L, int64_t token, int32_t* pos_out, int32_t* row_out, void* stream) {
+extern "C" int mart_find_token(const int64_t* ids, int B, int L, int64_t token, int32_t* pos_out, int32_t* row_out, int32_t* status, void* stream) {
   MART_CHECK(ids && pos_out && B > 0 && L > 0, "find_token: bad args");
-  hipLaunchKernelGGL(find_token_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, ids, B, L, token, pos_out, row_out);
+  hipLaunchKernelGGL(find_token_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, ids, B, L, token, pos_out, row_out, status);
   MART_LAUNCH_CHECK();
   return 0;
 }

@@ -108,26 +108,62 @@ class _ScoreFn(torch.autograd.Function):
         return dtrans, None, None, None, None, None, None, None
 
 
+_STATUS: dict = {}      # device -> int32 [1]: bit 0 set by mart_lsce_fwd (label outside [0, C) u {ignore_index}), bit 1 by mart_find_token (token absent)
+
+
+def _status(dev) -> torch.Tensor:
+    t = _STATUS.get(dev)
+    if t is None:
+        t = _STATUS[dev] = torch.zeros(1, device=dev, dtype=torch.int32)
+    return t
+
+
+def check_status() -> None:
+    """Raise for the conditions the reference raises for at once and the stream-ordered kernels can only flag (one host sync; the trainer calls
+    it where it reads the loss anyway, and after every evaluation pass):
+      * a label outside [0, num_classes) that is not ``ignore_index`` reached LabelSmoothSoftmaxCEV1 (the reference's ``scatter_`` raises,
+        lit_models/utils.py:54-55; here that step's loss is NaN),
+      * an example without [MASK] reached the [MASK]-row lookup (``logits[arange(bs), mask_idx]`` raises a shape error in the reference,
+        lit_models/transformer.py:94-95; here row 0 of that example was scored, as ``needed_rows`` was told)."""
+    for dev, t in _STATUS.items():
+        v = int(t.item())
+        if v:
+            t.zero_()
+            why = []
+            if v & 1:
+                why.append("LabelSmoothSoftmaxCEV1: a label outside [0, num_classes) that is not ignore_index (that step's loss is NaN)")
+            if v & 2:
+                why.append("an example without the [MASK] token (the reference raises a shape mismatch at logits[arange(bs), mask_idx])")
+            raise IndexError("; ".join(why))
+
+
+check_labels = check_status
+
+
 class _LSCEFn(torch.autograd.Function):
-    """LabelSmoothSoftmaxCEV1.forward, lit_models/utils.py:42-66 (reduction='mean', no ignored labels)."""
+    """LabelSmoothSoftmaxCEV1.forward, lit_models/utils.py:42-66: reduction 'mean' (sum over rows / n_valid), 'sum' or 'none'; rows whose
+    label == ignore_index contribute 0 and receive a zero gradient row."""
 
     @staticmethod
-    def forward(ctx, logits, label, eps):
+    def forward(ctx, logits, label, eps, ignore_index, reduction):
         logits = logits.contiguous()
         R = logits.shape[0]
         rows = torch.empty(R, device=logits.device, dtype=F32)
         lse = torch.empty(R, device=logits.device, dtype=F32)
-        ops.lsce_fwd(logits, label, eps, rows, lse)
-        ctx.save_for_backward(logits, label, lse)
-        ctx.eps = eps
-        return rows.mean()
+        red = torch.empty(2, device=logits.device, dtype=F32) if reduction != "none" else None
+        ops.lsce_fwd(logits, label, eps, rows, lse, ignore_index=ignore_index, loss_out=red, reduction=reduction, status=_status(logits.device))
+        ctx.save_for_backward(logits, label, lse, red)
+        ctx.eps, ctx.ignore_index, ctx.reduction = eps, ignore_index, reduction
+        return rows if red is None else red[0]
 
     @staticmethod
     def backward(ctx, g):
-        logits, label, lse = ctx.saved_tensors
+        logits, label, lse, red = ctx.saved_tensors
         dl = torch.empty_like(logits)
-        ops.lsce_bwd(logits, label, lse, ctx.eps, g.contiguous().view(1).float(), 1.0 / logits.shape[0], dl_f32=dl)
-        return dl, None, None
+        per_row = ctx.reduction == "none"
+        ops.lsce_bwd(logits, label, lse, ctx.eps, g.contiguous().float().view(-1), 1.0, dl_f32=dl, ignore_index=ctx.ignore_index,
+                     n_valid=red[1:] if ctx.reduction == "mean" else None, gscale_per_row=per_row)
+        return dl, None, None, None, None
 
 
 class _SimLossFn(torch.autograd.Function):
@@ -149,8 +185,10 @@ class _SimLossFn(torch.autograd.Function):
         return d, None, None, None
 
 
-def label_smooth_ce(logits: torch.Tensor, label: torch.Tensor, eps: float = 0.1) -> torch.Tensor:
-    return _LSCEFn.apply(logits, label.to(torch.int64).contiguous(), float(eps))
+def label_smooth_ce(logits: torch.Tensor, label: torch.Tensor, eps: float = 0.1, ignore_index: int = -100, reduction: str = "mean") -> torch.Tensor:
+    if reduction not in ("mean", "sum"):
+        reduction = "none"                          # lit_models/utils.py:59-62: any other string leaves the per-row losses
+    return _LSCEFn.apply(logits, label.to(torch.int64).contiguous(), float(eps), int(ignore_index), reduction)
 
 
 def relaxation_loss(trans: torch.Tensor, rel_idx: torch.Tensor, q_head_idx: torch.Tensor, a_head_idx: torch.Tensor) -> torch.Tensor:
@@ -162,7 +200,7 @@ def token_positions(input_ids: torch.Tensor, token_id: int) -> torch.Tensor:
     """First position of ``token_id`` in every row, int32 [B] on the device (-1: absent) -- ``(input_ids == id).nonzero()`` of
     lit_models/transformer.py:94 without the host sync."""
     pos = torch.empty(input_ids.shape[0], device=input_ids.device, dtype=torch.int32)
-    ops.find_token(input_ids.contiguous(), token_id, pos, None)
+    ops.find_token(input_ids.contiguous(), token_id, pos, None, status=_status(input_ids.device))
     return pos
 
 
@@ -244,7 +282,7 @@ class LazyLogits:
         B, L = input_ids.shape
         pos = torch.empty(B, device=input_ids.device, dtype=torch.int32)
         row = torch.empty(B, device=input_ids.device, dtype=torch.int32)
-        ops.find_token(input_ids.contiguous(), mask_token_id, pos, row)
+        ops.find_token(input_ids.contiguous(), mask_token_id, pos, row, status=_status(input_ids.device))     # absent: row b*L+0 + status bit (check_status)
         return LazyRows(self, row)
 
     def materialize(self) -> torch.Tensor:

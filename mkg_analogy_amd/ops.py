@@ -362,16 +362,21 @@ def transpose_bf16(inp, out, R, Cc, Rp, batch=1, stride_i=0, stride_o=0):
             "mart_transpose_bf16")
 
 
-def lsce_fwd(logits, label, eps, loss_rows, lse):
+REDUCE = {"none": 0, "mean": 1, "sum": 2}
+
+
+def lsce_fwd(logits, label, eps, loss_rows, lse, ignore_index=-100, loss_out=None, reduction="none", status=None):
+    """``loss_out`` (f32 [2] on the device): {reduced loss, n_valid}; ``status`` (int32 [1]): set to 1 by a label outside [0, C) u {ignore}."""
     R, Cc = logits.shape
-    L.check(L.lib().mart_lsce_fwd(_p(logits), _rows2d(logits), _p(label), eps, _p(loss_rows), _p(lse), R, Cc, _stream()), "mart_lsce_fwd")
+    L.check(L.lib().mart_lsce_fwd(_p(logits), _rows2d(logits), _p(label), int(ignore_index), eps, _p(loss_rows), _p(lse), _p(loss_out), REDUCE[reduction],
+                                  _p(status), R, Cc, _stream()), "mart_lsce_fwd")
 
 
-def lsce_bwd(logits, label, lse, eps, gscale, rowscale, dl_bf16=None, dl_f32=None):
+def lsce_bwd(logits, label, lse, eps, gscale, rowscale, dl_bf16=None, dl_f32=None, ignore_index=-100, n_valid=None, gscale_per_row=False):
     R, Cc = logits.shape
     ldo = _rows2d(dl_bf16) if dl_bf16 is not None else Cc
-    L.check(L.lib().mart_lsce_bwd(_p(logits), _rows2d(logits), _p(label), _p(lse), eps, _p(gscale), rowscale, _p(dl_bf16), ldo,
-                                  _p(dl_f32), R, Cc, _stream()), "mart_lsce_bwd")
+    L.check(L.lib().mart_lsce_bwd(_p(logits), _rows2d(logits), _p(label), int(ignore_index), _p(lse), eps, _p(gscale), int(gscale_per_row), rowscale,
+                                  _p(n_valid), _p(dl_bf16), ldo, _p(dl_f32), R, Cc, _stream()), "mart_lsce_bwd")
 
 
 def rank(logits, label, out):
@@ -390,9 +395,9 @@ def simloss_bwd(trans, rel_idx, q_idx, a_idx, gscale, rowscale, dtrans):
             "mart_simloss_bwd")
 
 
-def find_token(ids, token, pos_out, row_out=None):
+def find_token(ids, token, pos_out, row_out=None, status=None):
     B, Lq = ids.shape
-    L.check(L.lib().mart_find_token(_p(ids), B, Lq, token, _p(pos_out), _p(row_out), _stream()), "mart_find_token")
+    L.check(L.lib().mart_find_token(_p(ids), B, Lq, token, _p(pos_out), _p(row_out), _p(status), _stream()), "mart_find_token")
 
 
 def cast_f32_bf16(src, dst):

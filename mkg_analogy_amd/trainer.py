@@ -8,6 +8,7 @@ from typing import Dict, Iterable, List, Optional
 
 import torch
 
+from . import functional as Fn
 from .distributed import GradSync, all_gather_ranks
 
 
@@ -91,9 +92,11 @@ class Trainer:
             for i, batch in enumerate(train_batches):
                 loss = self.train_step(lit, batch, i, end_of_epoch=(i == n - 1))
                 if self.log_every and (i + 1) % self.log_every == 0:
+                    Fn.check_status()
                     print(f"epoch {epoch} step {i + 1}: loss {float(loss):.4f} lr {self.optimizer.param_groups[0]['lr']:.3e}")
                 if self.max_steps and self.global_step >= self.max_steps:
                     break
+            Fn.check_status()                                      # bad labels / examples without [MASK] seen during the epoch (one host sync)
             rec = {"epoch": epoch, "train_time_s": time.time() - t0}
             if val_batches is not None:
                 rec.update(self.validate(lit, val_batches))
@@ -105,6 +108,7 @@ class Trainer:
     def _run_eval(self, lit, batches, step_fn, end_fn) -> Dict[str, float]:
         lit.model.eval()
         outs = [step_fn(dict(b), i) for i, b in enumerate(batches)]
+        Fn.check_status()                                          # (the ranks were copied to the host already: no extra sync)
         merged = {}
         sharded = self._shards(batches) > 1 or getattr(batches, "sharded", False)   # every rank saw the whole set otherwise: no gather
         for key in ("entity_ranks", "relation_ranks"):

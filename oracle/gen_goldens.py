@@ -335,6 +335,31 @@ def g3(lit, out_dir):
     print("G3 ok", float(loss), ranks, (t2 + 1).numpy())
 
 
+def g3b(out_dir):
+    """LabelSmoothSoftmaxCEV1 with ignored labels (lit_models/utils.py:47-62): six rows, two of them ignore_index = -100; reductions
+    'mean' (sum / n_valid), 'sum' and per-row ('none'), each with the gradient of the logits."""
+    from lit_models.utils import LabelSmoothSoftmaxCEV1
+    rng = np.random.default_rng(33)
+    logits = torch.from_numpy(rng.standard_normal((6, 37), dtype=np.float32) * 3)
+    label = torch.from_numpy(rng.integers(0, 37, size=6))
+    label[1] = -100
+    label[4] = -100
+    out = dict(logits=logits.numpy(), label=label.numpy(), ignore_index=np.int64(-100))
+    w = torch.from_numpy(rng.standard_normal(6).astype(np.float32))
+    for red in ("mean", "sum", "none"):
+        lg = logits.clone().requires_grad_(True)
+        loss = LabelSmoothSoftmaxCEV1(lb_smooth=0.1, reduction=red)(lg, label)
+        (loss if red != "none" else (loss * w).sum()).backward()
+        out["loss_" + red] = loss.detach().numpy().astype(np.float64)
+        out["grad_" + red] = lg.grad.numpy()
+    out["none_weights"] = w.numpy()
+    # every row ignored: 0 / 0 (utils.py:60)
+    allign = LabelSmoothSoftmaxCEV1(lb_smooth=0.1)(logits.clone(), torch.full((6,), -100, dtype=torch.long))
+    out["loss_mean_all_ignored_isnan"] = np.bool_(bool(torch.isnan(allign)))
+    np.savez_compressed(os.path.join(out_dir, "g3b_lsce_ignore.npz"), **out)
+    print("G3b ok", out["loss_mean"], out["loss_sum"], out["loss_none"], bool(torch.isnan(allign)))
+
+
 def load_reference_flava():
     """The reference's FLAVA module imported in place, with the extra shims of SURVEY 8(c): prune helpers stubbed into
     transformers.modeling_utils; get_head_mask / get_extended_attention_mask of FlavaPreTrainedModel overridden with the
@@ -416,10 +441,14 @@ def g5_flava(out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default=None, help="g3b: only the ignored-label LSCE golden")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     torch.set_num_threads(8)
     lit, unimo = load_reference()
+    g3b(a.out)
+    if a.only == "g3b":
+        return
     g3(lit, a.out)
     g2(unimo, a.out)
     g1_g4(lit, unimo, a.out)

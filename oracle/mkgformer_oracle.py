@@ -358,13 +358,22 @@ def score(sd, trans_rows: Tensor, ids) -> Tensor:
 
 
 # --------------------------------------------------------------------------- losses / ranking
-def label_smooth_ce(logits: Tensor, label: Tensor, eps: float = 0.1) -> Tensor:
-    """LabelSmoothSoftmaxCEV1.forward (lit_models/utils.py:42-66), reduction='mean', no ignored labels:
-    target = eps/C everywhere, overwritten with 1-eps at the label."""
+def label_smooth_ce(logits: Tensor, label: Tensor, eps: float = 0.1, ignore_index: int = -100, reduction: str = "mean") -> Tensor:
+    """LabelSmoothSoftmaxCEV1.forward (lit_models/utils.py:42-66): target = eps/C everywhere, overwritten with 1-eps at the label; rows whose
+    label == ignore_index (:49-52) give 0 (:58); 'mean' = sum / n_valid (:59-60), 'sum' (:61-62), anything else per-row."""
     C = logits.shape[1]
+    ignore = label == ignore_index
+    n_valid = (~ignore).sum()
+    lab = label.masked_fill(ignore, 0)
     tgt = torch.full_like(logits, eps / C)
-    tgt.scatter_(1, label[:, None], 1.0 - eps)
-    return -(torch.log_softmax(logits, dim=1) * tgt).sum(1).sum() / logits.shape[0]
+    tgt.scatter_(1, lab[:, None], 1.0 - eps)
+    rows = -(torch.log_softmax(logits, dim=1) * tgt).sum(1)
+    rows = rows.masked_fill(ignore, 0.0)
+    if reduction == "mean":
+        return rows.sum() / n_valid
+    if reduction == "sum":
+        return rows.sum()
+    return rows
 
 
 def relaxation_loss(trans: Tensor, rel_idx: Tensor, q_head_idx: Tensor, a_head_idx: Tensor) -> Tensor:

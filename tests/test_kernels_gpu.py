@@ -642,6 +642,49 @@ def test_embeddings(ops):
     close(dty, torch.zeros_like(typ).index_add_(0, tt.view(-1), ds2), 1e-3, 1e-5, "dtype")
 
 
+def test_lsce_ignored_labels(ops, golden_dir):
+    """LabelSmoothSoftmaxCEV1 through the C ABI with ignore_index rows (reference golden G3b, lit_models/utils.py:47-62): 'mean' divides by
+    n_valid, ignored rows get loss 0 and a zero gradient row; 'sum' / per-row; a label outside [0, C) that is not ignore_index poisons the
+    row (NaN), sets the status word and reads nothing out of bounds; every row ignored -> 0 / 0 = NaN as the reference."""
+    import os
+    from mkg_analogy_amd import functional as Fn
+    from mkg_analogy_amd.lit_models.utils import LabelSmoothSoftmaxCEV1
+    g = np.load(os.path.join(golden_dir, "g3b_lsce_ignore.npz"))
+    label = torch.from_numpy(g["label"]).to(DEV)
+    w = torch.from_numpy(g["none_weights"]).to(DEV)
+    for red in ("mean", "sum", "none"):
+        lg = torch.from_numpy(g["logits"]).to(DEV).requires_grad_(True)
+        loss = LabelSmoothSoftmaxCEV1(lb_smooth=0.1, reduction=red, ignore_index=int(g["ignore_index"]))(lg, label)
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), g["loss_" + red], rtol=2e-6, atol=2e-5)
+        (loss if red != "none" else (loss * w).sum()).backward()
+        close(lg.grad, torch.from_numpy(g["grad_" + red]).to(DEV), 1e-6, 1e-4, f"lsce grad, ignored rows, reduction {red}")
+        assert float(lg.grad[[1, 4]].abs().max()) == 0.0
+    Fn.check_labels()                                              # nothing out of range so far
+    lg = torch.from_numpy(g["logits"]).to(DEV)
+    assert torch.isnan(LabelSmoothSoftmaxCEV1(0.1)(lg, torch.full((6,), -100, device=DEV, dtype=torch.long)))
+    # the raw ABI with the bf16 output as the engine uses it: ignored rows zero, padding zero
+    R, Cc = lg.shape
+    rows, lse, red2 = torch.empty(R, device=DEV), torch.empty(R, device=DEV), torch.empty(2, device=DEV)
+    ops.lsce_fwd(lg, label, 0.1, rows, lse, ignore_index=-100, loss_out=red2, reduction="mean")
+    assert float(red2[1]) == 4.0 and float(rows[1]) == 0.0 and float(rows[4]) == 0.0
+    dlb = torch.full((R, 64), 3.0, device=DEV, dtype=BF)
+    ops.lsce_bwd(lg, label, lse, 0.1, torch.ones(1, device=DEV), 1.0, dl_bf16=dlb, ignore_index=-100, n_valid=red2[1:])
+    assert float(dlb[:, Cc:].abs().max()) == 0 and float(dlb[[1, 4]].abs().max()) == 0
+    close(dlb[:, :Cc].float(), torch.from_numpy(g["grad_mean"]).to(DEV), 4e-3, 1e-2, "lsce bf16 grad, ignored rows")
+    # out-of-range labels (the reference's scatter_ raises): NaN row + status, and the trainer-side check raises once
+    bad = label.clone()
+    bad[0] = Cc
+    bad[2] = -7
+    loss = LabelSmoothSoftmaxCEV1(0.1)(lg.clone().requires_grad_(True), bad)
+    assert torch.isnan(loss)
+    with pytest.raises(IndexError):
+        Fn.check_labels()
+    Fn.check_labels()
+    rk = torch.empty(R, device=DEV, dtype=torch.long)
+    ops.rank(lg, bad, rk)
+    assert int(rk[0]) == 0 and int(rk[2]) == 0 and int(rk[3]) >= 1
+
+
 def test_loss_rank_kernels(ops, golden_dir):
     import os
     g = np.load(os.path.join(golden_dir, "g3_loss_rank.npz"))
@@ -708,6 +751,12 @@ def test_adamw_and_misc(ops):
     pos, row = torch.empty(4, dtype=torch.int32, device=DEV), torch.empty(4, dtype=torch.int32, device=DEV)
     ops.find_token(ids.to(DEV), 103, pos, row)
     assert pos.tolist() == [3, 15, 0, 9] and row.tolist() == [3, 31, 32, 57]
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.find_token(ids.to(DEV), 103, pos, row, status=status)
+    assert int(status) == 0
+    ids[1, 15] = 7                                      # an example without the token: pos -1, row b*L+0, status bit 1
+    ops.find_token(ids.to(DEV), 103, pos, row, status=status)
+    assert pos.tolist() == [3, -1, 0, 9] and row.tolist() == [3, 16, 32, 57] and int(status) == 2
 
 
 def test_device_side_batch_assembly(ops):

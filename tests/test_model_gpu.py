@@ -529,3 +529,36 @@ def test_store_ownership_fast_path_and_rebuild():
     with torch.no_grad():
         _, t2 = model(**kw)
     assert not torch.equal(t1, t2)                                 # the new bias is the one the kernels read
+
+
+def test_example_without_mask_token_is_flagged_not_nan():
+    """an example that holds no [MASK] (truncated / malformed).  The reference raises a shape mismatch at
+    ``logits[arange(bs), mask_idx]`` (lit_models/transformer.py:94-95).  Here the step stays finite -- ``needed_rows`` and the [MASK]-row lookup
+    agree on row 0 of that example, so nothing NaN reaches the loss, the gradients or AdamW -- and ``Fn.check_status`` raises for it."""
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd import functional as Fn
+    model, lit, cfg, vc = _product(32, seed=3, conditioned=True)
+    assert lit.last_layer_rows
+    batch = D.make_batch(4, 64, seed=11)
+    ids = batch["input_ids"].clone()
+    ids[2][ids[2] == 103] = 1999                        # example 2 loses its [MASK]
+    batch["input_ids"] = ids
+    gb = {k: v.cuda() for k, v in batch.items()}
+    Fn.check_status()
+    model.train()
+    st = model.store
+    st.zero_grad()
+    loss = lit.training_step(dict(gb), 1)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert math.isfinite(float(loss))
+    assert bool(torch.isfinite(st.grad).all())
+    with pytest.raises(IndexError, match="MASK"):
+        Fn.check_status()
+    Fn.check_status()                                   # reported once
+    # the evaluation pass flags it as well (Trainer._run_eval checks after the pass)
+    model.eval()
+    out = lit.validation_step(dict(gb), 0)
+    assert out["entity_ranks"].shape == (4,)
+    with pytest.raises(IndexError, match="MASK"):
+        Fn.check_status()

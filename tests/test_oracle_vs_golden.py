@@ -106,6 +106,21 @@ def test_g2_real_dim_layers(golden_dir):
     np.testing.assert_allclose(sd[q + "mlp.fc1.weight"].grad.numpy()[:8], g["g_vfc1_w"], rtol=2e-3, atol=1e-4)
 
 
+def test_g3b_lsce_ignored_labels(golden_dir):
+    """LabelSmoothSoftmaxCEV1 with ignore_index rows (lit_models/utils.py:47-62), all three reductions, vs the reference golden G3b."""
+    g = np.load(os.path.join(golden_dir, "g3b_lsce_ignore.npz"))
+    label = torch.from_numpy(g["label"])
+    w = torch.from_numpy(g["none_weights"])
+    for red in ("mean", "sum", "none"):
+        lg = torch.from_numpy(g["logits"]).requires_grad_(True)
+        loss = O.label_smooth_ce(lg, label, 0.1, ignore_index=int(g["ignore_index"]), reduction=red)
+        np.testing.assert_allclose(loss.detach().numpy(), g["loss_" + red], atol=2e-6)
+        (loss if red != "none" else (loss * w).sum()).backward()
+        np.testing.assert_allclose(lg.grad.numpy(), g["grad_" + red], atol=1e-7)
+    assert bool(g["loss_mean_all_ignored_isnan"])
+    assert torch.isnan(O.label_smooth_ce(torch.from_numpy(g["logits"]), torch.full((6,), -100, dtype=torch.long), 0.1))
+
+
 def test_g3_loss_and_ranks(golden_dir):
     g = np.load(os.path.join(golden_dir, "g3_loss_rank.npz"))
     lg = torch.from_numpy(g["logits"]).requires_grad_(True)
