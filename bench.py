@@ -284,6 +284,76 @@ def reference_parity(model, lit, batch, cfg, dev, timed_weights: str):
     return res
 
 
+def self_launch(n: int) -> int:
+    """Re-execute this command line under ``python -m torch.distributed.run`` with ``n`` ranks on this node (one process per GPU, rendezvous on
+    127.0.0.1, a free port), exactly the command the driver uses for N > 1; stdout / stderr pass through, so rank 0's JSON line is this process's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+class PowerSampler:
+    """Package power and shader clock of GPU ``index`` sampled from a helper thread while a timed region runs (rocm-smi, a few Hz; a separate
+    process per sample, so the launching thread is not slowed).  ``median()`` -> (W, MHz, n) or (None, None, 0) where the tool is absent."""
+
+    def __init__(self, index: int = 0):
+        import shutil
+        self.index, self.samples, self._stop, self._th = index, [], False, None
+        self.tool = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop:
+            try:
+                out = subprocess.run([self.tool, "-d", str(self.index), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:
+                return
+            p = re.search(r"Power \(W\): ([0-9.]+)", out)
+            c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out) or re.search(r"sclk clock level: \S+: \((\d+)Mhz\)", out)
+            if p and c:
+                self.samples.append((time.perf_counter(), float(p.group(1)), int(c.group(1))))
+
+    def __enter__(self):
+        if self.tool:
+            import threading
+            self._th = threading.Thread(target=self._run, daemon=True)
+            self._th.start()
+        self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *a):
+        self.t1 = time.perf_counter()
+        self._stop = True
+
+    def median(self):
+        if self._th is not None:
+            self._th.join(timeout=15)
+        xs = [(w, c) for t, w, c in self.samples if self.t0 <= t <= self.t1 + 0.05]
+        if not xs:
+            return None, None, 0
+        med = lambda v: sorted(v)[len(v) // 2]
+        return med([w for w, _ in xs]), med([c for _, c in xs]), len(xs)
+
+
+def timed_leg(tr, lit, batch, n_warm: int, n_steps: int, barrier, first_idx: int = 0):
+    """``n_warm`` untimed + ``n_steps`` timed training steps of an already set-up trainer; seconds of the timed part."""
+    for i in range(n_warm):
+        tr.train_step(lit, batch, first_idx + i)
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(n_steps):
+        tr.train_step(lit, batch, first_idx + n_warm + i)
+    barrier()
+    return time.perf_counter() - t1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -315,6 +385,9 @@ def main():
         print(cpu_step_rate(a.patch, a.seq_len, a.cpu_rate_only, a.cpu_iters), flush=True)
         return
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(a.gpus))                # `python bench.py --gpus N` as typed: spawn the N ranks (one per GPU) and relay rank 0's line
+
     from mkg_analogy_amd import data_synth as D
     from mkg_analogy_amd import ops
     from mkg_analogy_amd.distributed import init_from_env
@@ -322,7 +395,9 @@ def main():
     import torch.distributed as dist
 
     rank, local, world = init_from_env()
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, "
+                         f"or run `python bench.py --gpus {a.gpus}` without WORLD_SIZE / RANK in the environment (it then starts its own ranks)")
     ops.require_gpu()
     dev = torch.device("cuda", local)
     pre = a.task == "pretrain"
@@ -350,11 +425,13 @@ def main():
     for i in range(a.warmup):
         loss = tr.train_step(lit, batch, i)
     barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss = tr.train_step(lit, batch, a.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
+    with PowerSampler(local) as psamp:               # (helper thread; rank 0 reports it)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            loss = tr.train_step(lit, batch, a.warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
+    power_w, sclk_mhz, n_power = psamp.median() if rank == 0 else (None, None, 0)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -418,6 +495,12 @@ def main():
                 "algorithmic_bytes_per_launch": round(by / max(n, 1)), "launches_per_step": n, "ms_per_step": round(kms, 3),
                 "avg_launch_ms": round(kms / max(n, 1), 4), "algorithmic_gflop_per_launch": round(fl / max(n, 1) / 1e9, 1),
                 "step_frac_of_mfma_peak": round(value / world * train_gflop / 2.5e6, 4),
+                # the roofline at the clock the box actually granted during the timed region (the chip clocks to its package power cap: 2.5 PF is the
+                # 2.4 GHz figure); null when rocm-smi could not be sampled
+                "power_w": power_w, "sclk_mhz": sclk_mhz, "power_samples": n_power,
+                "frac_at_granted_clock": round(ach / (2500.0 * sclk_mhz / 2400.0), 4) if sclk_mhz else None,
+                "step_frac_at_granted_clock": round(value / world * train_gflop / 2.5e6 / (sclk_mhz / 2400.0), 4) if sclk_mhz else None,
+                "power_note": "medians of rocm-smi --showpower --showclocks sampled by a helper thread during the timed region of the headline steps",
                 "timing": "HIP events around every launch, one step with the side streams (weight gradients, text layers) off: kernel alone on the GPU",
                 "achieved_with_wgrad_overlap": round(fl_ov / (kms_ov * 1e-3) / 1e12, 1) if kms_ov > 0 else None,
                 "avg_launch_ms_with_wgrad_overlap": round(kms_ov / max(n_ov, 1), 4), "other_kernels": others}
@@ -440,6 +523,12 @@ def main():
     # Hits@1 of the (untrained, random-init) model on the same batch -- reported to exercise the ranking eval path (fp32-accurate pass: the
     # evaluation default, so the ranks behind this number are the reference's wherever its own margins are not rounding-level)
     metrics = tr.validate(lit, [batch]) if not a.train_only else {}
+    held_out_hits1 = None
+    if not a.train_only and not pre:
+        # the same pass over a batch the network has NOT been stepped on (random labels: chance level, 1 / entity_head)
+        hb = D.make_batch(a.batch, a.seq_len, seed=99991 + rank, device=dev, pretrain=pre, n_labels=head)
+        held_out_hits1 = tr.validate(lit, [hb]).get("Eval_entity/hits1")
+        del hb
     evalb = None
     if world == 1 and not a.train_only and not a.no_kernel_timing:
         # Evaluation-path throughput (lit_models/transformer.py:115-166: forward + scoring + rank of the label), per precision mode
@@ -537,6 +626,32 @@ def main():
                 "patches_per_image": 49, "vision_tokens": 99, "steps": 5, "warmup": 3, "ms_per_step": round(1000.0 * d5 / 5, 3), "value": round(v5, 2),
                 "train_gflop_per_example": round(gf5, 1), "step_frac_of_mfma_peak": round(v5 * gf5 / 2.5e6, 4),
                 "roofline_examples_per_s": round(2.5e6 / gf5, 1)}
+    altt = altm = None
+    if world == 1 and a.model == "mkgformer" and not pre and a.patch == 16 and not a.no_kernel_timing and not a.train_only:
+        # BASELINE configs[4] and configs[3] on the driver's box, briefly (2 warm-up + 5 timed steps each): the MarKG pre-train step (L = 96, LSCE over the
+        # full 11 292-entity / 192-relation slices, pre_type 50 / 50, no sep_idx) and the FLAVA backbone (12 + 12 + 6 layers, 393 image tokens, B = 256).
+        # The full-length runs with per-kernel tables are profiles/r06_bench_{pretrain,flava}.json (python bench.py --task pretrain --seq-len 96 / --model flava).
+        def leg(backbone, task_pre, L_, what):
+            try:
+                torch.cuda.empty_cache()
+                m_, lit_, _ = build(a.patch, seed=0, device=dev, backbone=backbone, entity_head=D.N_ANALOGY if task_pre else head)
+                if task_pre:
+                    lit_.args.pretrain = 1
+                b_ = D.make_batch(a.batch, L_, seed=1234, device=dev, pretrain=task_pre, n_labels=D.N_ENT if task_pre else head)
+                tr_ = Trainer(max_epochs=1, max_steps=200, world_size=1)
+                tr_._setup(lit_, [None] * 200)
+                d_ = timed_leg(tr_, lit_, b_, 2, 5, barrier)
+                v_ = a.batch * 5 / d_
+                gf_ = 3.0 * (fwd_gflop_per_example(P, L_, D.N_ENT if task_pre else head) if backbone == "mkgformer" else flava_fwd_gflop_per_example(P, L_, head))
+                return {"what": what, "batch": a.batch, "seq_len": L_, "patches_per_image": P, "steps": 5, "warmup": 2, "ms_per_step": round(1000.0 * d_ / 5, 3),
+                        "value": round(v_, 2), "unit": "examples/s", "train_gflop_per_example": round(gf_, 1), "step_frac_of_mfma_peak": round(v_ * gf_ / 2.5e6, 4)}
+            except Exception as e:                      # a failure of a side leg must not lose the headline measurement
+                return {"what": what, "error": f"{type(e).__name__}: {e}"[:300]}
+            finally:
+                torch.cuda.empty_cache()
+        m2 = lit2 = tr2 = None                          # (the 49-patch network of alt_geometry)
+        altt = leg("mkgformer", True, 96, "BASELINE configs[4]: MarKG pre-train step (link prediction), L = 96, heads E = 11292 / R = 192, pre_type 50/50, no sep_idx")
+        altm = leg("flava", False, a.seq_len, "BASELINE configs[3]: FLAVA-base backbone (12 image + 12 text + 6 multimodal layers, 393 image tokens), fine-tune step")
     spread = None
     if world > 1:
         # data-parallel self-check: every replica must hold the same weights after the same all-reduced updates
@@ -558,7 +673,10 @@ def main():
                           "entity_head": head, "relation_head": D.N_REL if pre else None, "vocab": D.VOCAB, "parallelism": f"dp{world}",
                           "weights": {"plain": "random-init N(0,0.02) (torch RNG)", "g7plain": "random-init N(0,0.02), the seeded set of golden G7 (plain)",
                                       "conditioned": "random-init N(0,0.02), the seeded, well-conditioned set of golden G7 (text value projections of layers 8-11 x 0.05)"}[a.weights]},
-               "loss": round(float(loss), 4), "hits1": metrics.get("Eval_entity/hits1"),
+               "loss": round(float(loss), 4),
+               # NOT an accuracy: the ranking eval of the timed batch after the network has taken steps + warmup (+ diagnostics) updates ON that very
+               # batch (memorised: -> 1.0).  No trained weights / real MARS split exist offline; the line exercises the Hits@1 path, nothing more.
+               "hits1_on_the_timed_batch": metrics.get("Eval_entity/hits1"), "hits1_held_out_synthetic_batch": held_out_hits1,
                "train_gflop_per_example": round(train_gflop, 1)}
         if spread is not None:
             out["replica_param_checksum_spread"] = spread        # 0.0: all ranks hold identical weights
@@ -572,6 +690,10 @@ def main():
             out["alt_weights"] = altw
         if altg is not None:
             out["alt_geometry"] = altg
+        if altt is not None:
+            out["alt_task"] = altt
+        if altm is not None:
+            out["alt_model"] = altm
         if tsplit is not None:
             out["alt_text_precision"] = tsplit
         if evalb is not None:

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import functional as Fn
-from ..optim import FusedAdamW, LinearWarmupSchedule
+from ..optim import FusedAdamW, LinearWarmupSchedule, TorchOptimizerOnStore
 from .base import BaseLitModel
 from .utils import LabelSmoothSoftmaxCEV1
 
@@ -188,12 +188,13 @@ class TransformerLitModel(BaseLitModel):
 
     # -- lit_models/transformer.py:224-241
     def configure_optimizers(self):
-        if self.optimizer_name != "AdamW":
-            raise NotImplementedError("the HIP path implements AdamW (the only optimizer MarT's scripts use)")
+        dead = [n for n in self.model.store.slots if "adaptive_weight" in n] if self.args.pretrain else []
         if self.args.pretrain:          # no sep_idx => the adaptive weights get grad None in the reference => torch never touches them
-            st = self.model.store
-            st.rebuild_chunks(extra_dead=[n for n in st.slots if "adaptive_weight" in n])
-        optimizer = FusedAdamW(self.model, lr=self.lr, eps=1e-8, weight_decay=self.args.weight_decay)
+            self.model.store.rebuild_chunks(extra_dead=dead)
+        if self.optimizer_name == "AdamW":
+            optimizer = FusedAdamW(self.model, lr=self.lr, eps=1e-8, weight_decay=self.args.weight_decay)
+        else:                           # base.py:31: any torch.optim class by name (torch's own update on the fp32 master views; not the fused path)
+            optimizer = TorchOptimizerOnStore(self.model, self.optimizer_name, lr=self.lr, eps=1e-8, weight_decay=self.args.weight_decay, extra_dead=dead)
         steps = self.num_training_steps
         scheduler = LinearWarmupSchedule(optimizer, num_warmup_steps=steps * self.args.warm_up_radio, num_training_steps=steps)
         return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "interval": "step", "frequency": 1}}

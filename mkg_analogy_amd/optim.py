@@ -134,6 +134,47 @@ class FusedAdamW(torch.optim.Optimizer):
             g["lr"] = sd["lr"]
 
 
+class TorchOptimizerOnStore:
+    """Any other ``torch.optim`` class by name, as the reference allows (lit_models/base.py:31 ``getattr(torch.optim, optimizer)``;
+    lit_models/transformer.py:224-232: the same two weight-decay groups, ``lr``, ``eps=1e-8`` -- so, as there, only classes that take ``eps``).
+    The update is torch's own (its kernels, on the fp32 master views: ``p`` / ``p.grad`` are views of FlatStore.master / .grad); afterwards the
+    bf16 / fp16 / W^T operand shadows follow.  Tensors that never receive a gradient in the reference (grad None: torch skips them -- no update,
+    no weight decay) are left out, like FusedAdamW's chunk table does.  Not the fast path: AdamW is the fused kernel."""
+
+    def __init__(self, model, name: str, lr=5e-5, eps=1e-8, weight_decay=0.01, extra_dead=()):
+        cls = getattr(torch.optim, name)                       # AttributeError for an unknown name, as the reference
+        store = model.store
+        dead = tuple(store.dead) + tuple(extra_dead)
+        named = {n: p for n, p in model.named_parameters() if p.requires_grad and not (dead and n.startswith(dead))}
+        decay = [p for n, p in named.items() if not any(nd in n for nd in NO_DECAY)]
+        no_decay = [p for n, p in named.items() if any(nd in n for nd in NO_DECAY)]
+        self.inner = cls([{"params": decay, "weight_decay": weight_decay}, {"params": no_decay, "weight_decay": 0}], lr=lr, eps=eps)
+        self.model, self.grad_scale, self._store_id = model, 1.0, id(store)
+
+    @property
+    def param_groups(self):
+        return self.inner.param_groups
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.model.store.zero_grad()                           # the gradient buffer is persistent (kernels accumulate into it): never None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        store = self.model.store
+        if id(store) != self._store_id:
+            raise RuntimeError("the model's parameter storage was rebuilt (resize/.to()) after the optimizer was created")
+        if self.grad_scale != 1.0:
+            store.grad.mul_(self.grad_scale)                   # 1 / world (DDP mean) and 1 / accumulation windows
+        self.inner.step()
+        store.refresh_shadows()
+
+    def state_dict(self):
+        return self.inner.state_dict()
+
+    def load_state_dict(self, sd):
+        self.inner.load_state_dict(sd)
+
+
 class LinearWarmupSchedule:
     """lambda(t) = t/max(1,w) for t<w else max(0,(T-t)/max(1,T-w)); w may be fractional (0.1*T)."""
 

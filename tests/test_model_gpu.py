@@ -562,3 +562,47 @@ def test_example_without_mask_token_is_flagged_not_nan():
     assert out["entity_ranks"].shape == (4,)
     with pytest.raises(IndexError, match="MASK"):
         Fn.check_status()
+
+
+def test_torch_optimizer_by_name_equals_fused_adamw_and_runs_adam():
+    """lit_models/base.py:31 takes any torch.optim class by name.  (1) torch.optim.AdamW routed through TorchOptimizerOnStore gives the fused
+    kernel's update on the same gradients (fp32 rounding), dead tensors untouched by both, shadows following the master; (2) ``--optimizer Adam``
+    drives two training steps through the trainer."""
+    import argparse as ap
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.optim import FusedAdamW, TorchOptimizerOnStore
+    from mkg_analogy_amd.trainer import Trainer
+    model, lit, cfg, vc = _product(32, seed=11, conditioned=True)
+    st = model.store
+    g = torch.Generator(device="cpu").manual_seed(3)
+    grad = (torch.randn(st.total, generator=g) * 1e-3).cuda()
+    m0 = st.master.clone()
+    st.grad.copy_(grad)
+    fused = FusedAdamW(model, lr=1e-3)
+    for _ in range(2):
+        fused.step()
+    ref = st.master.clone()
+    st.master.copy_(m0)
+    st.refresh_shadows()
+    st.grad.copy_(grad)
+    gen = TorchOptimizerOnStore(model, "AdamW", lr=1e-3)
+    for _ in range(2):
+        gen.step()
+    torch.cuda.synchronize()
+    assert float((st.master - ref).abs().max()) < 2e-6
+    assert torch.equal(st.shadow, st.master.to(torch.bfloat16))
+    s = st.slots["unimo.text_pooler.dense.weight"]                      # never receives a gradient in the reference: no update, no decay
+    assert torch.equal(st.master[s.offset:s.offset + s.numel], m0[s.offset:s.offset + s.numel])
+    with pytest.raises(AttributeError):
+        TorchOptimizerOnStore(model, "NoSuchOptimizer")
+    lit.optimizer_name = "Adam"
+    tr = Trainer(max_epochs=1, max_steps=10)
+    gb = {k: v.cuda() for k, v in D.make_batch(2, 64, seed=5).items()}
+    tr._setup(lit, [gb] * 10)
+    assert isinstance(tr.optimizer, TorchOptimizerOnStore) and type(tr.optimizer.inner).__name__ == "Adam"
+    w0 = st.master.clone()
+    for i in range(2):
+        loss = tr.train_step(lit, gb, i)
+    torch.cuda.synchronize()
+    assert math.isfinite(float(loss)) and not torch.equal(st.master, w0)
+    assert torch.equal(st.shadow, st.master.to(torch.bfloat16))

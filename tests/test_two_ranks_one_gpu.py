@@ -30,3 +30,20 @@ def test_bench_two_ranks_share_one_gpu():
     # communication diagnostics of the N > 1 path
     assert d["rccl_world"] == 2 and d["comm"]["buckets"] >= 1 and d["comm"]["bucket_dtype"] == "fp32"
     assert d["comm"]["comm_ms_per_step"] > 0 and 0 <= d["comm_exposed_ms"] <= d["comm"]["comm_ms_per_step"] + 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` as typed (no WORLD_SIZE / RANK in the environment: the shape of the driver's N = 1 command with a larger N) starts its
+    own two ranks under torch.distributed.run and relays rank 0's single JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LOCAL_WORLD_SIZE", "GROUP_RANK")}
+    env.update(MART_DIST_BACKEND="gloo", MART_DEVICE_INDEX="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--patch", "32",
+           "--no-cpu-baseline", "--no-kernel-timing", "--train-only"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["value"] > 0
+    assert d["replica_param_checksum_spread"] == 0.0, d
