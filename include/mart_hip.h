@@ -284,12 +284,28 @@ int mart_lsce_bwd(const float* logits, int ld, const int64_t* label, long long i
 /* rank = 1 + #(logit > logit[label])  == argsort(argsort(-logits))[label]+1 without ties (lit_models/transformer.py:162-164);
  * a label outside [0, C) gives rank 0 */
 int mart_rank(const float* logits, int ld, const int64_t* label, int64_t* rank, int R, int C, void* stream);
-/* relaxation loss rows (lit_models/transformer.py:103-108): relu(cos(q,a)) + 1 - cos(r0,r1) on rows of trans [B,L,H] */
-int mart_simloss_fwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, float* loss_rows,
+/* relaxation loss rows (lit_models/transformer.py:103-108): relu(cos(q,a)) + 1 - cos(r0,r1) on rows of trans.
+ * rows == NULL: trans is the dense [B,L,H] tensor.  rows != NULL (row-subset pass): trans is the COMPACT [B*nr, H] tensor and rows[b*nr + j] the flat id
+ * b*L + position of its slot j; a position the pass was not promised makes that example's loss NaN (nothing is read for it). */
+int mart_simloss_fwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, const int32_t* rows, int nr, float* loss_rows,
                      int B, int L, int H, void* stream);
-/* dtrans (atomic +=) for the four gathered rows; g = gscale[0]*rowscale */
-int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, const float* gscale,
+/* dtrans (atomic +=; same layout as trans) for the four gathered rows; g = gscale[0]*rowscale */
+int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, const int32_t* rows, int nr, const float* gscale,
                      float rowscale, float* dtrans, int B, int L, int H, void* stream);
+
+/* ---------------------------------------------------------------- row-subset passes (forward(needed_rows=...), engine.forward(rows=...))
+ * rows [B, nr] int32: flat ids b*L + position of the rows example b was promised, grouped by example.
+ * mart_needed_rows: the rows of a training / evaluation step built on the device in one launch -- column 0 the first position of `token` ([MASK];
+ * absent: position 0 and status bit 1, as mart_find_token), then rel_idx[:,0], rel_idx[:,1], q_idx, a_idx when given (nr = 5, else 1); negative
+ * positions wrap, then clamp.  mask_row_out (may be NULL) [B] = column 0. */
+int mart_needed_rows(const int64_t* ids, int B, int L, int64_t token, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx,
+                     int32_t* rows_out, int32_t* mask_row_out, int32_t* status, void* stream);
+/* out[i] = compact index (b*nr + slot, first slot that names it) of flat row id flat[i]; a row outside the promise: slot 0 of its example and status bit 2 (value 4) */
+int mart_rows_lookup(const int32_t* flat, int n, const int32_t* rows, int nr, int L, int32_t* out, int32_t* status, void* stream);
+/* out[i] = sum_s parts[s*n + i], s = 0 .. S-1 in order: the reduction of a split-K product run as a batched mart_gemm_nt (n % 4 == 0) */
+int mart_sum_splits_f32(const float* parts, int S, long long n, float* out, void* stream);
+/* dense [B*L, H] f32 view of a compact [B*nr, H] tensor: promised rows copied (first slot wins), `fill` elsewhere */
+int mart_rows_dense(const float* src, const int32_t* rows, int nr, int B, int L, int H, float* dst, float fill, void* stream);
 
 /* ---------------------------------------------------------------- small utilities
  * [MASK] position per row: (input_ids == mask_id).nonzero() without the host sync of lit_models/transformer.py:94
@@ -328,10 +344,11 @@ int mart_dropout_mask(uint8_t* out, long long n, float p, uint64_t seed, void* s
  * chunks: int32 triples (start, length, flags), start/length in elements; flags bit 0 = weight decay applies, bit 1 = the chunk also
  * refreshes the fp16 shadow (forward weights of the text stream, engine.text_f16). */
 typedef struct {
-  float* master; const float* grad; float* m; float* v; void* shadow_bf16;
+  float* master; float* grad /* read; written (zeros) only with zero_grad */; float* m; float* v; void* shadow_bf16;
   const int32_t* chunks; int n_chunks;
   float lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale;
   void* shadow_f16;                                                 /* optional fp16 shadow, same layout as master (written for chunks with flag bit 1) */
+  int zero_grad;                                                    /* 1: the gradient elements of the updated chunks are written back as 0 (the step's zero-fill folded into the update) */
 } mart_adamw_desc;
 int mart_adamw(const mart_adamw_desc* d, void* stream);
 /* batched bf16 transposes described by int64 quadruples (src_off, dst_off, rows, cols) into the W^T shadow */

@@ -95,7 +95,7 @@ class FusionBwd(C.Structure):
 class AdamW(C.Structure):
     _fields_ = [("master", vp), ("grad", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("chunks", vp), ("n_chunks", i32),
                 ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("bc1", f32), ("bc2", f32),
-                ("grad_scale", f32), ("shadow_f16", vp)]
+                ("grad_scale", f32), ("shadow_f16", vp), ("zero_grad", i32)]
 
 
 _SIGS = {
@@ -132,8 +132,12 @@ _SIGS = {
     "mart_lsce_fwd": (i32, [vp, i32, vp, i64, f32, vp, vp, vp, i32, vp, i32, i32, vp]),
     "mart_lsce_bwd": (i32, [vp, i32, vp, i64, vp, f32, vp, i32, f32, vp, vp, i32, vp, i32, i32, vp]),
     "mart_rank": (i32, [vp, i32, vp, vp, i32, i32, vp]),
-    "mart_simloss_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
-    "mart_simloss_bwd": (i32, [vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, vp]),
+    "mart_simloss_fwd": (i32, [vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp]),
+    "mart_simloss_bwd": (i32, [vp, vp, vp, vp, vp, i32, vp, f32, vp, i32, i32, i32, vp]),
+    "mart_needed_rows": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp]),
+    "mart_rows_lookup": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
+    "mart_rows_dense": (i32, [vp, vp, i32, i32, i32, i32, vp, f32, vp]),
+    "mart_sum_splits_f32": (i32, [vp, i32, i64, vp, vp]),
     "mart_find_token": (i32, [vp, i32, i32, i64, vp, vp, vp, vp]),
     "mart_cast_f32_bf16": (i32, [vp, vp, i64, vp]),
     "mart_cast_bf16_f32": (i32, [vp, vp, i64, vp]),

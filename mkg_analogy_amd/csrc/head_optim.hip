@@ -116,13 +116,25 @@ __device__ __forceinline__ Cos cos_parts(const float* a, const float* b, int H, 
   o.dot = block_sum(d, sh); o.na = sqrtf(block_sum(x, sh)); o.nb = sqrtf(block_sum(y, sh));
   return o;
 }
-__global__ void simloss_fwd_k(const float* __restrict__ tr, const int64_t* rel, const int64_t* qh, const int64_t* ah, float* loss_rows,
-                              int B, int L, int H) {
+// Row lookup of the relaxation loss.  Dense trans [B, L, H]: row b * L + pos.  Row-subset pass (rows != NULL: trans is the COMPACT [B * nr, H] tensor,
+// rows[b * nr + j] the flat id b * L + position of slot j): the first slot of example b that names the position; a position the pass was not
+// promised gives -1 (the loss row is NaN, nothing is read).
+__device__ __forceinline__ long long sim_row(const int32_t* rows, int nr, int b, int L, long long pos) {
+  if (pos < 0) pos += L;                                       // negative positions wrap like the reference's fancy indexing
+  if (!rows) return (long long)b * L + pos;
+  const int f = b * L + (int)pos;
+  for (int j = 0; j < nr; ++j) if (rows[b * nr + j] == f) return (long long)b * nr + j;
+  return -1;
+}
+__global__ void simloss_fwd_k(const float* __restrict__ tr, const int64_t* rel, const int64_t* qh, const int64_t* ah, const int32_t* rows, int nr,
+                              float* loss_rows, int B, int L, int H) {
   __shared__ float sh[8];
   const int b = blockIdx.x;
-  const float* base = tr + (long long)b * L * H;
-  Cos e = cos_parts(base + qh[b] * H, base + ah[b] * H, H, sh);
-  Cos r = cos_parts(base + rel[2 * b] * H, base + rel[2 * b + 1] * H, H, sh);
+  const long long rq = sim_row(rows, nr, b, L, qh[b]), ra = sim_row(rows, nr, b, L, ah[b]);
+  const long long r0 = sim_row(rows, nr, b, L, rel[2 * b]), r1 = sim_row(rows, nr, b, L, rel[2 * b + 1]);
+  if ((rq | ra | r0 | r1) < 0) { if (threadIdx.x == 0) loss_rows[b] = __builtin_nanf(""); return; }
+  Cos e = cos_parts(tr + rq * H, tr + ra * H, H, sh);
+  Cos r = cos_parts(tr + r0 * H, tr + r1 * H, H, sh);
   if (threadIdx.x == 0) {
     const float ce = e.dot / (fmaxf(e.na, 1e-8f) * fmaxf(e.nb, 1e-8f));
     const float cr = r.dot / (fmaxf(r.na, 1e-8f) * fmaxf(r.nb, 1e-8f));
@@ -130,17 +142,16 @@ __global__ void simloss_fwd_k(const float* __restrict__ tr, const int64_t* rel, 
   }
 }
 // d cos(a,b)/da = b/(|a||b|) - cos * a/|a|^2
-__global__ void simloss_bwd_k(const float* __restrict__ tr, const int64_t* rel, const int64_t* qh, const int64_t* ah,
+__global__ void simloss_bwd_k(const float* __restrict__ tr, const int64_t* rel, const int64_t* qh, const int64_t* ah, const int32_t* rows, int nr,
                               const float* __restrict__ gscale, float rowscale, float* dtr, int B, int L, int H) {
   __shared__ float sh[8];
   const int b = blockIdx.x;
   const float g = (gscale ? gscale[0] : 1.f) * rowscale;
-  const float* base = tr + (long long)b * L * H;
-  float* dbase = dtr + (long long)b * L * H;
   for (int pair = 0; pair < 2; ++pair) {
-    const long long ia = pair == 0 ? qh[b] : rel[2 * b], ib = pair == 0 ? ah[b] : rel[2 * b + 1];
-    const float* a = base + ia * H;
-    const float* bb = base + ib * H;
+    const long long ia = sim_row(rows, nr, b, L, pair == 0 ? qh[b] : rel[2 * b]), ib = sim_row(rows, nr, b, L, pair == 0 ? ah[b] : rel[2 * b + 1]);
+    if ((ia | ib) < 0) continue;                                  // (the forward pass made this example's loss NaN)
+    const float* a = tr + ia * H;
+    const float* bb = tr + ib * H;
     Cos c = cos_parts(a, bb, H, sh);
     const float na = fmaxf(c.na, 1e-8f), nb = fmaxf(c.nb, 1e-8f);
     const float cs = c.dot / (na * nb);
@@ -149,8 +160,8 @@ __global__ void simloss_bwd_k(const float* __restrict__ tr, const int64_t* rel, 
     for (int k = threadIdx.x; k < H; k += TPB) {
       const float da = coef * (bb[k] / (na * nb) - cs * a[k] / (na * na));
       const float db = coef * (a[k] / (na * nb) - cs * bb[k] / (nb * nb));
-      atomicAdd(dbase + ia * H + k, da);
-      atomicAdd(dbase + ib * H + k, db);
+      atomicAdd(dtr + ia * H + k, da);
+      atomicAdd(dtr + ib * H + k, db);
     }
   }
 }
@@ -186,6 +197,7 @@ __global__ __launch_bounds__(TPB) void adamw_k(mart_adamw_desc p) {
           w[e] -= step_size * m[e] / (sqrtf(v[e]) * inv_sqrt_bc2 + p.eps);
         }
         *(f32x4*)(p.master + o) = w; *(f32x4*)(p.m + o) = m; *(f32x4*)(p.v + o) = v;
+        if (p.zero_grad) *(f32x4*)(p.grad + o) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (sh) *(bf16x4*)(sh + o) = f4_to_bf4(w);
         if (sh16) *(bf16x4*)(sh16 + o) = f4_to_h4raw(w);
       } else {
@@ -196,6 +208,7 @@ __global__ __launch_bounds__(TPB) void adamw_k(mart_adamw_desc p) {
           const float v = p.beta2 * p.v[o + e] + (1.f - p.beta2) * ge * ge;
           w -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + p.eps);
           p.master[o + e] = w; p.m[o + e] = m; p.v[o + e] = v;
+          if (p.zero_grad) p.grad[o + e] = 0.f;
           if (sh) sh[o + e] = f2bf(w);
           if (sh16) sh16[o + e] = (h16)w;
         }
@@ -233,17 +246,17 @@ extern "C" int mart_rank(const float* logits, int ld, const int64_t* label, int6
   MART_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int mart_simloss_fwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, float* loss_rows, int B, int L,
-                                int H, void* stream) {
-  MART_CHECK(trans && rel_idx && q_idx && a_idx && loss_rows && B > 0 && L > 0 && H > 0, "simloss_fwd: bad args");
-  hipLaunchKernelGGL(simloss_fwd_k, dim3(B), dim3(TPB), 0, (hipStream_t)stream, trans, rel_idx, q_idx, a_idx, loss_rows, B, L, H);
+extern "C" int mart_simloss_fwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, const int32_t* rows, int nr,
+                                float* loss_rows, int B, int L, int H, void* stream) {
+  MART_CHECK(trans && rel_idx && q_idx && a_idx && loss_rows && B > 0 && L > 0 && H > 0 && (!rows || (nr > 0 && nr <= 64)), "simloss_fwd: bad args");
+  hipLaunchKernelGGL(simloss_fwd_k, dim3(B), dim3(TPB), 0, (hipStream_t)stream, trans, rel_idx, q_idx, a_idx, rows, nr, loss_rows, B, L, H);
   MART_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, const float* gscale,
-                                float rowscale, float* dtrans, int B, int L, int H, void* stream) {
-  MART_CHECK(trans && rel_idx && q_idx && a_idx && dtrans && B > 0 && L > 0 && H > 0, "simloss_bwd: bad args");
-  hipLaunchKernelGGL(simloss_bwd_k, dim3(B), dim3(TPB), 0, (hipStream_t)stream, trans, rel_idx, q_idx, a_idx, gscale, rowscale, dtrans, B, L, H);
+extern "C" int mart_simloss_bwd(const float* trans, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx, const int32_t* rows, int nr,
+                                const float* gscale, float rowscale, float* dtrans, int B, int L, int H, void* stream) {
+  MART_CHECK(trans && rel_idx && q_idx && a_idx && dtrans && B > 0 && L > 0 && H > 0 && (!rows || (nr > 0 && nr <= 64)), "simloss_bwd: bad args");
+  hipLaunchKernelGGL(simloss_bwd_k, dim3(B), dim3(TPB), 0, (hipStream_t)stream, trans, rel_idx, q_idx, a_idx, rows, nr, gscale, rowscale, dtrans, B, L, H);
   MART_LAUNCH_CHECK();
   return 0;
 }

@@ -90,6 +90,14 @@ __global__ void cast_pad_k(const float* __restrict__ s, int lds_, bf16* __restri
   const int r = blockIdx.x;
   for (int c = threadIdx.x; c < ldd; c += blockDim.x) d[(long long)r * ldd + c] = c < C ? f2bf(s[(long long)r * lds_ + c]) : (bf16)0.f;
 }
+// out[i] = sum over the S split-K partial results parts[s * n + i], in split order (deterministic); n % 4 == 0
+__global__ void sum_splits_k(const float* __restrict__ parts, int S, long long n, float* __restrict__ out) {
+  long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 a = *(const f32x4*)(parts + i);
+  for (int s = 1; s < S; ++s) a += *(const f32x4*)(parts + (long long)s * n + i);
+  *(f32x4*)(out + i) = a;
+}
 __global__ void add_f32_bf16_k(const float* __restrict__ a, const bf16* __restrict__ b, float* __restrict__ of,
                                bf16* __restrict__ ob, long long n) {
   long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4, stride = (long long)gridDim.x * TPB * 4;
@@ -125,6 +133,52 @@ __global__ void find_token_k(const int64_t* ids, int B, int L, int64_t tok, int3
   pos[b] = found;
   if (found < 0 && status) atomicOr(status, 2);       // an example without the token (the reference raises there): pos -1, row b*L+0, status bit 1
   if (row) row[b] = b * L + (found < 0 ? 0 : found);
+}
+// ---- row-subset passes (forward(needed_rows=...)): rows[b * nr + j] = flat id b * L + position of the j-th row example b was promised
+// The rows of the step, built on the device in one launch: column 0 = first position of `tok` ([MASK]; absent: position 0 + status bit 1), then
+// rel_idx[:, 0], rel_idx[:, 1], q_idx, a_idx when given (lit_models/transformer.py:94-95,103-107).  Negative positions wrap (+ L), then clamp to [0, L).
+__global__ void needed_rows_k(const int64_t* __restrict__ ids, int B, int L, int64_t tok, const int64_t* __restrict__ rel, const int64_t* __restrict__ qi,
+                              const int64_t* __restrict__ ai, int nr, int32_t* __restrict__ rows, int32_t* __restrict__ mask_row, int32_t* status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int found = -1;
+  for (int j = 0; j < L; ++j) if (ids[(long long)b * L + j] == tok) { found = j; break; }
+  if (found < 0 && status) atomicOr(status, 2);
+  const int m = found < 0 ? 0 : found;
+  rows[b * nr] = b * L + m;
+  if (mask_row) mask_row[b] = b * L + m;
+  if (nr >= 5) {
+    const long long p[4] = {rel[2 * b], rel[2 * b + 1], qi[b], ai[b]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long long v = p[j] < 0 ? p[j] + L : p[j];
+      v = v < 0 ? 0 : (v >= L ? L - 1 : v);
+      rows[b * nr + 1 + j] = b * L + (int)v;
+    }
+  }
+}
+// compact index of the flat row id f (example b = f / L): the FIRST slot of the example that names it (as scatter_rows_k / gather_rows_first_k);
+// a row the pass was not promised: slot 0 of the example + status bit 2 (value 4) -- never an out-of-range index
+__device__ __forceinline__ int rows_find(const int32_t* __restrict__ rows, int nr, int L, int f, int32_t* status) {
+  const int b = f / L;
+  for (int j = 0; j < nr; ++j) if (rows[b * nr + j] == f) return b * nr + j;
+  if (status) atomicOr(status, 4);
+  return b * nr;
+}
+__global__ void rows_lookup_k(const int32_t* __restrict__ flat, int n, const int32_t* __restrict__ rows, int nr, int L, int32_t* __restrict__ out, int32_t* status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = rows_find(rows, nr, L, flat[i], status);
+}
+// the dense [B * L, H] f32 tensor of a row-subset pass: the promised rows from their compact copies (first slot wins), `fill` (NaN) elsewhere -- one pass
+__global__ void rows_dense_k(const float* __restrict__ src, const int32_t* __restrict__ rows, int nr, int L, float* __restrict__ dst, float fill, int Mt, int H) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= Mt) return;
+  const int b = r / L;
+  int hit = -1;
+  for (int j = nr - 1; j >= 0; --j) if (rows[b * nr + j] == r) hit = b * nr + j;
+  const f32x4 fv = {fill, fill, fill, fill};
+  for (int c = lane * 4; c < H; c += 256)
+    *(f32x4*)(dst + (long long)r * H + c) = hit >= 0 ? *(const f32x4*)(src + (long long)hit * H + c) : fv;
 }
 __global__ void gather_rows_k(const float* __restrict__ src, int ld, const int32_t* __restrict__ rows, float* __restrict__ dst, int R, int H) {
   int r = blockIdx.x;
@@ -228,6 +282,29 @@ extern "C" int mart_find_token(const int64_t* ids, int B, int L, int64_t token, 
   MART_LAUNCH_CHECK();
   return 0;
 }
+extern "C" int mart_needed_rows(const int64_t* ids, int B, int L, int64_t token, const int64_t* rel_idx, const int64_t* q_idx, const int64_t* a_idx,
+                                int32_t* rows_out, int32_t* mask_row_out, int32_t* status, void* stream) {
+  MART_CHECK(ids && rows_out && B > 0 && L > 0, "needed_rows: bad args");
+  MART_CHECK((rel_idx && q_idx && a_idx) || (!rel_idx && !q_idx && !a_idx), "needed_rows: rel_idx / q_idx / a_idx come together");
+  MART_CHECK((long long)B * L < (1ll << 31), "needed_rows: B * L must fit 31 bits");
+  hipLaunchKernelGGL(needed_rows_k, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, ids, B, L, token, rel_idx, q_idx, a_idx, rel_idx ? 5 : 1, rows_out,
+                     mask_row_out, status);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_rows_lookup(const int32_t* flat, int n, const int32_t* rows, int nr, int L, int32_t* out, int32_t* status, void* stream) {
+  MART_CHECK(flat && rows && out && n > 0 && nr > 0 && nr <= 64 && L > 0, "rows_lookup: bad args");
+  hipLaunchKernelGGL(rows_lookup_k, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, flat, n, rows, nr, L, out, status);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int mart_rows_dense(const float* src, const int32_t* rows, int nr, int B, int L, int H, float* dst, float fill, void* stream) {
+  MART_CHECK(src && rows && dst && nr > 0 && nr <= 64 && B > 0 && L > 0 && H > 0 && H % 4 == 0, "rows_dense: bad args");
+  const int Mt = B * L;
+  hipLaunchKernelGGL(rows_dense_k, dim3((Mt + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, rows, nr, L, dst, fill, Mt, H);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int mart_gather_rows_f32(const float* src, int ld, const int32_t* rows, float* dst, int R, int H, void* stream) {
   MART_CHECK(src && rows && dst && R > 0 && H > 0, "gather_rows_f32: bad args");
   hipLaunchKernelGGL(gather_rows_k, dim3(R), dim3(256), 0, (hipStream_t)stream, src, ld, rows, dst, R, H);
@@ -255,6 +332,12 @@ extern "C" int mart_act_bwd(const void* dy_bf16, const void* z_bf16, int act, vo
   return 0;
 }
 
+extern "C" int mart_sum_splits_f32(const float* parts, int S, long long n, float* out, void* stream) {
+  MART_CHECK(parts && out && S > 0 && n > 0 && n % 4 == 0, "sum_splits_f32: bad args");
+  hipLaunchKernelGGL(sum_splits_k, dim3((unsigned)((n / 4 + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, parts, S, n, out);
+  MART_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int mart_cast_pad_f32_bf16(const float* src, int lds_, void* dst, int ldd, int R, int C, void* stream) {
   MART_CHECK(src && dst && R > 0 && C > 0 && ldd >= C && lds_ >= C, "cast_pad_f32_bf16: bad args");
   hipLaunchKernelGGL(cast_pad_k, dim3(R), dim3(256), 0, (hipStream_t)stream, src, lds_, (bf16*)dst, ldd, R, C);

@@ -250,6 +250,15 @@ class UnimoEngine:
             torch.cuda.current_stream().wait_stream(self._side_t)
             self._side_t_busy = False
 
+    def _mark(self, name: str) -> None:
+        """Timeline marks (tools/tail_marks.py): a HIP event on the current stream when ``self.marks`` is a list; free otherwise."""
+        m = getattr(self, "marks", None)
+        if m is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream())
+            import time
+            m.append((name, ev, time.perf_counter()))
+
     def _pass_begin(self):
         while self.max_inflight > 0 and len(self._inflight) >= self.max_inflight:
             self._inflight.popleft().synchronize()
@@ -267,8 +276,11 @@ class UnimoEngine:
         ``trans_hidden_states`` (lit_models/transformer.py:94-95,103-107: the [MASK] row and four more per example).  Nothing else reads
         the last text layer's other rows (modeling_unimo.py:616 exports the K/V of layers idx - 1 <= 10 only), so everything behind its
         attention / fusion -- output projection, FFN, both LayerNorms, the head transform, and their backward -- runs on B * nr rows
-        instead of B * L.  Exact: the computed rows are what the dense pass computes; the returned tensor is NaN elsewhere."""
+        instead of B * L.  Exact: the computed rows are what the dense pass computes.  With ``rows`` the returned tensors are COMPACT:
+        ``trans`` f32 [B * nr, H] and ``trans_bf16`` [B * nr, H], slot order = ``rows`` (the dense [B, L, H] view with NaN elsewhere is built by the
+        caller, functional._DenseRowsFn); ``backward`` then takes the gradient in the same compact layout."""
         self._pass_begin()
+        self._mark("fwd_begin")
         st, H, nh, I = self.st, self.H, self.nh, self.I
         dev = input_ids.device
         B, Lq = input_ids.shape
@@ -503,6 +515,7 @@ class UnimoEngine:
                     xt = self.inject[f"txt{l}"].reshape(Mt, H).to(device=dev, dtype=F32).contiguous()
                     xtb, xth = xt.to(BF), (xt.to(HF) if f16 else None)
 
+        self._mark("fwd_vision_end")
         # ---- MLM head transform (BertPredictionHeadTransform.forward, modeling_unimo.py:972-975)
         with self._text_ctx():
             hp = "cls.predictions.transform."
@@ -516,22 +529,16 @@ class UnimoEngine:
             trans, transb = _e((Mh, H), F32, dev), _e((Mh, H), BF, dev)
             hm, hr = _e((Mh,), F32, dev), _e((Mh,), F32, dev)
             ops.ln_fwd(x_f32=y, gamma=st.m(hp + "LayerNorm.weight"), beta=st.m(hp + "LayerNorm.bias"), eps=self.eps_t, M=Mh, H=H, mean=hm, rstd=hr,
-                       out_f32=trans, out_bf16=transb if Mh == Mt else None)
+                       out_f32=trans, out_bf16=transb)
             sv["head"] = (xtb, y, zh, hm, hr)
-            if Mh != Mt:                                    # the reference's [B, L, H] tensor with the requested rows filled in
-                tc = trans
-                # NaN, not zero, outside the requested rows: a consumer that breaks the promise (scores another position, reduces over all
-                # of trans_hidden_states) gets NaN logits / a NaN loss instead of silently bias-only numbers (the reference computes every row)
-                trans, transb = torch.full((Mt, H), float("nan"), device=dev, dtype=F32), torch.full((Mt, H), float("nan"), device=dev, dtype=BF)
-                ops.scatter_rows(tc, R, nr, trans)
-                ops.scatter_rows(tc, R, nr, transb)
         self._text_done()
+        self._mark("fwd_end")
         if self._tstream is not None:                  # allocated on the text stream, consumed by the caller on the main stream
             trans.record_stream(torch.cuda.current_stream())
             transb.record_stream(torch.cuda.current_stream())
         if not keep:
             self._pass_end()                           # forward-only pass (no_grad); otherwise the backward pass closes it
-        return trans.view(B, Lq, H), transb, sv
+        return (trans.view(B, Lq, H) if Mh == Mt else trans), transb, sv
 
     # ------------------------------------------------------------------ backward
     def backward(self, sv, dtrans: torch.Tensor) -> None:
@@ -541,6 +548,7 @@ class UnimoEngine:
         # the side / text streams fork from this (main) stream: it has to have waited for an off-stream gradient zero-fill / W^T refresh
         # (FlatStore.pending, MART_ASYNC_STEP=1 with zero_grad() between forward and backward) before any of them writes a gradient
         st.join_pending()
+        self._mark("bwd_begin")
         B, Lq, P, Nv, Nvp = sv["B"], sv["L"], sv["P"], sv["Nv"], sv["Nvp"]
         train, seed = sv["train"], sv["seed"]
         Mv, Mt = B * Nv, B * Lq
@@ -568,10 +576,8 @@ class UnimoEngine:
             xtb, y, zh, hm, hr = sv["head"]
             hp = "cls.predictions.transform."
             Mh = y.shape[0]                                               # B * L, or the B * nr rows the forward pass was asked for
-            dtr = dtrans.view(Mt, H)
-            if Mh != Mt:                                                  # gradient of the requested rows (a row requested twice: taken once)
-                dtr = _e((Mh, H), F32, dev)
-                ops.gather_rows_first_f32(dtrans.view(Mt, H), R, nr, dtr)
+            dtr = dtrans.view(-1, H)                                      # [B * L, H], or compact [B * nr, H] for a row-subset pass
+            assert dtr.shape[0] == Mh, "backward: the gradient must have the layout forward() returned (compact for a row-subset pass)"
             dyb = _e((Mh, H), BF, dev)
             self._ln_bwd(dy_f32=dtr, s=y, mean=hm, rstd=hr, gamma=st.m(hp + "LayerNorm.weight"), M=Mh, H=H, ds_bf16=dyb,
                        dgamma=st.g(hp + "LayerNorm.weight"), dbeta=st.g(hp + "LayerNorm.bias"))
@@ -721,11 +727,31 @@ class UnimoEngine:
                 else:
                     T["d_f32"], T["d_b16"] = ds1, dtb
 
+        def text_embed_bwd():
+            """Text embeddings backward: dropout -> LN -> scatter into the embedding tables (text stream)."""
+            with self._text_ctx():
+                s_t, tmean, trstd = sv["temb"]
+                u = "unimo.text_embeddings."
+                dyd = _e((Mt, H), F32, dev)
+                ops.dropout_bwd_f32(T["d_f32"], T["d_b16"], dyd, Mt * H, p_h, seed + 1)
+                dse = _e((Mt, H), F32, dev)
+                self._ln_bwd(dy_f32=dyd, s=s_t, mean=tmean, rstd=trstd, gamma=st.m(u + "LayerNorm.weight"), M=Mt, H=H, ds_f32=dse,
+                             dgamma=st.g(u + "LayerNorm.weight"), dbeta=st.g(u + "LayerNorm.bias"))
+                ops.text_embed_scatter(dse, sv["ids"], sv["tt"], st.g(u + "word_embeddings.weight"), st.g(u + "position_embeddings.weight"),
+                                       st.g(u + "token_type_embeddings.weight"), B, Lq, H)
+
         T["ev_vdone"], T["ev_vattn"] = ev_vdone, ev_vattn
         text_A(self.n_layers - 1)
         for l in reversed(range(self.n_layers)):
             # ================= text layer l (its first part was issued ahead: right above for the top layer, inside vision layer l + 1 below)
             text_B(l)
+            if l == 0:
+                # the text stream ends here: embedding backward, then its tables (params.layout_order puts them in front of vision layer 0) are released
+                # to the all-reduce / AdamW consumers while the vision stream still has layer 0 and its embeddings to go
+                text_embed_bwd()
+                if self.grad_ready is not None:
+                    self._join(); self._text_done(); self._text_begin()
+                notify(st.slots["unimo.encoder.vision_layers.0.self_attn.q_proj.weight"].offset)
             side_next = None                                           # d(visual) of the fusion of text layer l - 1, when it travels through a side buffer
             # ================= vision layer l
             if l in T["ev_tfus"] and T["A_side"].get(l) is None:
@@ -734,6 +760,7 @@ class UnimoEngine:
             T["fresh"] = False
             v = f"unimo.encoder.vision_layers.{l}."
             s = sv[f"v{l}"]
+            self._mark(f"bwd_v{l}")
             if self.taps is not None:
                 self.taps[f"dvis{l}"] = dxv.view(B, Nv, H).clone()
             if self.inject_grad is not None and f"vis{l}" in self.inject_grad:
@@ -806,17 +833,6 @@ class UnimoEngine:
                     self._join(); self._text_done(); self._text_begin()
                 notify(st.slots[f"unimo.encoder.text_layer.{l - 1}.attention.self.query.weight"].offset)
 
-        # ---- text embeddings backward: dropout -> LN -> scatter
-        with self._text_ctx():
-            s_t, tmean, trstd = sv["temb"]
-            u = "unimo.text_embeddings."
-            dyd = _e((Mt, H), F32, dev)
-            ops.dropout_bwd_f32(T["d_f32"], T["d_b16"], dyd, Mt * H, p_h, seed + 1)
-            dse = _e((Mt, H), F32, dev)
-            self._ln_bwd(dy_f32=dyd, s=s_t, mean=tmean, rstd=trstd, gamma=st.m(u + "LayerNorm.weight"), M=Mt, H=H, ds_f32=dse,
-                       dgamma=st.g(u + "LayerNorm.weight"), dbeta=st.g(u + "LayerNorm.bias"))
-            ops.text_embed_scatter(dse, sv["ids"], sv["tt"], st.g(u + "word_embeddings.weight"), st.g(u + "position_embeddings.weight"),
-                                   st.g(u + "token_type_embeddings.weight"), B, Lq, H)
         # ---- vision embeddings backward: pre-LN -> assemble -> patch GEMM weight gradient
         patches, s_v, vmean, vrstd = sv["vemb"]
         dsv = _e((Mv, H), F32, dev)
@@ -827,7 +843,9 @@ class UnimoEngine:
                                 B, P, H)
         gw = st.g("unimo.vision_embeddings.patch_embedding.weight")
         self._tn(dpe, patches, gw.view(H, -1))
+        self._mark("bwd_embed_end")
         self._text_done()                                             # main stream waits for the text stream
         self._join()
+        self._mark("bwd_end")
         notify(st.total)
         self._pass_end()

@@ -28,7 +28,7 @@ class _MKGformerFn(torch.autograd.Function):
                                            image_table=image_table, image_index=image_index, **kw)
         ctx.engine, ctx.sv = engine, sv
         holder["trans_bf16"] = transb
-        return trans
+        return trans                                 # [B, L, H]; with ``rows``: the compact [B * nr, H] tensor (RowSubset / _DenseRowsFn below)
 
     @staticmethod
     def backward(ctx, dtrans):
@@ -37,6 +37,44 @@ class _MKGformerFn(torch.autograd.Function):
             raise RuntimeError("MKGformer backward called twice (activations are freed after the first pass)")
         ctx.engine.backward(sv, dtrans)
         return (None,) * 13
+
+
+class RowSubset:
+    """The compact tensors of a row-subset pass (engine.forward(rows=...)): ``f32`` [B * nr, H] (the autograd output of the engine node), ``bf16`` its
+    bf16 copy, ``rows`` int32 [B, nr] flat ids b * L + position, ``mask_index`` (optional) int32 [B] compact indices of the [MASK] rows (slot 0).
+    Carried on the dense [B, L, H] tensor the model returns (attribute ``_mart_rows``) so that the scoring head and the relaxation loss read -- and
+    send their gradients to -- the compact rows: no [B, L, H] zero-fill, scatter, add or gather between the loss and the engine's backward pass."""
+
+    def __init__(self, f32, bf16, rows, L, mask_index=None, mask_row=None, mask_token=None):
+        self.f32, self.bf16, self.rows, self.L, self.mask_index = f32, bf16, rows, int(L), mask_index
+        self.mask_row, self.mask_token = mask_row, mask_token
+
+    def lookup(self, flat_rows: torch.Tensor) -> torch.Tensor:
+        """compact indices of flat row ids (first slot that names the row; a row outside the promise: flagged for check_status)."""
+        out = torch.empty(flat_rows.numel(), device=flat_rows.device, dtype=torch.int32)
+        ops.rows_lookup(flat_rows.contiguous(), self.rows, self.L, out, status=_status(flat_rows.device))
+        return out
+
+
+class _DenseRowsFn(torch.autograd.Function):
+    """[B, L, H] view of a compact row-subset tensor: the promised rows, NaN elsewhere (a consumer that breaks the promise -- reduces over all of
+    trans_hidden_states, reads another position -- gets NaN instead of silently wrong numbers; the reference computes every row).  Backward: the
+    gradient rows of the promised positions (a position named twice: taken once, by its first slot)."""
+
+    @staticmethod
+    def forward(ctx, compact, rows, B, L):
+        H = compact.shape[-1]
+        dense = torch.empty((B, L, H), device=compact.device, dtype=F32)
+        ops.rows_dense(compact, rows, B, L, dense.view(-1, H))
+        ctx.rows, ctx.shape = rows, compact.shape
+        return dense
+
+    @staticmethod
+    def backward(ctx, d):
+        rows = ctx.rows
+        out = torch.empty(ctx.shape, device=d.device, dtype=F32)
+        ops.gather_rows_first_f32(d.contiguous().view(-1, d.shape[-1]), rows.view(-1), int(rows.shape[1]), out)
+        return out, None, None, None
 
 
 _UNIQUE_OK: dict = {}      # id(tensor) -> (weak reference to that tensor object, the _version it was checked at)
@@ -90,7 +128,12 @@ class _ScoreFn(torch.autograd.Function):
         dev = dlogits.device
         R, A = dlogits.shape
         H = transb.shape[1]
-        Ap = ((A + 63) // 64) * 64
+        # d(rows) = dlogits @ W[ids]: M = R (a few hundred rows) x N = H with the contraction over the A scored ids -- 12 output tiles walking a
+        # K = 11 k loop (0.12 ms, the longest kernel between the loss and the first backward GEMM) as one launch; run split-K as a batched product
+        # (S slices of the contraction -> S x 12 tiles) + an ordered sum instead
+        S = max(1, min(16, A // 768)) if R <= 1024 else 1
+        Kc = ((A + 64 * S - 1) // (64 * S)) * 64
+        Ap = Kc * S
         dl = torch.empty((R, Ap), device=dev, dtype=BF)
         ops.cast_pad_f32_bf16(dlogits.contiguous(), dl, R, A)
         W = store.w(word_name)
@@ -99,7 +142,12 @@ class _ScoreFn(torch.autograd.Function):
         WgT = torch.empty((H, Ap), device=dev, dtype=BF)
         ops.transpose_bf16(Wg, WgT, A, H, Ap)
         drows = torch.empty((R, H), device=dev, dtype=F32)
-        ops.gemm_nt(dl, WgT, drows)
+        if S > 1:
+            parts = torch.empty((S, R, H), device=dev, dtype=F32)
+            ops.gemm_nt(dl[:, :Kc], WgT[:, :Kc], parts, M=R, N=H, batch=S, stride_a=Kc, stride_b=Kc, stride_c=R * H)
+            ops.sum_splits_f32(parts, drows)
+        else:
+            ops.gemm_nt(dl, WgT, drows)
         dtrans = torch.zeros(ctx.shape, device=dev, dtype=F32)
         ops.scatter_add_rows_f32(drows, rows, dtrans.view(-1, H))
         trows = torch.empty((R, H), device=dev, dtype=BF)
@@ -167,22 +215,24 @@ class _LSCEFn(torch.autograd.Function):
 
 
 class _SimLossFn(torch.autograd.Function):
-    """Relaxation loss, lit_models/transformer.py:103-108."""
+    """Relaxation loss, lit_models/transformer.py:103-108.  ``rows`` / ``L`` given: ``trans`` is the compact tensor of a row-subset pass."""
 
     @staticmethod
-    def forward(ctx, trans, rel_idx, q_idx, a_idx):
+    def forward(ctx, trans, rel_idx, q_idx, a_idx, rows=None, L=None):
         trans = trans.contiguous()
-        rows = torch.empty(trans.shape[0], device=trans.device, dtype=F32)
-        ops.simloss_fwd(trans, rel_idx, q_idx, a_idx, rows)
+        B = trans.shape[0] if rows is None else rows.shape[0]
+        lrows = torch.empty(B, device=trans.device, dtype=F32)
+        ops.simloss_fwd(trans, rel_idx, q_idx, a_idx, lrows, rows=rows, L_=L)
         ctx.save_for_backward(trans, rel_idx, q_idx, a_idx)
-        return rows.mean()
+        ctx.rows, ctx.L, ctx.B = rows, L, B
+        return lrows.mean()
 
     @staticmethod
     def backward(ctx, g):
         trans, rel_idx, q_idx, a_idx = ctx.saved_tensors
         d = torch.zeros_like(trans)
-        ops.simloss_bwd(trans, rel_idx, q_idx, a_idx, g.contiguous().view(1).float(), 1.0 / trans.shape[0], d)
-        return d, None, None, None
+        ops.simloss_bwd(trans, rel_idx, q_idx, a_idx, g.contiguous().view(1).float(), 1.0 / ctx.B, d, rows=ctx.rows, L_=ctx.L)
+        return d, None, None, None, None, None
 
 
 def label_smooth_ce(logits: torch.Tensor, label: torch.Tensor, eps: float = 0.1, ignore_index: int = -100, reduction: str = "mean") -> torch.Tensor:
@@ -192,8 +242,30 @@ def label_smooth_ce(logits: torch.Tensor, label: torch.Tensor, eps: float = 0.1,
 
 
 def relaxation_loss(trans: torch.Tensor, rel_idx: torch.Tensor, q_head_idx: torch.Tensor, a_head_idx: torch.Tensor) -> torch.Tensor:
-    return _SimLossFn.apply(trans, rel_idx.to(torch.int64).contiguous(), q_head_idx.to(torch.int64).contiguous(),
-                            a_head_idx.to(torch.int64).contiguous())
+    idx = (rel_idx.to(torch.int64).contiguous(), q_head_idx.to(torch.int64).contiguous(), a_head_idx.to(torch.int64).contiguous())
+    rs = getattr(trans, "_mart_rows", None)
+    if rs is not None:                               # the dense tensor of a row-subset pass: read (and differentiate) its compact rows
+        return _SimLossFn.apply(rs.f32, *idx, rs.rows, rs.L)
+    return _SimLossFn.apply(trans, *idx)
+
+
+def needed_rows(input_ids: torch.Tensor, mask_token_id: int, extra=None) -> torch.Tensor:
+    """The rows of ``trans_hidden_states`` a trainer-surface step reads, as ``forward(needed_rows=...)`` takes them: int32 [B, 1] (the [MASK] row) or
+    [B, 5] ([MASK], rel_idx[:, 0], rel_idx[:, 1], q_head_idx, a_head_idx) FLAT ids b * L + position, built by one device launch (no host sync;
+    an example without [MASK]: row 0 of that example, flagged for check_status).  The result carries ``_mart_flat`` (the model takes it as is)
+    and ``_mart_mask_row`` (int32 [B]: column 0, contiguous)."""
+    B, L = input_ids.shape
+    dev = input_ids.device
+    nr = 1 if extra is None else 5
+    rows = torch.empty((B, nr), device=dev, dtype=torch.int32)
+    mrow = torch.empty(B, device=dev, dtype=torch.int32)
+    if extra is None:
+        rel = q = a = None
+    else:
+        rel, q, a = (t.to(dev, torch.int64).contiguous() for t in extra)
+    ops.needed_rows(input_ids.contiguous(), int(mask_token_id), rel, q, a, rows, mrow, status=_status(dev))
+    rows._mart_flat, rows._mart_mask_row, rows._mart_mask_token = True, mrow, int(mask_token_id)
+    return rows
 
 
 def token_positions(input_ids: torch.Tensor, token_id: int) -> torch.Tensor:
@@ -240,6 +312,11 @@ class LazyRows:
         if not (isinstance(rsel, slice) and rsel == slice(None)):
             rows = rows[rsel].contiguous()
         o = self.owner
+        if o.compact is not None and o.precise is None:      # row-subset pass: score the compact rows (gradients go to the compact tensor)
+            cidx = getattr(rows, "_mart_compact_index", None)
+            if cidx is None:
+                cidx = o.compact.lookup(rows)
+            return _ScoreFn.apply(o.compact.f32, o.compact.bf16, cidx, self._ids(csel), o.store, o.word_name, o.bias_name, o.head_split)
         if o.precise is not None:
             if o.trans.requires_grad and hasattr(o.precise, "score_train"):
                 return o.precise.score_train(o.trans, rows, self._ids(csel), o.word_name, o.bias_name)
@@ -252,8 +329,9 @@ class LazyLogits:
     Indexing patterns used by the trainer surface are scored on demand; ``materialize()`` builds the full tensor."""
 
     def __init__(self, trans: torch.Tensor, trans_bf16: torch.Tensor, store, word_name: str = WORD, bias_name: str = BIAS, precise=None,
-                 head_split: bool = True, valid_rows=None):
+                 head_split: bool = True, valid_rows=None, compact: Optional[RowSubset] = None):
         self.trans, self.trans_bf16, self.store = trans, trans_bf16, store
+        self.compact = compact                      # RowSubset of a forward(needed_rows=...) pass: the scoring head reads the compact rows
         # forward(needed_rows=...): flat ids (b * L + position, int32 [B, n]) of the only rows of ``trans`` that were computed -- the rest is NaN
         self.valid_rows = valid_rows
         self.head_split = head_split                # the ENGINE's switch (one source of truth for the transform and the scoring GEMM)
@@ -280,6 +358,12 @@ class LazyLogits:
     def mask_rows(self, input_ids: torch.Tensor, mask_token_id: int) -> LazyRows:
         """Device-side ``(input_ids == mask).nonzero()`` + row gather (no host sync; lit_models/transformer.py:94)."""
         B, L = input_ids.shape
+        c = self.compact
+        if c is not None and c.mask_index is not None and c.mask_token == int(mask_token_id):
+            # the rows were built by Fn.needed_rows for this very token: slot 0 of every example is its [MASK] row -- no second search, no lookup
+            row = c.mask_row
+            row._mart_compact_index = c.mask_index
+            return LazyRows(self, row)
         pos = torch.empty(B, device=input_ids.device, dtype=torch.int32)
         row = torch.empty(B, device=input_ids.device, dtype=torch.int32)
         ops.find_token(input_ids.contiguous(), mask_token_id, pos, row, status=_status(input_ids.device))     # absent: row b*L+0 + status bit (check_status)

@@ -71,12 +71,9 @@ class TransformerLitModel(BaseLitModel):
         if not self.last_layer_rows or not getattr(self.model, "accepts_needed_rows", False) or getattr(self.model, "precision", "bf16") != "bf16":
             return {}
         dev = self.model.store.device
-        # an example without [MASK] (position -1; flagged for Fn.check_status): row 0 of that example, the same row mask_rows() / find_token_k fall back to
-        cols = [Fn.token_positions(input_ids.to(dev, torch.int64), int(self.tokenizer.mask_token_id)).to(torch.int64).clamp_(min=0)]
-        if extra is not None:
-            rel_idx, q_head_idx, a_head_idx = (t.to(dev, torch.int64) for t in extra)
-            cols += [rel_idx[:, 0], rel_idx[:, 1], q_head_idx, a_head_idx]
-        return dict(needed_rows=torch.stack(cols, 1))
+        # one device launch: [MASK] position (an example without [MASK]: its row 0, flagged for Fn.check_status -- the row mask_rows() falls back to as well)
+        # + the four relaxation-loss positions, as flat int32 row ids
+        return dict(needed_rows=Fn.needed_rows(input_ids.to(dev, torch.int64), int(self.tokenizer.mask_token_id), extra))
 
     def _mask_rows(self, logits, input_ids):
         return logits.mask_rows(input_ids, int(self.tokenizer.mask_token_id))

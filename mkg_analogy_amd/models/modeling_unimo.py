@@ -193,6 +193,7 @@ class UnimoForMaskedLM(nn.Module):
         self.precision = "bf16"                     # "fp32": fp32-accurate evaluation path (engine_precise), forward only
         self._precise = None
         self._precise_train = None
+        self._mask_index: dict = {}                  # (device, B, nr) -> compact indices of slot 0 (row-subset passes)
         self.tie_weights()
 
     # ------------------------------------------------------------------ embedding surgery (modeling_unimo.py:895-930)
@@ -349,15 +350,33 @@ class UnimoForMaskedLM(nn.Module):
         seed = (self.base_seed * 1000003 + self._step * 7919) & 0x7FFFFFFFFFFF
         holder: Dict[str, torch.Tensor] = {}
         self._engine.save_for_backward = torch.is_grad_enabled()
-        rows = None
+        rows = mask_row = None
         if needed_rows is not None and labels is None:
-            nr_ = needed_rows.to(dev).reshape(B, -1).to(torch.int64)
-            nr_ = torch.where(nr_ < 0, nr_ + L, nr_).clamp(0, L - 1)     # negative positions wrap as in the reference's fancy indexing; out of place
-            rows = (torch.arange(B, device=dev, dtype=torch.int64)[:, None] * L + nr_).to(torch.int32).contiguous()
+            if getattr(needed_rows, "_mart_flat", False):               # built by Fn.needed_rows: flat int32 ids already (one device launch)
+                rows, mask_row = needed_rows, getattr(needed_rows, "_mart_mask_row", None)
+                assert rows.dtype == torch.int32 and rows.dim() == 2 and rows.shape[0] == B and rows.device == dev
+            else:
+                nr_ = needed_rows.to(dev).reshape(B, -1).to(torch.int64)
+                nr_ = torch.where(nr_ < 0, nr_ + L, nr_).clamp(0, L - 1)     # negative positions wrap as in the reference's fancy indexing; out of place
+                rows = (torch.arange(B, device=dev, dtype=torch.int64)[:, None] * L + nr_).to(torch.int32).contiguous()
         trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
                                       image_table, image_index, rows)
         st.join_pending()                           # gradient zero-fill / W^T refresh issued next to this forward pass (optim.FusedAdamW)
-        logits = Fn.LazyLogits(trans, holder["trans_bf16"], st, head_split=self._engine.head_split, valid_rows=rows)
+        compact = None
+        if rows is not None and trans.dim() == 2:   # row-subset pass: the engine returned the compact [B * nr, H] rows
+            nr = int(rows.shape[1])
+            mi = None
+            if mask_row is not None:
+                key = (dev, B, nr)
+                mi = self._mask_index.get(key)
+                if mi is None:
+                    mi = self._mask_index[key] = (torch.arange(B, device=dev, dtype=torch.int32) * nr).contiguous()
+            compact = Fn.RowSubset(trans, holder["trans_bf16"], rows, L, mask_index=mi, mask_row=mask_row,
+                                   mask_token=getattr(needed_rows, "_mart_mask_token", None))
+            trans = Fn._DenseRowsFn.apply(trans, rows, B, L)            # the reference's [B, L, H] tensor: promised rows filled in, NaN elsewhere
+            trans._mart_rows = compact
+        logits = Fn.LazyLogits(trans, holder["trans_bf16"] if compact is None else None, st, head_split=self._engine.head_split, valid_rows=rows,
+                               compact=compact)
         loss = None
         if labels is not None:                      # CrossEntropyLoss over the full vocabulary (:880-882); not used by MarT
             full = logits.materialize()

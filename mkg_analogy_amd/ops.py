@@ -384,15 +384,44 @@ def rank(logits, label, out):
     L.check(L.lib().mart_rank(_p(logits), _rows2d(logits), _p(label), _p(out), R, Cc, _stream()), "mart_rank")
 
 
-def simloss_fwd(trans, rel_idx, q_idx, a_idx, loss_rows):
-    B, Lq, H = trans.shape
-    L.check(L.lib().mart_simloss_fwd(_p(trans), _p(rel_idx), _p(q_idx), _p(a_idx), _p(loss_rows), B, Lq, H, _stream()), "mart_simloss_fwd")
+def simloss_fwd(trans, rel_idx, q_idx, a_idx, loss_rows, rows=None, L_=None):
+    """``rows`` (int32 [B, nr] flat ids) given: ``trans`` is the compact [B * nr, H] tensor of a row-subset pass and ``L_`` the sequence length."""
+    if rows is None:
+        B, Lq, H = trans.shape
+        nr = 0
+    else:
+        B, nr = rows.shape
+        Lq, H = int(L_), trans.shape[-1]
+    L.check(L.lib().mart_simloss_fwd(_p(trans), _p(rel_idx), _p(q_idx), _p(a_idx), _p(rows), nr, _p(loss_rows), B, Lq, H, _stream()), "mart_simloss_fwd")
 
 
-def simloss_bwd(trans, rel_idx, q_idx, a_idx, gscale, rowscale, dtrans):
-    B, Lq, H = trans.shape
-    L.check(L.lib().mart_simloss_bwd(_p(trans), _p(rel_idx), _p(q_idx), _p(a_idx), _p(gscale), rowscale, _p(dtrans), B, Lq, H, _stream()),
+def simloss_bwd(trans, rel_idx, q_idx, a_idx, gscale, rowscale, dtrans, rows=None, L_=None):
+    if rows is None:
+        B, Lq, H = trans.shape
+        nr = 0
+    else:
+        B, nr = rows.shape
+        Lq, H = int(L_), trans.shape[-1]
+    L.check(L.lib().mart_simloss_bwd(_p(trans), _p(rel_idx), _p(q_idx), _p(a_idx), _p(rows), nr, _p(gscale), rowscale, _p(dtrans), B, Lq, H, _stream()),
             "mart_simloss_bwd")
+
+
+def needed_rows(ids, token, rel_idx, q_idx, a_idx, rows_out, mask_row_out=None, status=None):
+    B, Lq = ids.shape
+    L.check(L.lib().mart_needed_rows(_p(ids), B, Lq, int(token), _p(rel_idx), _p(q_idx), _p(a_idx), _p(rows_out), _p(mask_row_out), _p(status), _stream()),
+            "mart_needed_rows")
+
+
+def rows_lookup(flat, rows, Lq, out, status=None):
+    L.check(L.lib().mart_rows_lookup(_p(flat), flat.numel(), _p(rows), int(rows.shape[1]), int(Lq), _p(out), _p(status), _stream()), "mart_rows_lookup")
+
+
+def sum_splits_f32(parts, out):
+    L.check(L.lib().mart_sum_splits_f32(_p(parts), int(parts.shape[0]), out.numel(), _p(out), _stream()), "mart_sum_splits_f32")
+
+
+def rows_dense(src, rows, B, Lq, dst, fill=float("nan")):
+    L.check(L.lib().mart_rows_dense(_p(src), _p(rows), int(rows.shape[1]), B, Lq, src.shape[-1], _p(dst), fill, _stream()), "mart_rows_dense")
 
 
 def find_token(ids, token, pos_out, row_out=None, status=None):
@@ -461,9 +490,10 @@ def dropout_mask(out_u8, p, seed):
     L.check(L.lib().mart_dropout_mask(_p(out_u8), out_u8.numel(), p, seed, _stream()), "mart_dropout_mask")
 
 
-def adamw(*, master, grad, m, v, shadow, chunks, n_chunks, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale=1.0, shadow_f16=None):
+def adamw(*, master, grad, m, v, shadow, chunks, n_chunks, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale=1.0, shadow_f16=None, zero_grad=False):
     d = L.AdamW()
     d.shadow_f16 = _p(shadow_f16)
+    d.zero_grad = int(zero_grad)
     d.master, d.grad, d.m, d.v, d.shadow_bf16 = _p(master), _p(grad), _p(m), _p(v), _p(shadow)
     d.chunks, d.n_chunks = _p(chunks), n_chunks
     d.lr, d.beta1, d.beta2, d.eps, d.weight_decay, d.bc1, d.bc2, d.grad_scale = lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale

@@ -42,6 +42,14 @@ def layout_order(n_layers: int) -> List[str]:
               t + "intermediate.dense.weight", t + "intermediate.dense.bias",
               t + "intermediate.fusion_dense.weight", t + "intermediate.fusion_dense.bias",
               t + "output.dense.weight", t + "output.dense.bias", t + "output.LayerNorm.weight", t + "output.LayerNorm.bias"]
+        if l == 0:
+            # the text stream ends here: its embedding tables (the tied 32 M-element word embedding among them) are final once text layer 0 and the
+            # embedding backward are through -- typically while the vision stream is still in its last layers -- so their all-reduce bucket / AdamW range
+            # is released then (engine.backward) instead of after the whole pass (round 6; they used to sit at the very end of the buffer)
+            u = "unimo."
+            o += [u + "text_embeddings.LayerNorm.weight", u + "text_embeddings.LayerNorm.bias",
+                  u + "text_embeddings.position_embeddings.weight", u + "text_embeddings.token_type_embeddings.weight",
+                  "cls.predictions.bias", u + "text_embeddings.word_embeddings.weight"]
         v = f"unimo.encoder.vision_layers.{l}."
         o += [v + f"self_attn.{n}.weight" for n in ("q_proj", "k_proj", "v_proj")]
         o += [v + f"self_attn.{n}.bias" for n in ("q_proj", "k_proj", "v_proj")]
@@ -49,15 +57,12 @@ def layout_order(n_layers: int) -> List[str]:
               v + "mlp.fc1.weight", v + "mlp.fc1.bias", v + "mlp.fc2.weight", v + "mlp.fc2.bias",
               v + "layer_norm2.weight", v + "layer_norm2.bias"]
     u = "unimo."
-    o += [u + "text_embeddings.LayerNorm.weight", u + "text_embeddings.LayerNorm.bias",
-          u + "text_embeddings.position_embeddings.weight", u + "text_embeddings.token_type_embeddings.weight",
-          u + "vision_pre_layrnorm.weight", u + "vision_pre_layrnorm.bias",
+    o += [u + "vision_pre_layrnorm.weight", u + "vision_pre_layrnorm.bias",
           u + "vision_embeddings.class_embedding", u + "vision_embeddings.position_embedding.weight",
           u + "vision_embeddings.patch_embedding.weight",
           # never receive a gradient in the reference (dead pooler :748, unused post layernorm :683)
           u + "vision_post_layernorm.weight", u + "vision_post_layernorm.bias",
-          u + "text_pooler.dense.weight", u + "text_pooler.dense.bias",
-          "cls.predictions.bias", u + "text_embeddings.word_embeddings.weight"]
+          u + "text_pooler.dense.weight", u + "text_pooler.dense.bias"]
     return o
 
 
@@ -149,6 +154,7 @@ class FlatStore:
         # AdamW chunk table: (start, len, decay_flag); dead tensors are excluded (grad None in the reference => untouched)
         self.order = order
         self.version = 0                                           # bumped whenever the master weights change (derived operand caches)
+        self.grad_clean = True                                     # the gradient buffer is all-zero (FusedAdamW.fused_zero_grad / zero_grad)
         self.rebuild_chunks()
         self.refresh_shadows()
 
@@ -184,6 +190,7 @@ class FlatStore:
         if getattr(self, "_pending", None):
             self.join_pending()                      # an off-stream zero-fill may still be in flight (optim.FusedAdamW.zero_grad)
         s = self.slots[name]
+        self.grad_clean = False                      # handed out to a writer (every kernel's gradient destination comes from here or from fused())
         return self.grad[s.offset:s.offset + s.numel].view(s.shape)
 
     def w(self, name: str) -> torch.Tensor:
@@ -199,6 +206,8 @@ class FlatStore:
     def fused(self, names: Sequence[str], buf: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Adjacent tensors as one [sum(rows), ...] view of ``buf`` (default: bf16 shadow)."""
         buf = self.shadow if buf is None else buf
+        if buf is self.grad:
+            self.grad_clean = False
         first = self.slots[names[0]]
         rows = sum(self.slots[n].shape[0] for n in names)
         tail = first.shape[1:]
@@ -267,6 +276,11 @@ class FlatStore:
     def zero_grad(self) -> None:
         self.join_pending()
         self.grad.zero_()
+        self.grad_clean = True
+
+    def touch_grad(self) -> None:
+        """For writers that go to ``store.grad`` / ``p.grad`` directly (g() and fused(.., grad) mark the buffer themselves): no longer all-zero."""
+        self.grad_clean = False
 
     # ---- work enqueued on another stream that the gradient writers / the readers of the transposed shadows must not overtake
     def pending(self, stream) -> None:

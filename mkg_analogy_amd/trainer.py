@@ -38,6 +38,10 @@ class Trainer:
         self.sync = GradSync(lit.model)
         self.sync.broadcast_optimizer(self.optimizer)
         self.optimizer.grad_scale = self.sync.grad_scale / max(1, self.accumulate_grad_batches)
+        if hasattr(self.optimizer, "fused_zero_grad"):
+            # this loop owns zero_grad() and step(): the update zeroes the gradients it consumes and the next zero_grad() skips its fill (optim.FusedAdamW)
+            import os
+            self.optimizer.fused_zero_grad = os.environ.get("MART_FUSED_ZERO_GRAD", "1") == "1"
 
     @staticmethod
     def _shards(loader) -> int:

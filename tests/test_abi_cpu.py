@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported_and_bound(built):
     for n in names:
         assert hasattr(l, n), f"{n} declared in mart_hip.h but not exported by libmart_hip.so"
     assert set(names) == set(built.EXPORTS), set(names) ^ set(built.EXPORTS)
-    assert l.mart_abi_version() == built.EXPECTED_ABI == 9
+    assert l.mart_abi_version() == built.EXPECTED_ABI == 10
 
 
 def test_descriptor_layouts_match_header(built):

@@ -53,11 +53,16 @@ def test_flat_layout_covers_every_parameter_once(model):
     names = [n for n, _ in model.named_parameters()]
     order = layout_order(12)
     assert sorted(order) == sorted(names) and len(set(order)) == len(order)
-    # backward-completion order: head first, layer 11 before layer 0, tied embedding last
+    # backward-completion order: head first, layer 11 before layer 0; the text stream's embedding tables (tied word embedding last of them) right
+    # behind text layer 0 and in FRONT of vision layer 0 (they are final when the text stream ends: engine.backward releases them then); the vision
+    # embeddings and the never-trained tensors at the very end
     assert order[0].startswith("cls.predictions.transform")
     assert order.index("unimo.encoder.text_layer.11.output.dense.weight") < order.index("unimo.encoder.vision_layers.11.mlp.fc1.weight") \
         < order.index("unimo.encoder.text_layer.10.output.dense.weight") < order.index("unimo.encoder.vision_layers.0.mlp.fc1.weight")
-    assert order[-1] == "unimo.text_embeddings.word_embeddings.weight" and order[-2] == "cls.predictions.bias"
+    iw = order.index("unimo.text_embeddings.word_embeddings.weight")
+    assert order[iw - 1] == "cls.predictions.bias" and order[iw + 1] == "unimo.encoder.vision_layers.0.self_attn.q_proj.weight"
+    assert order.index("unimo.encoder.text_layer.0.output.LayerNorm.bias") < iw < order.index("unimo.vision_embeddings.patch_embedding.weight")
+    assert order[-1] == "unimo.text_pooler.dense.bias"
     # every GEMM weight group is made of adjacent, alignment-preserving members
     shapes = {n: tuple(p.shape) for n, p in model.named_parameters()}
     for key, members in gemm_weight_names(12):

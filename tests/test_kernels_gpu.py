@@ -777,3 +777,94 @@ def test_device_side_batch_assembly(ops):
     ops.patchify(pix, a, B, S, p)
     ops.patchify_gather(table, idx, b_, B, S, p)
     assert torch.equal(a, b_)
+
+
+def test_row_subset_helpers(ops):
+    """needed_rows / rows_lookup / rows_dense / the relaxation loss on compact rows / split-K sum / AdamW's folded zero-fill (round 6)."""
+    from mkg_analogy_amd import functional as Fn
+    B, L, H = 6, 24, 64
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(1000, 2000, (B, L), generator=g)
+    mpos = [3, 23, 0, 11, 7, 9]
+    for b, p in enumerate(mpos):
+        ids[b, p] = 103
+    ids[4, 7] = 5                                        # example 4 has no [MASK]
+    rel = torch.tensor([[1, 5], [2, 6], [3, 7], [1, 8], [-1, 4], [0, 0]])
+    qh, ah = torch.tensor([1, 1, 2, 3, 4, 5]), torch.tensor([4, 5, 6, 7, 4, -24])
+    dev_ids = ids.to(DEV)
+    st = Fn._status(dev_ids.device)
+    st.zero_()
+    rows = Fn.needed_rows(dev_ids, 103, (rel.to(DEV), qh.to(DEV), ah.to(DEV)))
+    exp = torch.stack([torch.tensor([m if b != 4 else 0 for b, m in enumerate(mpos)]), rel[:, 0] % L, rel[:, 1] % L, qh % L, ah % L], 1) + torch.arange(B)[:, None] * L
+    assert rows.dtype == torch.int32 and torch.equal(rows.cpu().long(), exp) and torch.equal(rows._mart_mask_row.cpu().long(), exp[:, 0])
+    assert int(st) == 2
+    st.zero_()
+    r1 = Fn.needed_rows(dev_ids, 103)
+    assert tuple(r1.shape) == (B, 1) and torch.equal(r1.cpu().long()[:, 0], exp[:, 0])
+    st.zero_()
+    # lookup: first slot wins; a row outside the promise -> slot 0 of its example + status bit 2
+    flat = torch.tensor([exp[0, 3], exp[5, 1], exp[2, 0], 1 * L + 20], dtype=torch.int32, device=DEV)
+    out = torch.empty(4, dtype=torch.int32, device=DEV)
+    ops.rows_lookup(flat, rows, L, out, status=st)
+    first = lambda b, f: b * 5 + [int(x) for x in exp[b]].index(int(f))
+    assert out.tolist() == [first(0, exp[0, 3]), first(5, exp[5, 1]), first(2, exp[2, 0]), 5] and int(st) == 4
+    st.zero_()
+    # dense view: promised rows (first slot), NaN elsewhere; its backward takes a repeated position once
+    comp = rnd(B * 5, H, seed=3, dtype=F32).requires_grad_(True)
+    dense = Fn._DenseRowsFn.apply(comp, rows, B, L)
+    ref = torch.full((B * L, H), float("nan"), device=DEV)
+    for b in range(B):
+        for j in reversed(range(5)):
+            ref[int(exp[b, j])] = comp.detach()[b * 5 + j]
+    assert torch.equal(torch.nan_to_num(dense.view(-1, H), nan=-7.0), torch.nan_to_num(ref, nan=-7.0))
+    gd = rnd(B, L, H, seed=4, dtype=F32)
+    dense.backward(gd)
+    gref = torch.zeros(B * 5, H, device=DEV)
+    for b in range(B):
+        seen = set()
+        for j in range(5):
+            f = int(exp[b, j])
+            if f not in seen:
+                gref[b * 5 + j] = gd.view(-1, H)[f]
+            seen.add(f)
+    assert torch.equal(comp.grad, gref)
+    # relaxation loss on the compact rows == on the dense tensor (values and gradients)
+    tr = rnd(B, L, H, seed=5, dtype=F32)
+    comp2 = torch.stack([tr.view(-1, H)[int(exp[b, j])] for b in range(B) for j in range(5)]).contiguous().requires_grad_(True)
+    trd = tr.clone().requires_grad_(True)
+    l_d = Fn.relaxation_loss(trd, rel.to(DEV), qh.to(DEV), ah.to(DEV))
+    l_d.backward()
+    l_c = Fn._SimLossFn.apply(comp2, rel.to(DEV), qh.to(DEV), ah.to(DEV), rows, L)
+    l_c.backward()
+    ar = torch.arange(B)
+    cos = torch.nn.functional.cosine_similarity
+    t_ = tr.cpu()
+    l_ref = (torch.relu(cos(t_[ar, qh], t_[ar, ah])) + 1 - cos(t_[ar, rel[:, 0]], t_[ar, rel[:, 1]])).mean()
+    assert abs(float(l_d) - float(l_ref)) < 1e-5 and abs(float(l_c) - float(l_d)) < 1e-6
+    gsum = torch.zeros(B * L, H, device=DEV)
+    for b in range(B):
+        for j in range(5):
+            gsum[int(exp[b, j])] += comp2.grad[b * 5 + j]
+    close(gsum, trd.grad.view(-1, H), 1e-6, 1e-5, "relaxation-loss gradient, compact rows vs dense")
+    # a position the pass was not promised: that example's loss is NaN (nothing read)
+    bad = Fn._SimLossFn.apply(comp2.detach(), rel.to(DEV), torch.tensor([1, 1, 2, 3, 4, 6], device=DEV), ah.to(DEV), rows, L)
+    assert torch.isnan(bad)
+    # ordered split-K sum
+    parts = rnd(5, 12, 64, seed=6, dtype=F32)
+    o = torch.empty(12, 64, device=DEV)
+    ops.sum_splits_f32(parts, o)
+    close(o, parts.sum(0), 1e-6, 1e-6, "sum_splits")
+    # AdamW with the zero-fill folded in: same update, gradients of the updated chunks read zero afterwards, the rest untouched
+    n = 70000
+    res = []
+    for zg in (False, True):
+        master, grad = rnd(n, seed=1, dtype=F32), rnd(n, seed=2, dtype=F32)
+        m, v, sh = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV, dtype=BF)
+        chunks = torch.tensor([[0, 65536, 1], [65536 + 256, 1000, 0]], dtype=torch.int32, device=DEV)
+        ops.adamw(master=master, grad=grad, m=m, v=v, shadow=sh, chunks=chunks, n_chunks=2, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01,
+                  bc1=0.1, bc2=0.001, zero_grad=zg)
+        res.append((master, grad, m))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    g1, g0 = res[1][1], res[0][1]
+    assert float(g1[:65536].abs().max()) == 0.0 and float(g1[65536 + 256:65536 + 1256].abs().max()) == 0.0
+    assert torch.equal(g1[65536:65536 + 256], g0[65536:65536 + 256]) and torch.equal(g1[65536 + 1256:], g0[65536 + 1256:])
