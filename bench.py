@@ -626,7 +626,7 @@ def main():
                 "patches_per_image": 49, "vision_tokens": 99, "steps": 5, "warmup": 3, "ms_per_step": round(1000.0 * d5 / 5, 3), "value": round(v5, 2),
                 "train_gflop_per_example": round(gf5, 1), "step_frac_of_mfma_peak": round(v5 * gf5 / 2.5e6, 4),
                 "roofline_examples_per_s": round(2.5e6 / gf5, 1)}
-    altt = altm = None
+    altt = altm = alts = None
     if world == 1 and a.model == "mkgformer" and not pre and a.patch == 16 and not a.no_kernel_timing and not a.train_only:
         # BASELINE configs[4] and configs[3] on the driver's box, briefly (2 warm-up + 5 timed steps each): the MarKG pre-train step (L = 96, LSCE over the
         # full 11 292-entity / 192-relation slices, pre_type 50 / 50, no sep_idx) and the FLAVA backbone (12 + 12 + 6 layers, 393 image tokens, B = 256).
@@ -650,6 +650,11 @@ def main():
             finally:
                 torch.cuda.empty_cache()
         m2 = lit2 = tr2 = None                          # (the 49-patch network of alt_geometry)
+        alts = leg("mkgformer", False, 57, "a length real MARS batches have: L = 57 (the reference pads a batch to its longest example, data_module.py:113-119; "
+                   "real lengths 40 .. 57), everything else as the headline -- no kernel of the step needs L to be a multiple of 32 / 64")
+        if "value" in alts:
+            alts["tokens_per_s_vs_headline"] = round(alts["value"] * (1 + 2 * P + 57) / (value * (1 + 2 * P + a.seq_len)), 4)
+            alts["text_tokens_per_s_vs_headline"] = round(alts["value"] * 57 / (value * a.seq_len), 4)
         altt = leg("mkgformer", True, 96, "BASELINE configs[4]: MarKG pre-train step (link prediction), L = 96, heads E = 11292 / R = 192, pre_type 50/50, no sep_idx")
         altm = leg("flava", False, a.seq_len, "BASELINE configs[3]: FLAVA-base backbone (12 image + 12 text + 6 multimodal layers, 393 image tokens), fine-tune step")
     spread = None
@@ -690,6 +695,8 @@ def main():
             out["alt_weights"] = altw
         if altg is not None:
             out["alt_geometry"] = altg
+        if alts is not None:
+            out["alt_seq_len"] = alts
         if altt is not None:
             out["alt_task"] = altt
         if altm is not None:

@@ -123,7 +123,7 @@ __device__ __forceinline__ void stage_tile(const Side& s, int b, int h, int r0, 
 // per 1-KB copy (per-lane clamp, prefix / own select and a 64-bit multiply, if-converted into vector code): four copies per tile were a third
 // of the forward kernel's VALU and most of its SALU instructions (16.5 VALU + 7.3 SALU per MFMA, profiles/r03_pmc_attn_fwd.txt).  Here the
 // source of a 32-row half is a WAVE-UNIFORM pointer (scalar unit: prefix or own block, rows j0 ..) plus ONE loop-invariant 32-bit lane offset,
-// issued in the saddr form; only a half that is cut by the last key takes the per-lane clamp.  Needs the prefix length to be a multiple of 32.
+// issued in the saddr form; only a half that is cut by the last key (per-lane clamp) or that straddles the prefix / own boundary (prefix length not a multiple of 32: per-lane select) leaves it.
 struct Stager {
   const bf16* own_b; const bf16* pre_b;   // first row of this (batch, head) in the own / prefix block
   unsigned voff_own, voff_pre;            // byte offset of this lane's chunk inside a 32-row half
@@ -151,8 +151,14 @@ __device__ __forceinline__ void stage_tile_fast(const Stager& g, int r0, char* l
   for (int r = 0; r < 2; ++r) {
     const int j0 = r0 + r * 32;                                                       // first row of this half (wave-uniform)
     char* dst = lds + (r * NTH + wave * 64) * 16;
-    if (j0 < g.n_pre) {
+    if (j0 + 32 <= g.n_pre) {
       dma_saddr(g.pre_b + (long long)j0 * g.ld_pre, g.voff_pre, dst);
+    } else if (j0 < g.n_pre) {
+      // the ONE half that straddles the prefix / own boundary (prefix length not a multiple of 32: text rows as long as the batch's longest example,
+      // data_module.py:113-119): per-lane source select, general 64-bit address form
+      const int rowh = tid >> 3, pc = tid & 7, lc = pc ^ swz_key(rowh), j = j0 + rowh;
+      const bf16* src = j < g.n_pre ? g.pre_b + (long long)j * g.ld_pre : g.own_b + (long long)min(j - g.n_pre, g.n_own - 1) * g.ld_own;
+      glds16(src + lc * 8, dst);
     } else {
       const int jj = j0 - g.n_pre;
       if (jj + 32 <= g.n_own) {
@@ -328,14 +334,16 @@ __global__ __launch_bounds__(RES ? RES_NTH : 64 * fwd_waves(TEXT, TPW, RES), RES
   const int ntiles = (Stot + 63) / 64;
   Stager gK, gV;
   if constexpr (!TEXT) { gK = make_stager(K, b, h, tid); gV = make_stager(V, b, h, tid); }
-  // vision: uniform-pointer staging (the host routes prefix lengths that are not multiples of 32 to the general instantiation)
+  // vision: uniform-pointer staging; a prefix length that is not a multiple of 32 has ONE 32-row half that straddles the prefix / own boundary
+  // (index strad): its tile takes the per-half form, the half itself a per-lane select (stage_tile_fast)
+  const int strad = (p.Lp & 31) ? (p.Lp >> 5) : -1;
 #ifndef FWD_STAGE_FULL
 #define FWD_STAGE_FULL 1
 #endif
 #define stage_kv(r0_, buf_)                                                                           \
   do {                                                                                                 \
     if constexpr (!TEXT) {                                                                             \
-      if (FWD_STAGE_FULL && (r0_) + 64 <= Stot) {                                                      \
+      if (FWD_STAGE_FULL && (r0_) + 64 <= Stot && ((r0_) >> 5) != strad && ((r0_) >> 5) + 1 != strad) {  \
         stage_tile_full(gK, (r0_), (buf_), wave);                                                      \
         stage_tile_full(gV, (r0_), (buf_) + TILE_BYTES, wave);                                         \
       } else {                                                                                         \
@@ -1871,7 +1879,7 @@ extern "C" int mart_debug_attn_stamps(unsigned long long* host_out) {
 extern "C" int mart_attn_fwd(const mart_attn_fwd_desc* d, void* stream) {
   if (int rc = check_fwd(d)) return rc;
   if (int rc = set_attrs()) return rc;
-  const bool text = d->attn_mask || d->sep || d->p_drop > 0.f || (d->Lp & 31) != 0;   // general instantiation: every option, any prefix length
+  const bool text = d->attn_mask || d->sep || d->p_drop > 0.f;   // general instantiation: every text option; the vision kernel takes any prefix length (round 6)
   static const int tpw = getenv("MART_ATTN_TPW") ? atoi(getenv("MART_ATTN_TPW")) : 1;
 #ifdef MART_EXPERIMENTS   // (tools/build_variant.sh attention.hip <out.so> -DMART_EXPERIMENTS; MART_ATTN_RES=1)
   static const int res = getenv("MART_ATTN_RES") ? atoi(getenv("MART_ATTN_RES")) : 0;

@@ -318,7 +318,9 @@ __global__ __launch_bounds__(FT, 1) void fusion_bwd_k(mart_fusion_bwd_desc p, in
       for (int c = 0; c < 4; ++c) {
         const int col = kt[t] * 32 + 8 * c + 4 * hh;
         bf16x4 v = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-        if (val[t] && u < g.QT && col < p.ldp) v = *(const bf16x4*)(prow + col);
+        // query rows past the end of a partial block (Lq not a multiple of 32: the reference pads a batch to its longest example, data_module.py:113-119)
+        // keep P = 0, hence dS = 0: their staged Q / dO rows are clamped copies of the last row and must not reach dV
+        if (val[t] && u < g.QT && u * 32 + l31 < g.nq && col < p.ldp) v = *(const bf16x4*)(prow + col);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { pr[t][u][4 * c + e] = (float)v[e]; rs[u] += (float)v[e] * dp[t][u][4 * c + e]; }
       }
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(FT, 1) void fusion_bwd_k(mart_fusion_bwd_desc p, in
 struct Plan { int lds, nbuf, red_off; bool ok; };
 Plan make_plan(int Lq, int Nv, int H, bool bwd = false) {
   Plan pl{0, 0, 0, false};
-  if (H != 768 || Lq <= 0 || Lq % 32 != 0 || Nv <= 0 || Nv > 512) return pl;
+  if (H != 768 || Lq <= 0 || Nv <= 0 || Nv > 512) return pl;      // any Lq: the last 32-row query block may be partial (rows clamped on load, masked in B2, skipped on store)
   const int KT64 = (Nv + 63) / 64, SB = (KT64 + 1) * 8192, PB = 2 * KT64 * 4096, VC = (H / 64) * 4096;
   const int p1 = 2 * SB;
   pl.nbuf = PB + 2 * VC + RED_BYTES <= LDS_MAX ? 2 : 1;
@@ -449,7 +451,7 @@ extern "C" int mart_fusion_supported(int Lq, int Nv, int H) { return make_plan(L
 extern "C" int mart_fusion_fwd(const mart_fusion_fwd_desc* d, void* stream) {
   MART_CHECK(d && d->q && d->v && d->out && d->probs && d->B > 0, "fusion_fwd: bad args");
   const Plan pl = make_plan(d->Lq, d->Nv, d->H);
-  MART_CHECK(pl.ok, "fusion_fwd: unsupported shape (H = 768, Lq a multiple of 32, Nv <= 512: mart_fusion_supported)");
+  MART_CHECK(pl.ok, "fusion_fwd: unsupported shape (H = 768, Nv <= 512: mart_fusion_supported)");
   const int KT64 = (d->Nv + 63) / 64;
   MART_CHECK(d->ldq >= d->H && d->ldv >= d->H && d->ldo >= d->H && d->ldq % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0, "fusion_fwd: row strides must cover H (ldq, ldv multiples of 8)");
   MART_CHECK(d->ldp >= d->Nv && d->ldp % 8 == 0 && d->ldp <= KT64 * 64, "fusion_fwd: ldp must be a multiple of 8 in [Nv, 64 * ceil(Nv / 64)]");

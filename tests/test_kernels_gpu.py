@@ -426,7 +426,10 @@ def _heads(x, B, S, nh):          # [B*S, nh*64] -> [B,nh,S,64]
                                         # of 64, with and without a prefix), and the fused backward's dQ pipeline is compiled for 14 or 16 chunks of 32 keys
                                         (1, 2, 65, 0), (1, 2, 95, 0), (1, 2, 96, 0), (1, 2, 97, 0), (2, 2, 129, 32), (2, 2, 128, 32), (1, 2, 393, 0),
                                         (1, 2, 448, 0), (1, 1, 449, 0), (1, 2, 448, 64), (1, 2, 416, 32),
-                                        (1, 2, 130, 20)])       # a prefix that is no multiple of 8: per-lane K staging in the fused backward, general forward instantiation
+                                        (1, 2, 130, 20),        # a prefix that is no multiple of 8: per-lane K staging in the fused backward
+                                        # round 6: prefix lengths real MARS batches have (L = longest example of the batch): ONE 32-row half of the key stream
+                                        # straddles the prefix / own boundary in the vision forward kernel (first / second half of a tile, short and long prefixes)
+                                        (2, 12, 393, 57), (2, 3, 393, 37), (1, 2, 200, 101), (2, 2, 99, 5), (1, 2, 393, 96), (2, 2, 260, 33), (1, 3, 150, 63)])
 def test_attention_vision(ops, B, nh, S, Lp):
     H = nh * 64
     qkv = rnd(B * S, 3 * H, seed=1, scale=1.0)
