@@ -182,6 +182,44 @@ __device__ __forceinline__ void stage_tile_full(const Stager& g, int r0, char* l
     dma_saddr(base, pre ? g.voff_pre : g.voff_own, lds + (r * NTH + wave * 64) * 16);
   }
 }
+// ---- round 6: the same copies with the row offset folded into the LANE offset.  The ISA of the forms above was ~120 VALU + ~330 SALU per key tile and
+// wave (64-bit row multiplies, prefix / own selects, three v_readfirstlane per copy, branch ladders) -- more instructions than the tile's softmax.  Here a
+// copy of a 32-row half that lies inside one block is: one scalar multiply (row * bytes per row), one v_add (lane offset + that), s_mov m0, the DMA --
+// against FOUR loop-invariant scalar bases (K / V x own / prefix block of this (batch, head)).  Offsets are 32-bit byte offsets inside the block
+// (host-checked: rows * ld * 2 < 2^32).  Halves cut by the last key or straddling the prefix / own boundary take the per-lane form.
+struct Lean {
+  const char* own_b; const char* pre_b;   // row 0 of this (batch, head) in the own / prefix block (wave-uniform)
+  unsigned vo_own, vo_pre;                // byte offset of this lane's chunk inside a 32-row half
+  unsigned rb_own, rb_pre;                // bytes per row
+  int n_own, n_pre;
+};
+__device__ __forceinline__ Lean make_lean(const Side& s, int b, int h, int tid) {
+  const int rowh = tid >> 3, pc = tid & 7, lc = pc ^ swz_key(rowh);
+  Lean g;
+  g.own_b = (const char*)(s.own + ((long long)b * s.n_own) * s.ld_own + h * 64);
+  g.pre_b = s.n_pre ? (const char*)(s.pre + ((long long)b * s.n_pre) * s.ld_pre + h * 64) : g.own_b;
+  g.rb_own = (unsigned)s.ld_own * 2u; g.rb_pre = (unsigned)s.ld_pre * 2u;
+  g.vo_own = (unsigned)rowh * g.rb_own + (unsigned)lc * 16u;
+  g.vo_pre = (unsigned)rowh * g.rb_pre + (unsigned)lc * 16u;
+  g.n_own = s.n_own; g.n_pre = s.n_pre;
+  return g;
+}
+__device__ __forceinline__ void dma_lean(const char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_dst), "v"(voff), "s"(sbase) : "memory", "m0");
+}
+// one 32-row half (rows j0 .. j0 + 31 of the key stream [prefix | own]) -> 4 KB at LDS byte address lds_dst (this wave's 1 KB slice: + wave * 1024 by the caller)
+__device__ __forceinline__ void stage_half_lean(const Lean& g, int j0, unsigned lds_dst, int tid) {
+  const int jj = j0 - g.n_pre;
+  if (j0 + 32 <= g.n_pre) {
+    dma_lean(g.pre_b, g.vo_pre + (unsigned)j0 * g.rb_pre, lds_dst);
+  } else if (jj >= 0 && jj + 32 <= g.n_own) {
+    dma_lean(g.own_b, g.vo_own + (unsigned)jj * g.rb_own, lds_dst);
+  } else {                                                    // cut by the last key (clamped rows) or straddling the prefix / own boundary: per-lane row
+    const int rowh = tid >> 3, pc = tid & 7, lc = pc ^ swz_key(rowh), j = j0 + rowh;
+    if (j < g.n_pre) dma_lean(g.pre_b, (unsigned)j * g.rb_pre + (unsigned)lc * 16u, lds_dst);
+    else dma_lean(g.own_b, (unsigned)min(j - g.n_pre, g.n_own - 1) * g.rb_own + (unsigned)lc * 16u, lds_dst);
+  }
+}
 // Per-lane byte offsets of the fragment reads inside a 64x64 tile -- loop invariant, computed once per kernel so the
 // tile loops carry no address arithmetic (the first version spent 36 VALU instructions per MFMA, mostly on this).
 struct LaneOffs {
@@ -340,9 +378,24 @@ __global__ __launch_bounds__(RES ? RES_NTH : 64 * fwd_waves(TEXT, TPW, RES), RES
 #ifndef FWD_STAGE_FULL
 #define FWD_STAGE_FULL 1
 #endif
+#ifndef FWD_LEAN_STAGE
+#define FWD_LEAN_STAGE 1
+#endif
+  Lean lK, lV;
+  unsigned lds_w = 0;                                  // LDS byte address of this wave's 1 KB slice of K half 0 of ring stage 0
+  if constexpr (!TEXT && !RES && FWD_LEAN_STAGE) {
+    lK = make_lean(K, b, h, tid); lV = make_lean(V, b, h, tid);
+    lds_w = __builtin_amdgcn_readfirstlane((unsigned)(__UINTPTR_TYPE__)LDS_PTR(smem)) + (unsigned)wave * 1024u;
+  }
 #define stage_kv(r0_, buf_)                                                                           \
   do {                                                                                                 \
-    if constexpr (!TEXT) {                                                                             \
+    if constexpr (!TEXT && !RES && FWD_LEAN_STAGE) {                                                   \
+      const unsigned d0_ = lds_w + (unsigned)((buf_) - smem);                                          \
+      stage_half_lean(lK, (r0_), d0_, tid);                                                            \
+      stage_half_lean(lK, (r0_) + 32, d0_ + 4096u, tid);                                               \
+      stage_half_lean(lV, (r0_), d0_ + (unsigned)TILE_BYTES, tid);                                     \
+      stage_half_lean(lV, (r0_) + 32, d0_ + (unsigned)TILE_BYTES + 4096u, tid);                        \
+    } else if constexpr (!TEXT) {                                                                      \
       if (FWD_STAGE_FULL && (r0_) + 64 <= Stot && ((r0_) >> 5) != strad && ((r0_) >> 5) + 1 != strad) {  \
         stage_tile_full(gK, (r0_), (buf_), wave);                                                      \
         stage_tile_full(gV, (r0_), (buf_) + TILE_BYTES, wave);                                         \
@@ -374,14 +427,20 @@ __global__ __launch_bounds__(RES ? RES_NTH : 64 * fwd_waves(TEXT, TPW, RES), RES
 #ifndef FWD_HALF_TAIL
 #define FWD_HALF_TAIL 1
 #endif
+#ifndef FWD_NOMAX
+#define FWD_NOMAX 1                                      // vision forward: probabilities against the running reference maximum, no per-tile maximum (round 6)
+#endif
 #ifndef FWD_PEEL
 #define FWD_PEEL 1                                       // the last key tile peeled out of the loop (vision ring kernel)
 #endif
   // One tile.  LAST (compile time, vision ring kernel with FWD_PEEL): the tile that may be cut by the last key -- the only one that carries the partial-tile
   // mask and the block guard NT (32-key blocks that hold keys: the last tile of the vision shapes, 393 = 6 x 64 + 9 and 457 = 7 x 64 + 9 keys, runs
   // as ONE block: half the MFMAs and exponentials of a tile that was 86 % padding).  The loop body proper is straight-line.
-  auto tile = [&](const int kt, auto last_c) {
+  // MODE (vision ring kernel with FWD_NOMAX): 0 = classic tile (tile maximum, new reference, rescale), 1 = fast tile (probabilities against the running
+  // reference; returns false -- nothing changed -- when the wave vote finds a sum that says the reference is too low)
+  auto tile = [&](const int kt, auto last_c, auto mode_c) -> bool {
     constexpr bool LAST = decltype(last_c)::value;
+    constexpr int MODE = decltype(mode_c)::value;
     const int NT = (LAST && FWD_HALF_TAIL && (!TEXT && !RES) && kt * 64 + 32 >= Stot) ? 1 : 2;      // wave-uniform
     const char* sK = RES ? smem + kt * TILE_BYTES : smem + (kt & 1) * STAGE_BYTES;
     const char* sV = RES ? smem + (ntiles + kt) * TILE_BYTES : sK + TILE_BYTES;
@@ -389,6 +448,73 @@ __global__ __launch_bounds__(RES ? RES_NTH : 64 * fwd_waves(TEXT, TPW, RES), RES
     f32x16 st[TPW][2];
     float pv[TPW][2][16];
     float alpha[TPW];
+    constexpr bool NOMAX = FWD_NOMAX && !TEXT && TPW == 1;
+    if constexpr (NOMAX) {
+      // Round 6 (vision ring kernel): NO per-tile maximum on the fast path.  The probabilities of a tile are formed against the running reference
+      // maximum m_run at once (fma, exp2, add per score, in place of the scores) and the per-row partial sums -- needed anyway -- tell whether that
+      // was legal: a lane's sum stays below 2^60 unless some score exceeds the reference by ~60 binary orders.  If one does (wave vote; never on
+      // activations this network produces) the tile is REDONE in the classic form -- S recomputed from the K tile still in LDS, tile maximum, new
+      // reference, O / l rescaled -- which is also how the first tile runs (m_run has no value yet).  The reference may lag the true row maximum by up
+      // to 2^60: harmless -- P is a floating-point number (bf16 keeps its 8 bits at any magnitude), O and l are f32 sums bounded by 2^60 x keys x |V|, and
+      // the saved statistic m + log2(l) does not depend on the reference.  Gone from every tile but the first: 22 v_max3 / v_max, a cross-lane
+      // exchange, a wave vote IN FRONT of the exponentials (they used to wait for the whole maximum chain) and the threshold logic of the
+      // deferred rescale (rounds 1-5 deferred only the rescale, threshold 2^8).
+      auto scores = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) if (t < NT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[0][t][r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) st[0][t] = mfma32(tile_frag(sK, t, ks, lo), qf[0][ks], st[0][t]);
+        }
+        if (LAST && kt * 64 + 64 > Stot) {                  // partial last key tile: mask in place; -1e30 * c2 - m underflows exp2 to exactly 0
+          const int lim = Stot - kt * 64;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) if (t < NT)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (t * 32 + mfma_row(r, hh) >= lim) st[0][t][r] = -1.0e30f;
+        }
+      };
+      auto probs = [&](const float m_ref) {                  // P = exp2(S c2 - m_ref) in the log2 domain, packed two scores per instruction; returns the lane's sum
+        f32x2 rs2 = {0.f, 0.f};
+        const f32x2 c22 = {c2, c2}, mn2 = {m_ref, m_ref};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) if (t < NT)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const f32x2 x = f32x2{st[0][t][r], st[0][t][r + 1]} * c22 - mn2;
+            const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            rs2 += e;
+            st[0][t][r] = e[0]; st[0][t][r + 1] = e[1];          // in place: the scores are dead (the classic form recomputes them from the K tile)
+          }
+        return rs2[0] + rs2[1];
+      };
+      float rs = 0.f;
+      alpha[0] = 1.f;
+      scores();
+      if constexpr (MODE == 1) {
+        rs = probs(m_run[0]);
+        if (!__all(rs < 1.152921504606846976e18f)) return false;    // 2^60; inf / NaN fail the compare as well.  Nothing of the wave's state was touched.
+      } else {                                               // first tile, or the redo of a tile that failed the vote (and whatever follows it)
+        float mx = st[0][0][0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) if (t < NT)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[0][t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
+        const float m_new = fmaxf(m_run[0], mx);
+        alpha[0] = __builtin_amdgcn_exp2f(m_run[0] - m_new);
+        rs = probs(m_new);
+        m_run[0] = m_new;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l_run[0] = l_run[0] * alpha[0] + rs;
+      if (!__all(alpha[0] == 1.f)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ot[0][0][r] *= alpha[0]; ot[0][1][r] *= alpha[0]; }
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
       if (u > 0 && !active[u]) continue;
@@ -514,6 +640,7 @@ __global__ __launch_bounds__(RES ? RES_NTH : 64 * fwd_waves(TEXT, TPW, RES), RES
         for (int r = 0; r < 16; ++r) { ot[u][0][r] *= alpha[u]; ot[u][1][r] *= alpha[u]; }
       }
     }
+    }
     // O^T[d][q] += V^T P^T   (the transposed V fragments are shared by the wave's tiles)
 #pragma unroll
     for (int t = 0; t < 2; ++t) if (t < NT)
@@ -525,26 +652,75 @@ __global__ __launch_bounds__(RES ? RES_NTH : 64 * fwd_waves(TEXT, TPW, RES), RES
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
           if (u > 0 && !active[u]) continue;
-          const bf16x8 pf = pack8(&pv[u][t][8 * a]);
+          bf16x8 pf;
+          if constexpr (NOMAX) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (bf16)st[u][t][8 * a + e];
+          } else {
+            pf = pack8(&pv[u][t][8 * a]);
+          }
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) ot[u][dt] = mfma32(vf[dt], pf, ot[u][dt]);
         }
       }
+    return true;
   };
   constexpr bool PEEL = FWD_PEEL && !TEXT && !RES;
-  for (int kt = 0; kt < ntiles - (PEEL ? 1 : 0); ++kt) {
-    if constexpr (!RES) {
+  using Classic = std::integral_constant<int, 0>;
+  using Fast = std::integral_constant<int, 1>;
+  if constexpr (PEEL && FWD_NOMAX && TPW == 1) {
+    // tile 0 classic (it gives the reference maximum its first value), the others fast; a wave whose vote fails redoes THAT tile in the classic form and
+    // finishes the key stream in it -- every wave still passes the same barriers and stages the same tiles, whichever form it runs
+    int kt = 0;
+    bool bad = false;
+    if (ntiles > 1) {
       tile_barrier();
-      ATTN_STAMP(0, stamp_on, 2 + kt);
-      if (kt + 1 < ntiles && (NWV == 4 || wave < 4)) stage_kv((kt + 1) * 64, smem + ((kt + 1) & 1) * STAGE_BYTES);
+      ATTN_STAMP(0, stamp_on, 2);
+      if (NWV == 4 || wave < 4) stage_kv(64, smem + STAGE_BYTES);
+      if (active[0]) tile(0, std::false_type{}, Classic{});
+      for (kt = 1; kt < ntiles - 1; ++kt) {
+        tile_barrier();
+        ATTN_STAMP(0, stamp_on, 2 + kt);
+        if (NWV == 4 || wave < 4) stage_kv((kt + 1) * 64, smem + ((kt + 1) & 1) * STAGE_BYTES);
+        if (!active[0]) continue;                     // wave past the last query row: only stages tiles and keeps the barriers
+        if (!tile(kt, std::false_type{}, Fast{})) { bad = true; break; }
+      }
+      if (!bad) {
+        tile_barrier();
+        ATTN_STAMP(0, stamp_on, 1 + ntiles);
+        if (active[0] && !tile(ntiles - 1, std::true_type{}, Fast{})) bad = true;     // (kt == ntiles - 1 here)
+      }
+    } else {
+      tile_barrier();
+      if (active[0]) tile(0, std::true_type{}, Classic{});
     }
-    if (!active[0]) continue;                         // wave past the last query row: only stages tiles and keeps the barriers
-    if constexpr (PEEL) tile(kt, std::false_type{}); else tile(kt, std::true_type{});
-  }
-  if constexpr (PEEL) {
-    tile_barrier();
-    ATTN_STAMP(0, stamp_on, 1 + ntiles);
-    if (active[0]) tile(ntiles - 1, std::true_type{});
+    if (__builtin_expect(bad, 0)) {
+      if (kt < ntiles - 1) {
+        tile(kt, std::false_type{}, Classic{});       // its barrier and the staging of tile kt + 1 were done by the fast loop
+        for (++kt; kt < ntiles - 1; ++kt) {
+          tile_barrier();
+          if (NWV == 4 || wave < 4) stage_kv((kt + 1) * 64, smem + ((kt + 1) & 1) * STAGE_BYTES);
+          tile(kt, std::false_type{}, Classic{});
+        }
+        tile_barrier();
+      }
+      tile(ntiles - 1, std::true_type{}, Classic{});  // (failed in the last tile itself: its barrier was passed above)
+    }
+  } else {
+    for (int kt = 0; kt < ntiles - (PEEL ? 1 : 0); ++kt) {
+      if constexpr (!RES) {
+        tile_barrier();
+        ATTN_STAMP(0, stamp_on, 2 + kt);
+        if (kt + 1 < ntiles && (NWV == 4 || wave < 4)) stage_kv((kt + 1) * 64, smem + ((kt + 1) & 1) * STAGE_BYTES);
+      }
+      if (!active[0]) continue;                       // wave past the last query row: only stages tiles and keeps the barriers
+      if constexpr (PEEL) tile(kt, std::false_type{}, Classic{}); else tile(kt, std::true_type{}, Classic{});
+    }
+    if constexpr (PEEL) {
+      tile_barrier();
+      ATTN_STAMP(0, stamp_on, 1 + ntiles);
+      if (active[0]) tile(ntiles - 1, std::true_type{}, Classic{});
+    }
   }
 #ifndef FWD_LDS_EPI
 #define FWD_LDS_EPI 1
