@@ -266,18 +266,30 @@ __global__ __launch_bounds__(NT) void gemm_tn8_kernel(Args2 p) {
     s16x4 hi = lds_tr_read(half + (r0 + 4) * 256 + boff);
     return join_tr(lo, hi);
   };
+  // Harness-only knock-outs (tools/tn_one_transposed.sh, -DMART_EXPERIMENTS -DTN_KO_PLAIN=1|2|3): the fragments of Y (1), X (2) or both (3) come from ONE
+  // plain ds_read_b128 each instead of two transposed reads -- WRONG RESULTS, same LDS-DMA traffic, same MFMAs: the upper bound of what an operand
+  // that arrives M-contiguous (a transposed copy written by its producer) could save in the loop.
+#if defined(MART_EXPERIMENTS) && defined(TN_KO_PLAIN)
+  constexpr int KO = TN_KO_PLAIN;
+#else
+  constexpr int KO = 0;
+#endif
+  auto frag_plain = [&](const char* half, int col0, int a) -> bf16x8 {      // (knock-out) a conflict-free 16-byte read per lane: row l31 of the 64 x 256 B image
+    return *(const bf16x8*)(half + (a * 16 + (l31 >> 1)) * 256 + ((((col0 >> 3) + (l31 & 1) * 2 + h) ^ ((l31 >> 1) & 3) << 2) & 15) * 16);
+  };
   bf16x8 xf[2][4], yf[2][4];                         // X fragments [block of the pair][k-step], Y fragments [j][k-step]
   auto readX = [&](const char* st, auto IH) {
     constexpr int ih = decltype(IH)::value;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) xf[ii][a] = frag(st + ih * HALF_BYTES, wr * 64 + ii * 32, a);
+      for (int a = 0; a < 4; ++a) xf[ii][a] = (KO & 2) ? frag_plain(st + ih * HALF_BYTES, wr * 64 + ii * 32, a) : frag(st + ih * HALF_BYTES, wr * 64 + ii * 32, a);
   };
   auto readY = [&](const char* st, auto J) {
     constexpr int j = decltype(J)::value;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) yf[j][a] = frag(st + X_BYTES + (wq >> 1) * HALF_BYTES, (wq & 1) * 64 + j * 32, a);
+    for (int a = 0; a < 4; ++a)
+      yf[j][a] = (KO & 1) ? frag_plain(st + X_BYTES + (wq >> 1) * HALF_BYTES, (wq & 1) * 64 + j * 32, a) : frag(st + X_BYTES + (wq >> 1) * HALF_BYTES, (wq & 1) * 64 + j * 32, a);
   };
   auto colsum_step = [&](auto IH) {                   // k-step a == wave column: VALU sums of fragments the MFMAs consume anyway
     constexpr int ih = decltype(IH)::value;
@@ -337,7 +349,8 @@ __global__ __launch_bounds__(NT) void gemm_tn8_kernel(Args2 p) {
     __builtin_amdgcn_sched_barrier(0);
     readY(st, I0{});
     if (more1) issueX(t + 1, I1{});
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); // the 16 X reads (issued first) are retired: Xl may be re-staged in P2
+    if (KO) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); // the 16 X reads (issued first) are retired: Xl may be re-staged in P2
     bar();
     lgkm0();
     mma(I0{}, I0{});
