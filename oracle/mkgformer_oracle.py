@@ -166,6 +166,34 @@ def condition_weights(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
     return out
 
 
+def outlier_weights(sd: Dict[str, Tensor], channels=(5, 77, 300, 511, 700), gain: float = 12.0, offset: float = 2.0,
+                    residual_gain: float = 2.0, fusion_comp: bool = True) -> Dict[str, Tensor]:
+    """Synthetic weights with the activation statistics trained CLIP / BERT checkpoints are known for (none can be loaded offline; test
+    infrastructure): a handful of OUTLIER CHANNELS -- every LayerNorm scales them by ``gain`` and shifts them by ``offset``, so post-LayerNorm
+    activations carry entries ~10-30 where the rest is O(1), with large per-row means -- and LARGE RESIDUAL NORMS (the vision out-proj / fc2 and the
+    text attention-output / output projections are scaled by ``residual_gain``, so the f32 residual streams grow from layer to layer instead of
+    staying at the embedding scale).  Applied on top of ``condition_weights``; ``fusion_comp`` keeps the score scale of the unscaled fusion softmax
+    (which reads the vision residual stream directly) where ``condition_weights`` put it, so the map stays smooth: the reference's own bf16-weight control
+    moves the logits by ~1e-2 on this set (3e-3 .. 1.5e-2 for residual_gain 1 .. 3), as on the conditioned set without outliers.  Returns a new dict."""
+    out = condition_weights(sd)
+    ch = torch.as_tensor(list(channels), dtype=torch.long)
+    for k, v in list(out.items()):
+        if v.dim() == 1 and ("LayerNorm.weight" in k or "layer_norm1.weight" in k or "layer_norm2.weight" in k or "layrnorm.weight" in k):
+            w = v.clone(); w[ch] = w[ch] * gain; out[k] = w
+        elif v.dim() == 1 and ("LayerNorm.bias" in k or "layer_norm1.bias" in k or "layer_norm2.bias" in k or "layrnorm.bias" in k):
+            b = v.clone(); b[ch] = b[ch] + offset; out[k] = b
+        elif v.dim() == 2 and (k.endswith("self_attn.out_proj.weight") or k.endswith("mlp.fc2.weight") or
+                               (("text_layer" in k) and (k.endswith("attention.output.dense.weight") or k.endswith(".output.dense.weight")))):
+            out[k] = v * residual_gain
+    if fusion_comp:
+        # the unscaled fusion softmax softmax(ctx vis^T) sees the vision residual stream directly: keep its score scale where condition_weights put it
+        for l in range(8, 12):
+            for k in ("weight", "bias"):
+                n = f"unimo.encoder.text_layer.{l}.attention.self.value.{k}"
+                out[n] = out[n] / (residual_gain * residual_gain)
+    return out
+
+
 # --------------------------------------------------------------------------- small pieces
 def gelu_erf(x: Tensor) -> Tensor:
     """transformers ACT2FN['gelu'] = exact erf GELU (call sites modeling_unimo.py:454,967)."""
