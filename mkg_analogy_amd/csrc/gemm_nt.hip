@@ -25,7 +25,25 @@ namespace {
 // The pointers are cast to the global address space explicitly: where address-space inference fails (pointers carried
 // around the persistent tile loop) the compiler emits FLAT accesses, which have no scalar-base addressing form and count
 // on lgkmcnt as well -- every LDS wait of the epilogue then also waited for the stores before it.
+// Harness-only (tools/nt_store_policy.sh, -DMART_EXPERIMENTS -DMART_ST_POLICY=k): the cache policy of the epilogue's 16-byte stores -- 1 sc1 (write-through,
+// the line is dropped from the XCD's L2), 2 sc0 sc1, 3 sc1 nt -- against the shipped nt stores (which keep the line in L2 until evicted).
+#if defined(MART_EXPERIMENTS) && defined(MART_ST_POLICY)
+template <typename T> __device__ __forceinline__ void st_policy16(T* p, T v) {
+  static_assert(sizeof(T) == 16, "16-byte stores only");
+  const f32x4 d = __builtin_bit_cast(f32x4, v);
+#if MART_ST_POLICY == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(d) : "memory");
+#elif MART_ST_POLICY == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(d) : "memory");
+#endif
+}
+#endif
 template <typename T> __device__ __forceinline__ void st_stream(T* p, T v) {
+#if defined(MART_EXPERIMENTS) && defined(MART_ST_POLICY)
+  if constexpr (sizeof(T) == 16) { st_policy16(p, v); return; }
+#endif
   auto* g = (__attribute__((address_space(1))) T*)p;
 #if MART_NT_EPILOGUE
   __builtin_nontemporal_store(v, g);
