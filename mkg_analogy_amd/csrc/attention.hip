@@ -96,7 +96,7 @@ __device__ __forceinline__ int swz_key(int row) {
 // 64-bit multiply: ~28 VALU instructions per copy, four copies per tile iteration) is left to the cut halves.
 // (Measured and dropped, twice each: the copy as opaque assembly -- no compiler-forced vmcnt(0) in front of the
 // transposed reads -- is 2 % slower; a 4-stage ring with three tiles in flight and counted waits changes nothing:
-// the loop does not wait for the DMA)
+// the loop does not wait for the DMA, see docs/LAB_r01-r05.md section 4.2.)
 #ifndef STAGE_RAW
 #define STAGE_RAW 0
 #endif
@@ -321,7 +321,7 @@ __device__ __forceinline__ float mask_add(uint64_t mb_lane, int c) { return ((mb
 #ifndef ATTN_FWD_MINW1
 #define ATTN_FWD_MINW1 4
 #endif
-// RES (vision, round 4; an experiment, compiled only with -DMART_EXPERIMENTS -- measured 40 % SLOWER): the K / V of the whole head RESIDENT in LDS.  One 16-wave workgroup per (batch, head): every thread brings in one 16-byte
+// RES (vision, round 4; an experiment, compiled only with -DMART_EXPERIMENTS -- measured 40 % SLOWER, docs/LAB_r01-r05.md section 4.2): the K / V of the whole head RESIDENT in LDS.  One 16-wave workgroup per (batch, head): every thread brings in one 16-byte
 // chunk of every 64-key tile of K (waves 0-7) or V (waves 8-15) with one LDS-DMA instruction per tile -- the head is staged ONCE instead of once
 // per 128-query part (four times at 393 queries, the fourth for 9 rows), by straight-line address code in a prologue instead of the branchy
 // per-tile staging of the ring -- then ONE barrier, and every wave walks the image with its 32 queries at its own pace: no barrier, no DMA wait and

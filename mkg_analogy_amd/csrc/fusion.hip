@@ -34,7 +34,7 @@ __device__ __forceinline__ void dma_wait_barrier() {
 }
 // The LDS-DMA goes out as opaque assembly: through the builtin the compiler, which cannot tell which LDS bytes a DMA writes, puts s_waitcnt vmcnt(0)
 // in front of the next LDS read -- i.e. right behind the prefetch of the NEXT chunk, which it thereby serialises with the compute of this one
-// (attention.hip).  Every consumer sits behind dma_wait_barrier(), which carries the wait explicitly.
+// (attention.hip, docs/LAB_r01-r05.md section 4.2).  Every consumer sits behind dma_wait_barrier(), which carries the wait explicitly.
 #ifndef FUSION_RAW
 #define FUSION_RAW 0   // measured neutral on both kernels (65.6 vs 66.6 us forward, 288 vs 287 us backward): the builtin stays
 #endif

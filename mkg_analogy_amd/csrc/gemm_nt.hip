@@ -1157,7 +1157,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   // ONE full round of large tiles over the first rows and 128x128 tiles (two workgroups per CU) over the rest: two launches on the same stream, every
   // row-indexed operand advanced by the rows of the first part.  Alone: the eight products of a layer 0.888 -> 0.824 ms (-7 %, tools/bench_nt_p49.py).
   // In the step: 34.61 / 34.63 ms against 34.55 / 34.64 without it (same box, alternating) -- NOTHING: the weight-gradient and text queues already
-  // run in the CUs a second round leaves idle.  Not shipped.
+  // run in the CUs a second round leaves idle.  Not shipped (docs/LAB_r01-r05.md section 6).
   if (NT_SPLIT_ROUNDS && d->tile_cfg == 0 && d->batch <= 1 && !d->a_rows && !d->b_blocked && !d->c_split3 && d->N % 256 == 0 && d->M > 256) {
     const int tn = d->N / 256, t256s = ((d->M + 255) / 256) * tn;
     const int rows_big = (256 / tn) * 256;

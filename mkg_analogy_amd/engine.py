@@ -104,7 +104,7 @@ class UnimoEngine:
         # unfused pass (tests/test_ln_fold_model_gpu.py) and +0.2-2.7 % (mean +1.3 %) on the bf16 evaluation pass (28.34 against 28.71 ms over five alternations: the producers'
         # extra 155 MB and the consumers' heavier epilogues eat most of the 1.75 ms) -- NOT the default, because with it a no_grad pass and the forward
         # pass of a training step stop being bit-identical (test_text_fp16_forward_vs_plain_bf16_text_stream) for that 1 %.  A training step cannot
-        # use it at all: the weight-gradient GEMM needs the normalised activations as its operand.
+        # use it at all: the weight-gradient GEMM needs the normalised activations as its operand (docs/LAB_r01-r05.md section 6).
         self.ln_fold = os.environ.get("MART_LN_FOLD", "0") == "1"
         self._foldcache: Dict[str, tuple] = {}
         # wgrad_lag: the backward pass of a vision layer does not wait for the weight-gradient stream before its LayerNorm-1 backward rewrites the bf16

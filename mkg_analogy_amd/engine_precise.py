@@ -31,7 +31,7 @@ class _PreciseBase:
     def _init_base(self, store: FlatStore):
         self.st = store
         self._w3: Dict[str, Tuple[int, torch.Tensor]] = {}
-        # Error-budget hook (tools/error_budget.py): the components named here run with their operands ROUNDED TO BF16
+        # Error-budget hook (tools/error_budget.py, docs/LAB_r01-r05.md section 5): the components named here run with their operands ROUNDED TO BF16
         # (as the training path stores them) while everything else stays fp32-accurate, so the logit error each component class
         # contributes can be measured in isolation.  Tags: vis_lin, vis_attn, txt_lin_lo (layers < 8), txt_lin_hi, txt_attn,
         # fusion, head_t, head_s.  Empty in normal use.

@@ -36,7 +36,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # MART_ASYNC_STEP=1: step-boundary work that the NEXT forward pass does not need -- the gradient zero-fill and the refresh of the transposed
         # weight shadows (read by data-gradient GEMMs only) -- stays on the optimizer stream; the backward pass joins it (FlatStore.join_pending).
         # Off by default: measured within noise of the in-order form (87.24 / 87.50 vs 87.47 / 87.36 ms: the un-profiled step boundary has no idle
-        # time to recover), and with it ``zero_grad()`` returns before ``p.grad`` reads as zero on the caller's stream.
+        # time to recover, docs/LAB_r01-r05.md section 4.3), and with it ``zero_grad()`` returns before ``p.grad`` reads as zero on the caller's stream.
         self.async_step = os.environ.get("MART_ASYNC_STEP", "0") == "1"
         # fused_zero_grad: the update kernel writes 0 back to the gradient elements it has just consumed, and the next ``zero_grad()`` finds the buffer
         # clean (FlatStore.grad_clean) and skips its 0.94 GB fill -- 0.13-0.19 ms at the head of every step on the main queue, moved under the backward

@@ -13,7 +13,7 @@ kernel (same issue points, same counts) for both wave-rows and asserts, for ever
 
 The 8-phase loop (kept for tile-blocked weights and operands beyond 2^31 elements) is replayed too: with the wait where rounds 2-4 had it -- at
 the end of P4's MFMA cluster -- the checker flags a one-barrier-short wait for the lagging wave-row (the finding that put the new loop's waits into
-its read segments); with the wait in front of P4's first barrier (round 5) it is ordered as well."""
+its read segments, docs/LAB_r01-r05.md section 4.1e); with the wait in front of P4's first barrier (round 5) it is ordered as well."""
 from collections import deque
 
 import pytest

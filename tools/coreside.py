@@ -1,4 +1,4 @@
-"""Do memory-bound kernels co-reside with the 256 x 256 GEMM workgroups on a CU?  (round 4)
+"""Do memory-bound kernels co-reside with the 256 x 256 GEMM workgroups on a CU?  (round 4, docs/LAB_r01-r05.md section 4.4)
 
 A GEMM workgroup holds 128 KB of the CU's 160 KB LDS and 8 waves x 221-256 VGPRs: at 224 allocated registers per wave a SIMD has 64 registers per
 lane (and the CU 32 KB of LDS) left, so a wave of a <= 64-VGPR kernel fits next to it; at 256 nothing does.  This script times a GEMM loop on one

@@ -1,4 +1,4 @@
-"""Per-component bf16 error budget of the mask-row logits.
+"""Per-component bf16 error budget of the mask-row logits (docs/LAB_r01-r05.md section 5).
 
 Runs the fp32-accurate forward (engine_precise) on the golden batch G7 with ONE component class at a time degraded to bf16 operands
 (``PreciseUnimoForward.degrade``) and prints how far the mask logits move from the reference's (tests/golden/g7_bench_*.npz), next to

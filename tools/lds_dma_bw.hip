@@ -1,5 +1,5 @@
 // Micro-benchmark: sustained global->LDS (LDS-DMA, 16 B/lane) bandwidth of one 512-thread workgroup per CU, for the access
-// patterns of the NT GEMM stage (diagnostic for DESIGN.md section 4.1).   usage: lds_dma_bw
+// patterns of the NT GEMM stage (diagnostic for docs/LAB_r01-r05.md section 4.1).   usage: lds_dma_bw
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

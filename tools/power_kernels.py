@@ -1,4 +1,4 @@
-"""Package power and shader clock per kernel family: each family runs alone in a 3 s loop while rocm-smi is sampled at ~4 Hz (round 4).
+"""Package power and shader clock per kernel family: each family runs alone in a 3 s loop while rocm-smi is sampled at ~4 Hz (round 4, docs/LAB_r01-r05.md section 4.1d).
 usage: python tools/power_kernels.py"""
 import os
 import re
