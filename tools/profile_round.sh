@@ -1,9 +1,9 @@
 #!/bin/bash
 # Evidence of a round's final state, one gpurun call: the bench line, rocprofv3 kernel-trace summaries (serial + shipped schedule), PMC passes of the
 # dominant kernel (-> roofline.traffic), the other BASELINE configurations.  Everything lands in gpurun_out/; what is judged is copied to profiles/.
-# usage: bash tools/profile_round.sh r05
+# usage: bash tools/profile_round.sh r06
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out
 for mode in serial overlap; do
   if [ $mode = serial ]; then export MART_OVERLAP_WGRAD=0 MART_TWO_STREAM=0; else export MART_OVERLAP_WGRAD=1 MART_TWO_STREAM=1; fi
@@ -40,9 +40,18 @@ run p49 --patch 32
 run head2063 --entity-head 2063
 run pretrain --task pretrain --seq-len 96
 run pretrain_p49 --task pretrain --seq-len 96 --patch 32
-run flava --model flava --batch 128
+run flava --model flava
 run plain --weights plain
 timeout 300 python tools/step_boundary.py 20 > gpurun_out/${TAG}_step_boundary.txt 2>&1
+# un-profiled main-queue intervals (HIP events at phase boundaries) at both geometries
+{ timeout 300 python tools/tail_marks.py --patch 16 --steps 12 2>&1 | grep -v amdgpu.ids; timeout 300 python tools/tail_marks.py --patch 32 --steps 12 2>&1 | grep -v amdgpu.ids; } > gpurun_out/${TAG}_tail_marks.txt
+# queue timeline of the 49-patch geometry (shipped schedule) and the kernel-by-kernel listing of its tail
+rm -rf gpurun_out/prof_tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -- python bench.py --patch 32 --steps 4 --warmup 2 --no-cpu-baseline --train-only --no-kernel-timing > /dev/null 2>&1
+DB=$(find gpurun_out/prof_tmp -name "*.db" | head -1)
+python tools/rocpd_streams.py $DB > gpurun_out/${TAG}_streams_overlap_p49.txt 2>&1
+python tools/rocpd_tail.py $DB 700 1500 > gpurun_out/${TAG}_tail_p49.txt 2>&1
+rm -rf gpurun_out/prof_tmp
 python - <<PY
 import json
 d = json.load(open("gpurun_out/${TAG}_bench.json"))
