@@ -588,6 +588,10 @@ def main():
         barrier()
         d2 = time.perf_counter() - t1
         alt = {"entity_head": other, "steps": 5, "ms_per_step": round(1000.0 * d2 / 5, 3), "value": round(a.batch * 5 / d2, 2)}
+        # back to the headline's head: the legs below train on `batch`, whose labels index THAT head (a label beyond the 2063-entity head is out of range:
+        # NaN loss since round 6, an out-of-bounds read before -- rounds 2-5 timed `alt_weights` that way)
+        lit.analogy_entity_ids = D.data_config()["analogy_entity_ids"] if head == D.N_ANALOGY else list(range(D.BASE_VOCAB, D.BASE_VOCAB + D.N_ENT))
+        lit._ids_cache.clear()
     altw = None
     if world == 1 and a.model == "mkgformer" and not pre and a.weights == "conditioned" and not a.no_kernel_timing and not a.train_only:
         # the same step on PLAIN N(0, 0.02) weights (the golden G7-plain set), timed briefly: the rate does not depend on the values
@@ -711,6 +715,12 @@ def main():
             out["comm"] = comm
             out["comm_exposed_ms"] = comm["comm_exposed_ms"]
             out["rccl_world"] = comm["rccl_world"]
+        try:                                            # bad labels / examples without [MASK] flagged by any kernel of this process (functional.check_status)
+            from mkg_analogy_amd import functional as Fn_
+            Fn_.check_status()
+            out["status_check"] = "ok"
+        except IndexError as e:
+            out["status_check"] = f"FLAGGED: {e}"
         out["metric_detail"] = f"entity_head={head}, text_f16={int(getattr(getattr(model, 'engine', None), 'text_f16', False))}, weights={a.weights}"
         if not a.no_cpu_baseline and world == 1 and a.model == "mkgformer" and not pre:
             try:

@@ -264,6 +264,7 @@ class UnimoEngine:
             self._inflight.popleft().synchronize()
 
     def _pass_end(self):
+        self._wg2 = False                           # (set per backward pass; a weight-gradient launch outside one uses the first side queue)
         if self.max_inflight > 0:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -350,7 +351,9 @@ class UnimoEngine:
 
         t_qkv_prev = None
         ev_tqkv = ev_vis = None
-        fold = self.ln_fold and not keep and self.taps is None and self.inject is None and H % 128 == 0
+        # (the fold's epilogues exist on gemm_nt's aligned fast path only: 16-byte aligned rows -- H a multiple of 128 covers every operand here -- and operands
+        # below 2^31 elements; anything else takes the separate LayerNorm pass instead of an error from the kernel library)
+        fold = self.ln_fold and not keep and self.taps is None and self.inject is None and H % 128 == 0 and Mv * max(I, 3 * H) < 2 ** 31
         xv_b = xv_stats = None                                         # bf16 copy / per-row partial sums of xv, when the previous layer's fc2 epilogue wrote them
         for l in range(self.n_layers):
             # ================= vision layer l (CLIPEncoderLayer.forward, modeling_unimo.py:490-527)
