@@ -69,7 +69,8 @@ typedef struct {
                                                                      written as fp16 and C2, when given, is its bf16 copy (what the backward pass reads).  preact stays bf16. */
   int c_split3;                                                   /* C is bf16 [M, >= 3N]: the f32 result (after bias / activation) as the two-term split [hi | lo | hi]
                                                                      (mart_split_bf16x3 role 0) -- the A operand of the next GEMM of the fp32-accurate path, written by
-                                                                     the epilogue instead of an f32 C plus a split pass.  256 x 256 tiles, N % 256 == 0, no other outputs */
+                                                                     the epilogue instead of an f32 C plus a split pass.  256 x 256 tiles, N % 256 == 0, no other outputs;
+                                                                     NOT available with b_blocked or operands beyond 2^31 elements (status < 0, as of ABI 9) */
   /* LayerNorm folded into the product that consumes it (nn.LayerNorm -> nn.Linear: modeling_unimo.py:509 -> :223-225 and :518 -> :284-286), for forward
    * passes that keep nothing for a backward pass:  LN(x) W^T + b = rstd (x (gamma o W)^T - mean s) + b'  (mart_ln_fold_prep makes gamma o W, s, b').
    * row_stats (producer: f32 C + res_f32 + C2, N % 64 == 0): float [M][N / 64][2], per row and 64-column slice the (sum, sum of squares) of the f32 values

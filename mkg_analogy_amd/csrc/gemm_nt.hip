@@ -1149,16 +1149,15 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
   MART_CHECK(!d->b_blocked || (d->N % 256 == 0 && !d->b_rows && (d->batch <= 1 || d->stride_b == 0)), "gemm_nt: b_blocked needs N % 256 == 0, no b_rows, shared B");
   MART_CHECK((long long)(d->a_rows ? d->a_src_rows : d->M) * d->lda < (1LL << 32) && (long long)(d->b_rows ? d->b_src_rows : d->N) * d->ldb < (1LL << 32),
              "gemm_nt: operand (or the table a row gather indexes: a_src_rows / b_src_rows) too large for 32-bit element offsets");
-#ifndef NT_SPLIT_ROUNDS
-#define NT_SPLIT_ROUNDS 0
-#endif
-  // Tile quantisation experiment (round 5; variant builds with -DNT_SPLIT_ROUNDS=1): a product of 1.0-1.6 rounds of 256x256 tiles on the 256 CUs -- the
+#if defined(MART_EXPERIMENTS) && defined(NT_SPLIT_ROUNDS) && NT_SPLIT_ROUNDS
+  // Harness / variant builds only (-DMART_EXPERIMENTS -DNT_SPLIT_ROUNDS=1; valid for the plain, residual and activation epilogues of the benchmarked shapes:
+  // A2 / bias_by_brow / a_rows semantics are NOT carried into the second launch).  Tile quantisation experiment (round 5): a product of 1.0-1.6 rounds of 256x256 tiles on the 256 CUs -- the
   // five N = 768 products per layer at the reference's default geometry, M = 25 344: 297 tiles -- pays two rounds when it runs alone.  Here it runs as
   // ONE full round of large tiles over the first rows and 128x128 tiles (two workgroups per CU) over the rest: two launches on the same stream, every
   // row-indexed operand advanced by the rows of the first part.  Alone: the eight products of a layer 0.888 -> 0.824 ms (-7 %, tools/bench_nt_p49.py).
   // In the step: 34.61 / 34.63 ms against 34.55 / 34.64 without it (same box, alternating) -- NOTHING: the weight-gradient and text queues already
   // run in the CUs a second round leaves idle.  Not shipped (docs/LAB_r01-r05.md section 6).
-  if (NT_SPLIT_ROUNDS && d->tile_cfg == 0 && d->batch <= 1 && !d->a_rows && !d->b_blocked && !d->c_split3 && d->N % 256 == 0 && d->M > 256) {
+  if (d->tile_cfg == 0 && d->batch <= 1 && !d->a_rows && !d->A2 && !d->bias_by_brow && !d->b_blocked && !d->c_split3 && d->N % 256 == 0 && d->M > 256) {
     const int tn = d->N / 256, t256s = ((d->M + 255) / 256) * tn;
     const int rows_big = (256 / tn) * 256;
     if (t256s > 256 && t256s <= 410 && rows_big > 0 && rows_big < d->M) {
@@ -1185,6 +1184,7 @@ extern "C" int mart_gemm_nt(const mart_gemm_nt_desc* d, void* stream) {
       return rc ? rc : mart_gemm_nt(&d2, stream);
     }
   }
+#endif
   Args a;
   a.A = (const bf16*)d->A; a.B = (const bf16*)d->B; a.A2 = (const bf16*)d->A2; a.B2 = (const bf16*)d->B2;
   a.lda = d->lda; a.ldb = d->ldb; a.M = d->M; a.N = d->N; a.K = d->K; a.K2 = d->K2;
