@@ -338,9 +338,17 @@ class UnimoEngine:
                                type_=st.m(u + "token_type_embeddings.weight"), gamma=st.m(u + "LayerNorm.weight"), beta=st.m(u + "LayerNorm.bias"),
                                eps=self.eps_t, p_drop=p_h, seed=seed + 1, B=B, Lq=Lq, H=H, s_out=s_t, mean=tmean, rstd=trstd, out_f32=xt, out_bf16=xtb, out_f16=xth)
             sv["temb"] = (s_t, tmean, trstd)
+        def tap_text(name, t):
+            """Snapshot of the text stream, taken ON the text queue (that is where ``t`` is produced); the caller reads it on the main queue after the pass."""
+            with self._text_ctx():
+                c = t.view(B, Lq, H).clone()
+            if self._tstream is not None:
+                c.record_stream(torch.cuda.current_stream())
+            self.taps[name] = c
+
         if self.taps is not None:
             self.taps["vis_emb"] = xv.view(B, Nv, H).clone()
-            self.taps["txt_emb"] = xt.view(B, Lq, H).clone()
+            tap_text("txt_emb", xt)
         if self.inject is not None:
             assert not self.two_stream and not self.overlap_wgrad, "teacher forcing runs on the single-stream schedule"
             if "vis_emb" in self.inject:
@@ -510,7 +518,7 @@ class UnimoEngine:
             if self.taps is not None:
                 self.taps[f"vis{l}"] = xv.view(B, Nv, H).clone()
                 if xt.shape[0] == Mt:
-                    self.taps[f"txt{l}"] = xt.view(B, Lq, H).clone()
+                    tap_text(f"txt{l}", xt)
             if self.inject is not None:
                 if f"vis{l}" in self.inject:
                     xv = self.inject[f"vis{l}"].reshape(Mv, H).to(device=dev, dtype=F32).contiguous()

@@ -302,8 +302,10 @@ class UnimoForMaskedLM(nn.Module):
         post-attention part and the head transform then run on those rows only; the returned ``trans_hidden_states`` is NaN elsewhere, and
         ``logits`` refuses to score (or materialise) any other row.
         Exact for the rows named; omit it to get every row as the reference does."""
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / per-layer hidden states are not materialised by the fused HIP path")
+        if output_attentions:
+            raise NotImplementedError("attention maps are never materialised by the flash-style attention kernels (output_attentions is unused by MarT)")
+        if output_hidden_states and self.precision != "bf16":
+            raise NotImplementedError("output_hidden_states is served by the bf16 engine's stream taps; call set_precision('bf16') for it")
         if position_ids is not None or head_mask is not None:
             raise NotImplementedError("position_ids / head_mask are unused by MarT (modeling_unimo.py:78-80) and unsupported here")
         st = self.finalize()
@@ -351,6 +353,11 @@ class UnimoForMaskedLM(nn.Module):
         holder: Dict[str, torch.Tensor] = {}
         self._engine.save_for_backward = torch.is_grad_enabled()
         rows = mask_row = None
+        if output_hidden_states:
+            # modeling_unimo.py:604-646: the text stream entering every layer + the last layer's output (13 tensors [B, L, H]).  Served by the engine's
+            # stream taps: f32 copies of its text stream, DETACHED (no gradient flows through them); the pass runs dense (a row subset has no layer-11 rows)
+            needed_rows = None
+            self._engine.taps = {}
         if needed_rows is not None and labels is None:
             if getattr(needed_rows, "_mart_flat", False):               # built by Fn.needed_rows: flat int32 ids already (one device launch)
                 rows, mask_row = needed_rows, getattr(needed_rows, "_mart_mask_row", None)
@@ -359,8 +366,16 @@ class UnimoForMaskedLM(nn.Module):
                 nr_ = needed_rows.to(dev).reshape(B, -1).to(torch.int64)
                 nr_ = torch.where(nr_ < 0, nr_ + L, nr_).clamp(0, L - 1)     # negative positions wrap as in the reference's fancy indexing; out of place
                 rows = (torch.arange(B, device=dev, dtype=torch.int64)[:, None] * L + nr_).to(torch.int32).contiguous()
-        trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
-                                      image_table, image_index, rows)
+        hidden_states = None
+        try:
+            trans = Fn._MKGformerFn.apply(self._anchor, self._engine, input_ids, attention_mask, token_type_ids, pixel_values, sep_idx, train, seed, holder,
+                                          image_table, image_index, rows)
+            if output_hidden_states:
+                tp = self._engine.taps
+                hidden_states = (tp["txt_emb"],) + tuple(tp[f"txt{l}"] for l in range(self.config.num_hidden_layers))
+        finally:
+            if output_hidden_states:
+                self._engine.taps = None
         st.join_pending()                           # gradient zero-fill / W^T refresh issued next to this forward pass (optim.FusedAdamW)
         compact = None
         if rows is not None and trans.dim() == 2:   # row-subset pass: the engine returned the compact [B * nr, H] rows
@@ -381,7 +396,7 @@ class UnimoForMaskedLM(nn.Module):
         if labels is not None:                      # CrossEntropyLoss over the full vocabulary (:880-882); not used by MarT
             full = logits.materialize()
             loss = torch.nn.functional.cross_entropy(full.view(-1, full.shape[-1]), labels.to(dev).view(-1))
-        out = MaskedLMOutput(loss=loss, logits=logits, hidden_states=None, attentions=None)
+        out = MaskedLMOutput(loss=loss, logits=logits, hidden_states=hidden_states, attentions=None)
         if not return_dict:
-            return ((loss, logits) if loss is not None else (logits,)), trans
+            return tuple(v for v in (loss, logits, hidden_states) if v is not None), trans
         return out, trans

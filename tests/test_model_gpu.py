@@ -606,3 +606,38 @@ def test_torch_optimizer_by_name_equals_fused_adamw_and_runs_adam():
     torch.cuda.synchronize()
     assert math.isfinite(float(loss)) and not torch.equal(st.master, w0)
     assert torch.equal(st.shadow, st.master.to(torch.bfloat16))
+
+
+def test_output_hidden_states_vs_oracle():
+    """``output_hidden_states=True`` (modeling_unimo.py:604-646: the text stream entering every layer + the last layer's output, 13 x [B, L, H]) on the bf16
+    engine, shipped multi-queue schedule, against the oracle's per-layer text streams; the rest of the output is what a plain call returns."""
+    from mkg_analogy_amd import data_synth as D
+    model, lit, cfg, vc = _product(32, seed=3, conditioned=True)
+    sd = _oracle_sd(vc, 3, cfg["analogy_relation_ids"], True)
+    tc = O.TextCfg(vocab_size=BASE + NE + NR + 1)
+    batch = D.make_batch(3, 57, seed=11)
+    taps = {}
+    with torch.no_grad():
+        txt_emb = O.text_embed(sd, tc, batch["input_ids"], batch["token_type_ids"], False)
+        _, trans_ref = O.forward(sd, vc, tc, batch["input_ids"], batch["attention_mask"], batch["token_type_ids"], batch["pixel_values"], batch["sep_idx"],
+                                 train=False, taps=taps)
+    gb = {k: v.cuda() for k, v in batch.items()}
+    keys = ("input_ids", "attention_mask", "token_type_ids", "pixel_values", "sep_idx")
+    model.eval()
+    with torch.no_grad():
+        out, trans = model(**{k: gb[k] for k in keys}, return_dict=True, output_hidden_states=True)
+        out0, trans0 = model(**{k: gb[k] for k in keys}, return_dict=True)
+        tup, _ = model(**{k: gb[k] for k in keys}, return_dict=False, output_hidden_states=True)
+    hs = out.hidden_states
+    assert len(hs) == 13 and all(tuple(h.shape) == (3, 57, 768) for h in hs) and out0.hidden_states is None
+    assert len(tup) == 2 and len(tup[1]) == 13
+    assert torch.equal(trans, trans0)
+    refs = [txt_emb] + [taps[f"txt{l}"] for l in range(12)]
+    worst = 0.0
+    for i, (h, r) in enumerate(zip(hs, refs)):
+        rel = float((h.float().cpu() - r).norm() / r.norm())
+        worst = max(worst, rel)
+        assert rel < (1e-5 if i == 0 else 1.5e-2), (i, rel)
+    print(f"\nhidden_states: 13 text streams, worst rel-L2 vs the oracle {worst:.3e}")
+    with pytest.raises(NotImplementedError):
+        model(**{k: gb[k] for k in keys}, return_dict=True, output_attentions=True)
