@@ -188,7 +188,7 @@ class KernelTimer:
                 return which + ("_vision" if kw["M"] > 50000 else "_text"), 0.0, sum(n * sz for key, sz in sizes if kw.get(key) is not None)
             return f
         self.ops.ln_fwd = self._wrap("ln_fwd", lambda **kw: ln("ln_fwd", (("x_f32", 4), ("y_bf16", 2), ("s_out", 4), ("out_f32", 4), ("out_bf16", 2)))(**kw))
-        self.ops.ln_bwd = self._wrap("ln_bwd", lambda **kw: ln("ln_bwd", (("dy_f32", 4), ("dy_bf16", 2), ("s", 4), ("add_f32", 4), ("ds_f32", 4), ("ds_bf16", 2)))(**kw))
+        self.ops.ln_bwd = self._wrap("ln_bwd", lambda **kw: ln("ln_bwd", (("dy_f32", 4), ("dy_bf16", 2), ("s", 4), ("add_f32", 4), ("add_bf16", 2), ("ds_f32", 4), ("ds_bf16", 2)))(**kw))
         self.ops.gemm_nt = self._wrap("gemm_nt", nt)
         self.ops.gemm_tn = self._wrap("gemm_tn", tn)
         self.ops.attn_fwd = self._wrap("attn_fwd", lambda **kw: att(1)(**kw))
@@ -488,8 +488,8 @@ def main():
                               famrow("attn_fwd_vision", "attn_fwd_k<vision> (393 queries x 393 / 457 keys, d 64)"),
                               famrow("attn_bwd_vision", "attn_bwd_fused_k <vision> (one workgroup per head: dQ, dK, dV in one pass; algorithmic flops = 2 x forward)"),
                               famrow("gemm_nt_128", "gemm_nt_kernel<128,128,2,2> (small products: head, short grids)"),
-                              hbmrow("ln_bwd_vision", "ln_bwd_k (vision stream: dy bf16 + x f32 + residual gradient f32 in, f32 + bf16 out)"),
-                              hbmrow("ln_fwd_vision", "ln_fwd_k (vision stream: x f32 in, bf16 out)")) if r]
+                              hbmrow("ln_bwd_vision", "ln_bwd_fast_k (vision stream: dy bf16 + x f32 + residual gradient bf16 in, bf16 total out: 10 bytes per element; 16 with MART_GRAD_STREAM_BF16=0)"),
+                              hbmrow("ln_fwd_vision", "ln_fwd_fast_k (vision stream: x f32 in, bf16 out)")) if r]
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<256,256,2,4> (bf16 MFMA 16x16x32 NT GEMM, 4-phase K loop, fused epilogues)", "achieved": round(ach, 1),
                 "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": round(by / max(n, 1)), "launches_per_step": n, "ms_per_step": round(kms, 3),

@@ -140,6 +140,8 @@ typedef struct {
                                                                       d(visual) of the fusion op of the text layer below, delivered through a side buffer */
   int defer_reduce;                                                /* 1 (needs ws): only the partials are written; the caller adds them with mart_ln_dgb_reduce
                                                                       (same order, same result) -- e.g. on the weight-gradient stream, off the data-gradient chain */
+  const void* add_bf16;                                            /* instead of add_f32: the residual operand as bf16 -- the gradient w.r.t. the residual stream carried in
+                                                                      bf16 between layers (with bf16_total and no ds_f32: 10 bytes per element instead of 16) */
 } mart_ln_bwd_desc;
 int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream);
 /* number of per-workgroup partial rows mart_ln_bwd writes into ws for M rows ([partials][2][H] floats: dgamma, dbeta) */
@@ -246,7 +248,8 @@ int mart_fusion_supported(int Lq, int Nv, int H);
 int mart_fusion_fwd(const mart_fusion_fwd_desc* d, void* stream);
 /* autograd of the three lines above: dq = d(hidden) (bf16, written), dv_f32 += d(visual) in place (the vision-stream gradient; each
  * element is updated by one wave per launch and the 64-query blocks are sequential launches: no atomics, fixed order),
- * dv_bf16 = optional bf16 copy of the updated rows. */
+ * dv_bf16 = optional bf16 copy of the updated rows.  dv_f32 == NULL (round 6): the vision-stream gradient is carried in bf16 and dv_bf16 itself is
+ * read, updated and written (f32 arithmetic, one rounding). */
 typedef struct {
   const void* q; int ldq; const void* v; int ldv;
   const void* dout; int lddo;                                       /* d(fusion_output) bf16 [B*Lq, H] */

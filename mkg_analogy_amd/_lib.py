@@ -45,7 +45,7 @@ class LnFwd(C.Structure):
 class LnBwd(C.Structure):
     _fields_ = [("dy_f32", vp), ("dy_bf16", vp), ("s", vp), ("mean", vp), ("rstd", vp), ("gamma", vp), ("add_f32", vp),
                 ("M", i32), ("H", i32), ("ds_f32", vp), ("ds_bf16", vp), ("p_drop", f32), ("seed", u64),
-                ("dgamma", vp), ("dbeta", vp), ("bf16_total", i32), ("ws", vp), ("ws_bytes", i64), ("add2_f32", vp), ("defer_reduce", i32)]
+                ("dgamma", vp), ("dbeta", vp), ("bf16_total", i32), ("ws", vp), ("ws_bytes", i64), ("add2_f32", vp), ("defer_reduce", i32), ("add_bf16", vp)]
 
 
 class TextEmbed(C.Structure):

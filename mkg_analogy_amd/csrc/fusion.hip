@@ -364,7 +364,10 @@ __global__ __launch_bounds__(FT, 1) void fusion_bwd_k(mart_fusion_bwd_desc p, in
     stage64(Ob, p.lddo, 0, g.nq, dc * 64, buf + 8192, tid, wave);
   };
   const int rrow = lane >> 3, rcol = (lane & 7) * 4;            // row layout: 8 rows per instruction
-  float* dvf = p.dv_f32 + (long long)g.b * p.Nv * p.lddv + rcol;
+  // dv_f32 == NULL (round 6: the vision-stream gradient carried in bf16): the read-modify-write goes to the bf16 tensor alone (2 + 2 bytes per element
+  // instead of 4 + 4 + 2)
+  const bool gb16 = p.dv_f32 == nullptr;
+  float* dvf = gb16 ? nullptr : p.dv_f32 + (long long)g.b * p.Nv * p.lddv + rcol;
   bf16* dvb = p.dv_bf16 ? (bf16*)p.dv_bf16 + (long long)g.b * p.Nv * p.lddvb + rcol : nullptr;
   stage4(0, st0);
   for (int dc = 0; dc < ((dbg & 4) ? 0 : g.NDC); ++dc) {
@@ -379,7 +382,8 @@ __global__ __launch_bounds__(FT, 1) void fusion_bwd_k(mart_fusion_bwd_desc p, in
         for (int it = 0; it < 4; ++it) {
           const int key = kt[t] * 32 + it * 8 + rrow;
           old[dt][t][it] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (val[t] && key < p.Nv && !(dbg & 1)) old[dt][t][it] = *(const f32x4*)(dvf + (long long)key * p.lddv + dc * 64 + dt * 32);
+          if (val[t] && key < p.Nv && !(dbg & 1))
+            old[dt][t][it] = gb16 ? bf4_to_f4(*(const bf16x4*)(dvb + (long long)key * p.lddvb + dc * 64 + dt * 32)) : *(const f32x4*)(dvf + (long long)key * p.lddv + dc * 64 + dt * 32);
         }
     dma_wait_barrier();
     if (dc + 1 < g.NDC) stage4(dc + 1, st0 + ((dc + 1) & 1) * 16384);
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(FT, 1) void fusion_bwd_k(mart_fusion_bwd_desc p, in
           const int key = kt[t] * 32 + it * 8 + rrow;
           const f32x4 x = old[dt][t][it] + *(const f32x4*)(scr + (it * 8 + rrow) * 36 + rcol);
           if (key < p.Nv && !(dbg & 2)) {
-            *(f32x4*)(dvf + (long long)key * p.lddv + dcol) = x;
+            if (!gb16) *(f32x4*)(dvf + (long long)key * p.lddv + dcol) = x;
             if (dvb) *(bf16x4*)(dvb + (long long)key * p.lddvb + dcol) = f4_to_bf4(x);
           }
         }
@@ -467,15 +471,15 @@ extern "C" int mart_fusion_fwd(const mart_fusion_fwd_desc* d, void* stream) {
 }
 
 extern "C" int mart_fusion_bwd(const mart_fusion_bwd_desc* d, void* stream) {
-  MART_CHECK(d && d->q && d->v && d->dout && d->probs && d->dq && d->dv_f32 && d->B > 0, "fusion_bwd: bad args");
+  MART_CHECK(d && d->q && d->v && d->dout && d->probs && d->dq && (d->dv_f32 || d->dv_bf16) && d->B > 0, "fusion_bwd: bad args");
   const Plan pl = make_plan(d->Lq, d->Nv, d->H, true);
   MART_CHECK(pl.ok, "fusion_bwd: unsupported shape (mart_fusion_supported)");
-  MART_CHECK(d->ldq >= d->H && d->ldv >= d->H && d->lddo >= d->H && d->lddq >= d->H && d->lddv >= d->H && d->ldq % 8 == 0 && d->ldv % 8 == 0 && d->lddo % 8 == 0 &&
+  MART_CHECK(d->ldq >= d->H && d->ldv >= d->H && d->lddo >= d->H && d->lddq >= d->H && (!d->dv_f32 || d->lddv >= d->H) && d->ldq % 8 == 0 && d->ldv % 8 == 0 && d->lddo % 8 == 0 &&
              d->lddq % 4 == 0 && (!d->dv_bf16 || d->lddvb >= d->H), "fusion_bwd: row strides must cover H (ldq, ldv, lddo multiples of 8)");
   MART_CHECK(d->ldp >= d->Nv && d->ldp % 8 == 0 && d->ldp <= ((d->Nv + 63) / 64) * 64, "fusion_bwd: ldp must be a multiple of 8 in [Nv, 64 * ceil(Nv / 64)]");
   MART_CHECK(((uintptr_t)d->q | (uintptr_t)d->v | (uintptr_t)d->dout) % 16 == 0 && ((uintptr_t)d->dq | (uintptr_t)d->probs) % 8 == 0, "fusion_bwd: operands must be 16-byte aligned");
   // the vision-stream gradient is read and written as f32x4 (and its bf16 copy as bf16x4) at columns that are multiples of 4
-  MART_CHECK(d->lddv % 4 == 0 && (uintptr_t)d->dv_f32 % 16 == 0, "fusion_bwd: dv_f32 must be 16-byte aligned with lddv a multiple of 4");
+  MART_CHECK(!d->dv_f32 || (d->lddv % 4 == 0 && (uintptr_t)d->dv_f32 % 16 == 0), "fusion_bwd: dv_f32 must be 16-byte aligned with lddv a multiple of 4");
   MART_CHECK(!d->dv_bf16 || (d->lddvb % 4 == 0 && (uintptr_t)d->dv_bf16 % 8 == 0), "fusion_bwd: dv_bf16 must be 8-byte aligned with lddvb a multiple of 4");
   bool* once = g_attr_bwd.slot();
   if (!*once) {

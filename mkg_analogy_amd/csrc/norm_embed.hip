@@ -194,6 +194,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
         const long long o = (long long)m * p.H + (v * 64 + lane) * 4;
         r.add[v] = f32x4{0.f, 0.f, 0.f, 0.f}; r.dyf[v] = r.add[v]; r.dyh[v] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
         if (p.add_f32) r.add[v] = __builtin_nontemporal_load((const f32x4*)(p.add_f32 + o));
+        if (p.add_bf16) r.add[v] = bf4_to_f4(__builtin_nontemporal_load((const bf16x4*)((const bf16*)p.add_bf16 + o)));
         if (p.add2_f32) r.add[v] += __builtin_nontemporal_load((const f32x4*)(p.add2_f32 + o));
         if (p.dy_f32) r.dyf[v] = __builtin_nontemporal_load((const f32x4*)(p.dy_f32 + o));
         if (dyb) r.dyh[v] = __builtin_nontemporal_load((const bf16x4*)(dyb + o));
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
           if (p.p_drop > 0.f) dd = dd * dropout_scale4(p.seed, s2_lo, o, thr16, inv_keep);
           stx((bf16x4*)((bf16*)p.ds_bf16 + o), f4_to_bf4(dd), (LN_NT & 4) != 0);
         }
-        if (p.add_f32) ds += r.add[v];
+        if (p.add_f32 || p.add_bf16) ds += r.add[v];
         if (p.ds_f32) stx((f32x4*)(p.ds_f32 + o), ds, (LN_NT & 2) != 0);
         if (p.ds_bf16 && p.bf16_total) stx((bf16x4*)((bf16*)p.ds_bf16 + o), f4_to_bf4(ds), (LN_NT & 4) != 0);
       }
@@ -276,20 +277,25 @@ __global__ __launch_bounds__(TPB) void ln_bwd_k(mart_ln_bwd_desc p) {
 
 // vision-stream shape of the backward pass: dy bf16, x f32, residual gradient f32 in; f32 total + its bf16 copy out; dgamma / dbeta partials to the
 // workspace.  Straight-line and pipelined like ln_fwd_fast_k (rows past the end: clamped duplicates, weight 0 in dgamma / dbeta).
-template <int VMAX, bool ADD2 = false>     // ADD2: a second f32 residual operand (the fusion op's d(visual) side buffer, engine.backward)
-__global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ add, const float* __restrict__ mean_i,
+// GB16 (round 6): the residual GRADIENT stream lives in bf16 -- `add` is a bf16 tensor and only the bf16 total is written (no f32 copy): 10 bytes per element
+// instead of 16 (dy 2 + x 4 + add 2 in, 2 out against dy 2 + x 4 + add 4 in, 4 + 2 out).
+template <int VMAX, bool ADD2 = false, bool GB16 = false>     // ADD2: a second f32 residual operand (the fusion op's d(visual) side buffer, engine.backward)
+__global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy, const float* __restrict__ x, const void* __restrict__ add_, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, const float* __restrict__ gamma, int M, float* __restrict__ ds_f32, bf16* __restrict__ ds_bf16,
                                                      float* __restrict__ ws, const float* __restrict__ add2 = nullptr, int rev = 0) {
   constexpr int H = VMAX * 256;
+  static_assert(!(ADD2 && GB16), "the side-buffer operand belongs to the f32 gradient stream");
   __shared__ float red[WPB][2][VMAX * 256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int wave_g = blockIdx.x * WPB + w;
   const int nwaves = gridDim.x * WPB;
+  const float* add = (const float*)add_;
+  const bf16* addb = (const bf16*)add_;
   f32x4 dg[VMAX], db[VMAX], gam[VMAX];
 #pragma unroll
   for (int v = 0; v < VMAX; ++v) { dg[v] = f32x4{0.f, 0.f, 0.f, 0.f}; db[v] = dg[v]; gam[v] = *(const f32x4*)(gamma + (v * 64 + lane) * 4); }
   const int iters = (M + nwaves - 1) / nwaves;
-  struct Row { f32x4 a[VMAX], a2[ADD2 ? VMAX : 1], s[VMAX]; bf16x4 d[VMAX]; float mean, rstd; };
+  struct Row { f32x4 a[GB16 ? 1 : VMAX], a2[ADD2 ? VMAX : 1], s[VMAX]; bf16x4 d[VMAX], ab[GB16 ? VMAX : 1]; float mean, rstd; };
   auto row_of = [&](int k) { const int r = min(wave_g + k * nwaves, M - 1); return rev ? M - 1 - r : r; };     // rev: last row first (see ln_fwd_fast_k)
   auto fetch = [&](int k, Row& r) {
     const int m = row_of(k);
@@ -297,7 +303,8 @@ __global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy
     r.mean = mean_i[m]; r.rstd = rstd_i[m];
 #pragma unroll
     for (int v = 0; v < VMAX; ++v) {
-      r.a[v] = __builtin_nontemporal_load((const f32x4*)(add + o + v * 256));
+      if constexpr (GB16) r.ab[v] = __builtin_nontemporal_load((const bf16x4*)(addb + o + v * 256));
+      else r.a[v] = __builtin_nontemporal_load((const f32x4*)(add + o + v * 256));
       if constexpr (ADD2) r.a2[v] = __builtin_nontemporal_load((const f32x4*)(add2 + o + v * 256));
       r.d[v] = __builtin_nontemporal_load((const bf16x4*)(dy + o + v * 256));
       r.s[v] = __builtin_nontemporal_load((const f32x4*)(x + o + v * 256));
@@ -323,11 +330,12 @@ __global__ __launch_bounds__(TPB) void ln_bwd_fast_k(const bf16* __restrict__ dy
     const long long o = (long long)row_of(k) * H + lane * 4;
 #pragma unroll
     for (int v = 0; v < VMAX; ++v) {
-      f32x4 t;
+      f32x4 t, av;
+      if constexpr (GB16) av = bf4_to_f4(r.ab[v]); else av = r.a[v];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = r.rstd * (d[v][e] * gam[v][e] - c1 - xh[v][e] * c2) + r.a[v][e];
+      for (int e = 0; e < 4; ++e) t[e] = r.rstd * (d[v][e] * gam[v][e] - c1 - xh[v][e] * c2) + av[e];
       if constexpr (ADD2) t += r.a2[v];
-      __builtin_nontemporal_store(t, (f32x4*)(ds_f32 + o + v * 256));
+      if constexpr (!GB16) __builtin_nontemporal_store(t, (f32x4*)(ds_f32 + o + v * 256));
       *(bf16x4*)(ds_bf16 + o + v * 256) = f4_to_bf4(t);
     }
   };
@@ -849,6 +857,7 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   MART_CHECK(d->M > 0 && d->H % 256 == 0 && d->H <= 256 * VMAX_ALL, "ln_bwd: H must be a multiple of 256 and <= 1024");
   MART_CHECK(d->s && d->mean && d->rstd && d->gamma && (d->ds_f32 || d->ds_bf16), "ln_bwd: null pointer");
   MART_CHECK(!d->add2_f32 || d->add_f32, "ln_bwd: add2_f32 is a second residual operand (needs add_f32)");
+  MART_CHECK(!d->add_bf16 || (!d->add_f32 && !d->add2_f32), "ln_bwd: add_bf16 replaces add_f32 (the residual gradient stream in bf16)");
   MART_CHECK(!d->defer_reduce || d->ws, "ln_bwd: defer_reduce needs the workspace");
   int g = row_grid(d->M);
   // Two rows in flight per wave cost 206 VGPRs: two waves per SIMD, i.e. two 4-wave workgroups per CU -> grid = 512 is exactly ONE round
@@ -862,10 +871,17 @@ extern "C" int mart_ln_bwd(const mart_ln_bwd_desc* d, void* stream) {
   if (g > cap) g = cap;
   static const int revb = getenv("MART_LN_REV") ? (atoi(getenv("MART_LN_REV")) >> 1) & 1 : 0;
   MART_CHECK(!d->ws || d->ws_bytes >= (long long)g * 2 * d->H * (long long)sizeof(float), "ln_bwd: workspace too small (768 * 2 * H floats always suffice)");
-#define LNB_FAST(V_, A_) hipLaunchKernelGGL((ln_bwd_fast_k<V_, A_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws, d->add2_f32, revb)
-  if (fast_shape && d->H == 768) { if (d->add2_f32) LNB_FAST(3, true); else LNB_FAST(3, false); }
+  // the same shape with the residual gradient stream in bf16: bf16 residual operand in, bf16 total out, nothing else
+  const bool fast_gb16 = fastb && d->dy_bf16 && !d->dy_f32 && d->add_bf16 && !d->ds_f32 && d->ds_bf16 && d->bf16_total && d->p_drop == 0.f && d->ws && d->dgamma && d->dbeta &&
+                         (d->H == 768 || d->H == 1024) && d->M >= 4096 && d->add_bf16 != d->ds_bf16 && d->dy_bf16 != d->ds_bf16;
+#define LNB_FAST(V_, A_) hipLaunchKernelGGL((ln_bwd_fast_k<V_, A_>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, (const void*)d->add_f32, d->mean, d->rstd, d->gamma, d->M, d->ds_f32, (bf16*)d->ds_bf16, d->ws, d->add2_f32, revb)
+#define LNB_FAST16(V_) hipLaunchKernelGGL((ln_bwd_fast_k<V_, false, true>), dim3(g), dim3(TPB), 0, (hipStream_t)stream, (const bf16*)d->dy_bf16, d->s, d->add_bf16, d->mean, d->rstd, d->gamma, d->M, (float*)nullptr, (bf16*)d->ds_bf16, d->ws, (const float*)nullptr, revb)
+  if (fast_gb16 && d->H == 768) LNB_FAST16(3);
+  else if (fast_gb16) LNB_FAST16(4);
+  else if (fast_shape && d->H == 768) { if (d->add2_f32) LNB_FAST(3, true); else LNB_FAST(3, false); }
   else if (fast_shape) { if (d->add2_f32) LNB_FAST(4, true); else LNB_FAST(4, false); }
 #undef LNB_FAST
+#undef LNB_FAST16
   else if (d->H <= 768) hipLaunchKernelGGL(ln_bwd_k<3>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   else hipLaunchKernelGGL(ln_bwd_k<4>, dim3(g), dim3(TPB), 0, (hipStream_t)stream, *d);
   MART_LAUNCH_CHECK();

@@ -112,6 +112,13 @@ class UnimoEngine:
         # queue by more than one layer (joined at the end of the pass).  Same kernels, same operands, bit-identical gradients; 85.2 -> 84.1 ms per step at
         # 196 patches (three alternations, profiles/r05_wgrad_lag_ab.txt), neutral at 49.  MART_WGRAD_LAG=0: the per-layer join of rounds 1-4.
         self.wgrad_lag = os.environ.get("MART_WGRAD_LAG", "1") == "1"
+        # grad_stream_bf16 (round 6): the gradient w.r.t. the VISION residual stream is carried in bf16 between layers instead of f32 + a bf16 copy.  Every
+        # consumer of that stream already read the bf16 copy (data- and weight-gradient GEMMs); the f32 tensor only fed the next LayerNorm backward's
+        # residual add and the fusion op's in-place accumulation.  Those now read / update the bf16 tensor (f32 arithmetic, one rounding per half layer):
+        # the vision LayerNorm backward moves 10 bytes per element instead of 16, the fusion backward's read-modify-write 4 instead of 10.  Measured on the
+        # reference golden G7 (emulation on the f32 path, tests/test_parity_full_gpu.py): worst gradient-norm deviation unchanged (7.8e-3 over 431 tensors),
+        # worst sampled rel-L2 1.33e-2 -> 1.49e-2 -- the bf16 GEMM operands dominate.  The forward residual streams stay f32.  MART_GRAD_STREAM_BF16=0: f32.
+        self.grad_stream_bf16 = os.environ.get("MART_GRAD_STREAM_BF16", "1") == "1"
 
     # ------------------------------------------------------------------ helpers
     def _lin(self, name):
@@ -602,8 +609,15 @@ class UnimoEngine:
             self._join(); self._text_done(); self._text_begin()
         notify(st.slots["unimo.encoder.text_layer.%d.attention.self.query.weight" % (self.n_layers - 1)].offset)
 
-        dxv = torch.zeros((Mv, H), device=dev, dtype=F32)             # gradient w.r.t. the vision stream
-        dxvb = _e((Mv, H), BF, dev)
+        # gradient w.r.t. the vision stream: bf16 only (grad_stream_bf16; needs the fused fusion kernels in every fusion layer and none of the debugging
+        # hooks / the side-buffer schedule, which work on the f32 tensor), or f32 + its bf16 copy
+        gb16 = (self.grad_stream_bf16 and self.taps is None and self.inject_grad is None and not self.fusion_side and
+                all(sv[f"t{l}"]["fus"] is None or sv[f"t{l}"]["visT"] is None for l in range(self.n_layers)))
+        if gb16:
+            dxv, dxvb = None, torch.zeros((Mv, H), device=dev, dtype=BF)
+        else:
+            dxv = torch.zeros((Mv, H), device=dev, dtype=F32)
+            dxvb = _e((Mv, H), BF, dev)
         ev_vdone = self._main_record()                                # dxv / dxvb exist
         ev_vattn = None
         # d(visual) of the fusion op of text layer l (l = 8 .. 10) through a SIDE buffer: fusion_bwd used to accumulate into dxv in place, i.e. it
@@ -613,7 +627,7 @@ class UnimoEngine:
         # residual operand (+25 % bytes in one HBM-bound launch).  The top layer keeps the in-place form (its dxv is the zero buffer above).
         side_mode = (self.fusion_side and self._tstream is not None and self.inject_grad is None and self.taps is None and
                      self.fused_fusion and ops.fusion_supported(Lq, Nv, H))
-        T = dict(d_f32=d_f32, d_b16=d_b16, ev_tfus={}, A={}, A_side={}, fresh=False)
+        T = dict(d_f32=d_f32, d_b16=d_b16, ev_tfus={}, A={}, A_side={}, fresh=False, dxvb=dxvb)
 
         def will_side(l):
             t_ = sv.get(f"t{l}") if l >= 0 else None
@@ -660,7 +674,7 @@ class UnimoEngine:
                             ops.fusion_bwd(s["ctx"], s["visb"], dfus, s["probs"], dctx_fus, side, None, B, Lq, Nv, H)
                         else:
                             self._text_wait(T["ev_vdone"])                         # dxv holds the gradient left by vision layer l+1
-                            ops.fusion_bwd(s["ctx"], s["visb"], dfus, s["probs"], dctx_fus, dxv, dxvb, B, Lq, Nv, H)   # d(vis) added in place, bf16 copy refreshed
+                            ops.fusion_bwd(s["ctx"], s["visb"], dfus, s["probs"], dctx_fus, dxv, T["dxvb"], B, Lq, Nv, H)   # d(vis) added in place (f32 stream: bf16 copy refreshed; bf16 stream: dxv is None)
                             T["fresh"] = True
                     else:
                         dprobs = _e((Mt, Nvp), F32, dev)
@@ -778,7 +792,7 @@ class UnimoEngine:
                 dxv.copy_(self.inject_grad[f"vis{l}"].reshape(Mv, H))
                 dxvb_fresh = False
                 ops.add_f32_bf16(dxv, None, None, dxvb)
-            elif (l >= self.fuse_from or l == self.n_layers - 1) and not dxvb_fresh:   # fusion of text layer l added d(vis) into dxv
+            elif not gb16 and (l >= self.fuse_from or l == self.n_layers - 1) and not dxvb_fresh:   # fusion of text layer l added d(vis) into dxv
                 ops.add_f32_bf16(dxv, None, None, dxvb)                # -> refresh the bf16 copy (otherwise ln1 bwd wrote it)
             self._wgrad(dxvb, s["f"], v + "mlp.fc2.weight", v + "mlp.fc2.bias")
             dz = _e((Mv, I), BF, dev)
@@ -787,8 +801,9 @@ class UnimoEngine:
             dh2 = _e((Mv, H), BF, dev)
             ops.gemm_nt(dz, st.wt(f"v{l}.fc1"), dh2)
             del dz
-            dx1, dx1b = _e((Mv, H), F32, dev), _e((Mv, H), BF, dev)
-            self._ln_bwd(dy_bf16=dh2, s=s["x1"], mean=s["m2"], rstd=s["r2"], gamma=st.m(v + "layer_norm2.weight"), M=Mv, H=H, add_f32=dxv,
+            dx1, dx1b = (None if gb16 else _e((Mv, H), F32, dev)), _e((Mv, H), BF, dev)
+            self._ln_bwd(dy_bf16=dh2, s=s["x1"], mean=s["m2"], rstd=s["r2"], gamma=st.m(v + "layer_norm2.weight"), M=Mv, H=H,
+                       add_f32=dxv, add_bf16=dxvb if gb16 else None,
                        ds_f32=dx1, ds_bf16=dx1b, bf16_total=True, dgamma=st.g(v + "layer_norm2.weight"), dbeta=st.g(v + "layer_norm2.bias"))
             self._wgrad(dx1b, s["ctx"], v + "self_attn.out_proj.weight", v + "self_attn.out_proj.bias")
             dctx = dh2                                                 # reuse
@@ -829,8 +844,9 @@ class UnimoEngine:
             else:
                 self._join()                                           # dxvb (read by the fc2 weight-gradient GEMM) is rewritten next
             self._ln_bwd(dy_bf16=dh1, s=s["x"], mean=s["m1"], rstd=s["r1"], gamma=st.m(v + "layer_norm1.weight"), M=Mv, H=H, add_f32=dx1,
-                       add2_f32=side_next, ds_f32=dxv, ds_bf16=dxvb, bf16_total=True, dgamma=st.g(v + "layer_norm1.weight"),
-                       dbeta=st.g(v + "layer_norm1.bias"))
+                       add_bf16=dx1b if gb16 else None, add2_f32=side_next, ds_f32=dxv, ds_bf16=dxvb, bf16_total=True,
+                       dgamma=st.g(v + "layer_norm1.weight"), dbeta=st.g(v + "layer_norm1.bias"))
+            T["dxvb"] = dxvb                                           # (a fresh buffer under wgrad_lag: what text layer l - 1's fusion backward updates)
             if early:
                 T["A_side"][l - 1] = True                              # consumed: keep the "a side buffer existed" mark, drop the [Mv, H] f32 tensor
                 del side_next
@@ -847,7 +863,7 @@ class UnimoEngine:
         # ---- vision embeddings backward: pre-LN -> assemble -> patch GEMM weight gradient
         patches, s_v, vmean, vrstd = sv["vemb"]
         dsv = _e((Mv, H), F32, dev)
-        self._ln_bwd(dy_f32=dxv, s=s_v, mean=vmean, rstd=vrstd, gamma=st.m("unimo.vision_pre_layrnorm.weight"), M=Mv, H=H, ds_f32=dsv,
+        self._ln_bwd(dy_f32=dxv, dy_bf16=dxvb if gb16 else None, s=s_v, mean=vmean, rstd=vrstd, gamma=st.m("unimo.vision_pre_layrnorm.weight"), M=Mv, H=H, ds_f32=dsv,
                    dgamma=st.g("unimo.vision_pre_layrnorm.weight"), dbeta=st.g("unimo.vision_pre_layrnorm.bias"))
         dpe = _e((B * 2 * P, H), BF, dev)
         ops.vision_assemble_bwd(dsv, dpe, st.g("unimo.vision_embeddings.class_embedding"), st.g("unimo.vision_embeddings.position_embedding.weight"),

@@ -117,11 +117,11 @@ def ln_fwd(*, x_f32=None, y_bf16=None, y_f32=None, gamma, beta, eps, M, H, mean,
 
 
 def ln_bwd(*, dy_f32=None, dy_bf16=None, s, mean, rstd, gamma, M, H, add_f32=None, ds_f32=None, ds_bf16=None,
-           p_drop=0.0, seed=0, dgamma=None, dbeta=None, bf16_total=False, add2_f32=None, defer_reduce=False):
+           p_drop=0.0, seed=0, dgamma=None, dbeta=None, bf16_total=False, add2_f32=None, defer_reduce=False, add_bf16=None):
     """LayerNorm backward.  ``defer_reduce`` (deterministic path only): the dgamma / dbeta partials stay in the returned workspace and the caller
     adds them with :func:`ln_dgb_reduce` (same kernel, same order) -- e.g. on the weight-gradient stream; returns ``(ws, partials)`` then."""
     d = L.LnBwd()
-    d.add2_f32 = _p(add2_f32)
+    d.add2_f32, d.add_bf16 = _p(add2_f32), _p(add_bf16)
     d.dy_f32, d.dy_bf16, d.s, d.mean, d.rstd, d.gamma = _p(dy_f32), _p(dy_bf16), _p(s), _p(mean), _p(rstd), _p(gamma)
     d.add_f32, d.M, d.H, d.ds_f32, d.ds_bf16 = _p(add_f32), M, H, _p(ds_f32), _p(ds_bf16)
     d.p_drop, d.seed, d.dgamma, d.dbeta = p_drop, seed, _p(dgamma), _p(dbeta)
@@ -342,7 +342,7 @@ def fusion_fwd(q, v, out, probs, B, Lq, Nv, H, out_f16=None):
 def fusion_bwd(q, v, dout, probs, dq, dv_f32, dv_bf16, B, Lq, Nv, H):
     d = L.FusionBwd()
     d.q, d.ldq, d.v, d.ldv, d.dout, d.lddo, d.probs, d.ldp = _p(q), _rows2d(q), _p(v), _rows2d(v), _p(dout), _rows2d(dout), _p(probs), _rows2d(probs)
-    d.dq, d.lddq, d.dv_f32, d.lddv = _p(dq), _rows2d(dq), _p(dv_f32), _rows2d(dv_f32)
+    d.dq, d.lddq, d.dv_f32, d.lddv = _p(dq), _rows2d(dq), _p(dv_f32), (_rows2d(dv_f32) if dv_f32 is not None else 0)
     d.dv_bf16, d.lddvb = _p(dv_bf16), (_rows2d(dv_bf16) if dv_bf16 is not None else 0)
     d.B, d.Lq, d.Nv, d.H = B, Lq, Nv, H
     L.check(L.lib().mart_fusion_bwd(C.byref(d), _stream()), "mart_fusion_bwd")

@@ -54,6 +54,16 @@ def test_fusion_kernels_match_fp32_reference(B, Lq, Nv):
     dq2, dv2 = torch.empty_like(dq), base.clone()
     ops.fusion_bwd(q, v, dout, probs, dq2, dv2, None, B, Lq, Nv, H)
     assert torch.equal(dq, dq2) and torch.equal(dv, dv2)
+    # round 6: the vision-stream gradient carried in bf16 -- the read-modify-write goes to the bf16 tensor alone (dv_f32 = None)
+    dq3 = torch.empty_like(dq)
+    dvb3 = base.to(torch.bfloat16)
+    ops.fusion_bwd(q, v, dout, probs, dq3, None, dvb3, B, Lq, Nv, H)
+    assert torch.equal(dq3, dq)
+    want = (base.to(torch.bfloat16).float() + (dv - base)).to(torch.bfloat16)        # bf16(old bf16 value + the f32 update), one rounding per 64-query block
+    diff = (dvb3.float() - want.float()).abs()
+    upd = (dv - base).abs()
+    tol = 2.0 ** -7 * (base.abs() + upd) + (2.0 ** -8 * float(upd.max()) if Lq > 64 else 0.0) + 2e-3   # (64-query blocks are sequential launches: Lq > 64 rounds twice, at the magnitude of the intermediate sum)
+    assert bool((diff <= tol).all()), float((diff - tol).max())
 
 
 def test_fusion_shape_gate():

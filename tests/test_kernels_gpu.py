@@ -365,6 +365,18 @@ def test_layernorm_vision_stream_shapes(ops, M):
     dg3, db3, ds3, dsb3 = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV), torch.empty_like(ds), torch.empty_like(dsb)
     ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_f32=add, ds_f32=ds3, ds_bf16=dsb3, bf16_total=True, dgamma=dg3, dbeta=db3)
     assert torch.equal(dg, dg3) and torch.equal(db, db3) and torch.equal(ds, ds3) and torch.equal(dsb, dsb3), "run-to-run"
+    # round 6: the residual GRADIENT stream in bf16 -- bf16 residual operand in, bf16 total out, no f32 tensor (ln_bwd_fast_k<., ., GB16>); == the f32-stream
+    # kernel fed the same (bf16-valued) residual operand, bit for bit, and the general kernel takes the operand too (small M / an f32 output requested)
+    addb = add.to(BF)
+    dsb4, dg4, db4 = torch.empty_like(dsb), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_bf16=addb, ds_bf16=dsb4, bf16_total=True, dgamma=dg4, dbeta=db4)
+    ds5, dsb5, dg5, db5 = torch.empty_like(ds), torch.empty_like(dsb), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_f32=addb.float(), ds_f32=ds5, ds_bf16=dsb5, bf16_total=True, dgamma=dg5, dbeta=db5)
+    assert torch.equal(dsb4, dsb5) and torch.equal(dg4, dg5) and torch.equal(db4, db5)
+    close(dsb4, xr.grad + addb.float(), 2e-2, 1e-2, "bf16 gradient stream: total")
+    ds6, dg6, db6 = torch.empty_like(ds), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_bf16=addb, ds_f32=ds6, dgamma=dg6, dbeta=db6)       # general kernel
+    close(ds6, ds5, 1e-5, 1e-5, "general kernel with a bf16 residual operand")
 
 
 def test_layernorm_reversed_sweep_knob():
