@@ -372,7 +372,14 @@ def test_layernorm_vision_stream_shapes(ops, M):
     ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_bf16=addb, ds_bf16=dsb4, bf16_total=True, dgamma=dg4, dbeta=db4)
     ds5, dsb5, dg5, db5 = torch.empty_like(ds), torch.empty_like(dsb), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
     ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_f32=addb.float(), ds_f32=ds5, ds_bf16=dsb5, bf16_total=True, dgamma=dg5, dbeta=db5)
-    assert torch.equal(dsb4, dsb5) and torch.equal(dg4, dg5) and torch.equal(db4, db5)
+    # (the bf16-stream kernel owns 8 consecutive columns per lane -- 16-byte accesses -- so its row sums are taken in another order: the totals agree to a
+    # rounding of the bf16 result, the column sums bit for bit where the order is the same)
+    close(dsb4, dsb5, 2e-2, 1e-2, "bf16 gradient stream vs the f32-stream kernel on the same operands")
+    assert float((dsb4.float() - dsb5.float()).abs().max()) <= 2.0 ** -6 * float(dsb5.float().abs().max())
+    close(dg4, dg5, 1e-4, 1e-4, "dgamma, bf16 stream"); close(db4, db5, 1e-4, 1e-4, "dbeta, bf16 stream")
+    dsb7, dg7, db7 = torch.empty_like(dsb), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_bf16=addb, ds_bf16=dsb7, bf16_total=True, dgamma=dg7, dbeta=db7)
+    assert torch.equal(dsb4, dsb7) and torch.equal(dg4, dg7) and torch.equal(db4, db7), "run-to-run"
     close(dsb4, xr.grad + addb.float(), 2e-2, 1e-2, "bf16 gradient stream: total")
     ds6, dg6, db6 = torch.empty_like(ds), torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
     ops.ln_bwd(dy_bf16=dyb, s=x, mean=mean, rstd=rstd, gamma=gamma, M=M, H=H, add_bf16=addb, ds_f32=ds6, dgamma=dg6, dbeta=db6)       # general kernel
