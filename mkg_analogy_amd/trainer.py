@@ -3,6 +3,7 @@ drives TransformerLitModel's hooks (training_step / validation_step / *_epoch_en
 steps the scheduler every batch (interval 'step'), averages gradients across ranks when launched under torchrun."""
 from __future__ import annotations
 
+import os
 import time
 from typing import Dict, Iterable, List, Optional
 
@@ -25,6 +26,7 @@ class Trainer:
         self.stream_optimizer = os.environ.get("MART_STREAM_OPT", "1") == "1"   # AdamW ranges launched under the backward pass
         self.num_train_batches = 0
         self.global_step = 0
+        self._steps_seen = 0
         self.history: List[Dict[str, float]] = []
 
     def _setup(self, lit, train_batches):
@@ -82,7 +84,30 @@ class Trainer:
             self.global_step += 1
             if self.sync.reducer is not None:
                 eng.grad_ready_async = self.sync.reducer.ready
+        self._steps_seen += 1
+        if self._steps_seen == 3:
+            self._pool_headroom()
         return loss.detach()
+
+    @staticmethod
+    def _pool_headroom() -> None:
+        """Once, after the third step (both in-flight steps have their buffers by then): reserve MART_POOL_HEADROOM (default 10 %) more device
+        memory and hand it straight back to the caching allocator.  A block that a side queue touched returns to the pool only when that queue has
+        passed the free (record_stream), so now and then a request finds its size class still pending and the pool grows by one hipMalloc -- about
+        once per step for the next 25 steps (78.3 -> 82.4 GiB at B = 256; tools/alloc_trace.py, profiles/r06_alloc_trace.txt).  With the slab cached
+        those requests are carved from it and the steady state starts here instead."""
+        frac = float(os.environ.get("MART_POOL_HEADROOM", "0.10"))
+        if frac <= 0 or not torch.cuda.is_available():
+            return
+        want = int(frac * torch.cuda.memory_reserved())
+        free, _ = torch.cuda.mem_get_info()
+        if want < (64 << 20) or want > free // 2:
+            return
+        try:
+            slab = torch.empty(want, dtype=torch.uint8, device="cuda")
+            del slab
+        except torch.cuda.OutOfMemoryError:
+            pass
 
     def fit(self, lit, train_batches: Iterable, val_batches: Optional[Iterable] = None):
         train_batches = list(train_batches) if not hasattr(train_batches, "__len__") else train_batches
