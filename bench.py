@@ -351,13 +351,14 @@ def device_allocs() -> int:
 def timed_leg(tr, lit, batch, n_warm: int, n_steps: int, barrier, first_idx: int = 0):
     """``n_warm`` untimed + ``n_steps`` timed training steps of an already set-up trainer; seconds of the timed part
     (``timed_leg.allocs``: device allocations inside it)."""
+    seq = batch if isinstance(batch, (list, tuple)) else [batch]      # (a list: one batch after the other, round robin)
     for i in range(n_warm):
-        tr.train_step(lit, batch, first_idx + i)
+        tr.train_step(lit, seq[i % len(seq)], first_idx + i)
     barrier()
     n0 = device_allocs()
     t1 = time.perf_counter()
     for i in range(n_steps):
-        tr.train_step(lit, batch, first_idx + n_warm + i)
+        tr.train_step(lit, seq[(n_warm + i) % len(seq)], first_idx + n_warm + i)
     barrier()
     dt = time.perf_counter() - t1
     timed_leg.allocs = device_allocs() - n0
@@ -635,6 +636,18 @@ def main():
                 "patches_per_image": 49, "vision_tokens": 99, "steps": 5, "warmup": 4, "ms_per_step": round(1000.0 * d5 / 5, 3), "value": round(v5, 2),
                 "train_gflop_per_example": round(gf5, 1), "step_frac_of_mfma_peak": round(v5 * gf5 / 2.5e6, 4),
                 "roofline_examples_per_s": round(2.5e6 / gf5, 1), "device_allocs_in_timed_region": timed_leg.allocs}
+        # ... and the same network on batches padded as the reference's collate pads them (data_module.py:113-119: to the longest example of the batch;
+        # MARS examples are 40 .. 57 tokens): the length changes from step to step, no kernel or buffer is specialised on it (tools/var_len.py:
+        # 60-step runs, profiles/r06_var_len.txt).
+        import random
+        rng_ = random.Random(0)
+        lens_ = [rng_.randint(40, 57) for _ in range(14)]
+        seq_ = [D.make_batch(a.batch, L_, seed=4321 + i, device=dev, pretrain=False, n_labels=head) for i, L_ in enumerate(lens_)]
+        d10 = timed_leg(tr2, lit2, seq_, 4, 10, barrier, first_idx=9)
+        altg["real_lengths"] = {"what": "padded length drawn from 40 .. 57 per batch (the reference pads a batch to its longest example)", "seq_lens_timed": lens_[4:],
+                                "steps": 10, "warmup": 4, "ms_per_step": round(1000.0 * d10 / 10, 3), "value": round(a.batch * 10 / d10, 2), "unit": "examples/s",
+                                "device_allocs_in_timed_region": timed_leg.allocs}
+        del seq_
     altt = altm = alts = None
     if world == 1 and a.model == "mkgformer" and not pre and a.patch == 16 and not a.no_kernel_timing and not a.train_only:
         # BASELINE configs[4] and configs[3] on the driver's box, briefly (4 warm-up + 5 timed steps each: the second in-flight step's buffers are allocated in step 2, the pool headroom after step 3): the MarKG pre-train step (L = 96, LSCE over the

@@ -432,6 +432,44 @@ def test_gradients_are_run_to_run_identical():
         assert not differ, (mode, differ[:10])
 
 
+def test_changing_batch_shapes_leave_no_stale_state():
+    """The reference pads every batch to its own longest example (data_module.py:113-119), so consecutive steps see different (B, L).  A pass on
+    one shape, then passes on others, then the first shape again: loss, [MASK] logits and every gradient of the repeated pass are BIT-IDENTICAL
+    to the first one, in eval and in train mode (same dropout step) -- nothing cached per shape (row bookkeeping, [MASK] positions, operand
+    twins, kernel plans, workspaces) survives into a pass it does not belong to.  And a model that has only ever seen the second shape agrees
+    with the one that saw it between two others."""
+    from mkg_analogy_amd import data_synth as D
+    model, lit, cfg, vc = _product(32, seed=13, conditioned=True)
+    fresh, lit_f, _, _ = _product(32, seed=13, conditioned=True)
+    shapes = [(8, 64), (5, 37), (8, 57), (3, 44), (8, 64), (5, 37)]
+    batches = {sh: D.make_batch(sh[0], sh[1], seed=60 + sh[1], device="cuda") for sh in set(shapes)}
+    st = model.store
+
+    def one(m, l, gb, mode):
+        getattr(m, mode)()
+        m._step = 7
+        m.store.zero_grad()
+        loss = l.training_step(dict(gb), 1)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), m.store.grad.clone()
+
+    for mode in ("eval", "train"):
+        seen = {}
+        for sh in shapes:
+            got = one(model, lit, batches[sh], mode)
+            assert np.isfinite(got[0]), (mode, sh)
+            if sh in seen:
+                assert got[0] == seen[sh][0], (mode, sh, got[0], seen[sh][0])
+                differ = [n for n, sl in st.slots.items()
+                          if not torch.equal(got[1][sl.offset:sl.offset + sl.numel], seen[sh][1][sl.offset:sl.offset + sl.numel])]
+                assert not differ, (mode, sh, differ[:10])
+            seen[sh] = got
+        ref = one(fresh, lit_f, batches[(5, 37)], mode)
+        assert ref[0] == seen[(5, 37)][0], (mode, ref[0], seen[(5, 37)][0])
+        assert torch.equal(ref[1], seen[(5, 37)][1]), mode
+
+
 def test_fused_fusion_kernels_equal_the_general_path_in_the_model():
     """BertFusion through mart_fusion_fwd / mart_fusion_bwd (one kernel per direction) against the GEMM / softmax / transpose launches
     they replace, inside the full model (P=196: 393 vision tokens, L=64): same logits and gradients up to the bf16 rounding of
