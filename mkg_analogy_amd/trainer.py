@@ -91,23 +91,41 @@ class Trainer:
 
     @staticmethod
     def _pool_headroom() -> None:
-        """Once, after the third step (both in-flight steps have their buffers by then): reserve MART_POOL_HEADROOM (default 10 %) more device
-        memory and hand it straight back to the caching allocator.  A block that a side queue touched returns to the pool only when that queue has
-        passed the free (record_stream), so now and then a request finds its size class still pending and the pool grows by one hipMalloc -- about
-        once per step for the next 25 steps (78.3 -> 82.4 GiB at B = 256; tools/alloc_trace.py, profiles/r06_alloc_trace.txt).  With the slab cached
-        those requests are carved from it and the steady state starts here instead."""
+        """Once, after the third step: bring the caching allocator's pool to what two steps in flight need -- 2.25 x the peak of live
+        bytes (two steps plus fragmentation; timing-independent), or MART_POOL_HEADROOM (default 10 %) above what is reserved, whichever is larger --
+        with one allocation per stream that is handed straight back.  A block that a side queue touched returns to the pool only when that queue has passed the free (record_stream), so the pool
+        of a host that runs ahead holds two steps' worth of buffers plus whatever size classes happened to be pending when they were asked for:
+        without this it grows by a hipMalloc about once per step for 25 steps (78.3 -> 82.4 GiB at B = 256), and when the first steps ran with the
+        host NOT ahead (a cold process: libraries paging in) the whole second step's worth (32 GiB, ~140 allocations) is allocated later, in
+        whatever steps are being timed (tools/alloc_trace.py, profiles/r06_alloc_trace.txt).  With the slab cached those requests are carved from it."""
         frac = float(os.environ.get("MART_POOL_HEADROOM", "0.10"))
         if frac <= 0 or not torch.cuda.is_available():
             return
-        want = int(frac * torch.cuda.memory_reserved())
-        free, _ = torch.cuda.mem_get_info()
-        if want < (64 << 20) or want > free // 2:
+        # the allocator keeps one pool per stream (a block serves only the stream it was allocated on): the deficit is split over the streams in
+        # proportion to what each has reserved so far, and each share is allocated -- and freed -- on its own stream
+        dev = torch.cuda.current_device()
+        by_stream = {}
+        for seg in torch.cuda.memory_snapshot():
+            if seg.get("device", dev) == dev:
+                by_stream[seg["stream"]] = by_stream.get(seg["stream"], 0) + seg["total_size"]
+        reserved = sum(by_stream.values())
+        if reserved <= 0:
             return
-        try:
-            slab = torch.empty(want, dtype=torch.uint8, device="cuda")
-            del slab
-        except torch.cuda.OutOfMemoryError:
-            pass
+        deficit = max(2.25 * torch.cuda.max_memory_allocated(), (1.0 + frac) * reserved) - reserved
+        free, _ = torch.cuda.mem_get_info()
+        if deficit > free // 2:
+            return
+        for ptr, r in by_stream.items():
+            want = int(deficit * r / reserved)
+            if want < (32 << 20):
+                continue
+            stream = torch.cuda.ExternalStream(ptr) if ptr else torch.cuda.default_stream()
+            try:
+                with torch.cuda.stream(stream):
+                    slab = torch.empty(want, dtype=torch.uint8, device="cuda")
+                    del slab
+            except torch.cuda.OutOfMemoryError:
+                return
 
     def fit(self, lit, train_batches: Iterable, val_batches: Optional[Iterable] = None):
         train_batches = list(train_batches) if not hasattr(train_batches, "__len__") else train_batches

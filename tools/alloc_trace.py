@@ -19,8 +19,8 @@ prev = torch.cuda.memory_stats()
 for i in range(steps):
     t0 = time.perf_counter()
     tr.train_step(lit, batch, i)
-    if os.environ.get("SYNC_EACH", "0") == "1":
-        torch.cuda.synchronize()
+    if os.environ.get("SYNC_EACH", "0") == "1" or i < int(os.environ.get("SYNC_FIRST", "0")):
+        torch.cuda.synchronize()                                   # SYNC_FIRST=3: a cold process, whose first steps run with the host not ahead
     st = torch.cuda.memory_stats()
     print(f"step {i:3d}  host {1e3 * (time.perf_counter() - t0):7.2f} ms  device_alloc +{st['num_device_alloc'] - prev['num_device_alloc']:3d}  free +{st['num_device_free'] - prev['num_device_free']:3d}  "
           f"reserved {st['reserved_bytes.all.current'] / 2**30:7.2f} GiB  active {st['active_bytes.all.current'] / 2**30:7.2f} GiB  "
