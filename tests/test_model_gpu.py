@@ -1,6 +1,7 @@
 """End-to-end parity of the HIP MKGformer path (bf16 compute) against the CPU oracle (fp32), real dimensions.
 Tolerances follow BASELINE.json north_star: logits within 1e-2 (bf16); ranks exact where the margin exceeds it."""
 import argparse
+import os
 import math
 
 import numpy as np
@@ -376,6 +377,50 @@ def test_unsynchronised_steps_do_not_grow_memory():
     r1 = torch.cuda.memory_reserved()
     print(f"\nreserved after 6 steps {r0 / 2**30:.2f} GiB, after 66 steps {r1 / 2**30:.2f} GiB")
     assert r1 <= 1.5 * r0 + (1 << 30)
+
+
+def test_pool_headroom_stops_allocator_growth():
+    """Trainer._pool_headroom: after the third step the caching allocator's pool holds what two steps in flight need, on every stream pool -- the steps
+    that follow make (next to) no device allocation, also when the first three ran with the host NOT ahead of the GPU (a cold process; emulated with a
+    synchronize after each), the case in which the whole second in-flight step's buffers (~140 allocations at B = 256) used to be allocated later, inside
+    whatever steps were being timed.  Without the headroom (MART_POOL_HEADROOM=0) the same loop allocates several dozen times."""
+    import bench
+    from mkg_analogy_amd import data_synth as D
+    from mkg_analogy_amd.trainer import Trainer
+    dev = torch.device("cuda", 0)
+
+    def run(headroom):
+        old = os.environ.get("MART_POOL_HEADROOM")
+        os.environ["MART_POOL_HEADROOM"] = headroom
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            model, lit, cfg = bench.build(32, seed=0, device=dev, backbone="mkgformer")
+            batch = D.make_batch(256, 64, seed=99, device=dev)      # (B = 256: a 33 ms step, so that the host does run ahead of the GPU)
+            tr = Trainer(max_epochs=1, max_steps=1000, world_size=1)
+            tr._setup(lit, [None] * 1000)
+            for i in range(3):
+                tr.train_step(lit, batch, i)
+                torch.cuda.synchronize()
+            n0 = torch.cuda.memory_stats()["num_device_alloc"]
+            for i in range(10):
+                tr.train_step(lit, batch, 3 + i)
+            torch.cuda.synchronize()
+            return torch.cuda.memory_stats()["num_device_alloc"] - n0
+        finally:
+            model = lit = tr = batch = None
+            import gc
+            gc.collect()
+            if old is None:
+                os.environ.pop("MART_POOL_HEADROOM", None)
+            else:
+                os.environ["MART_POOL_HEADROOM"] = old
+
+    without, with_ = run("0"), run("0.10")
+    print(f"\ndevice allocations in 10 un-synchronised steps after a cold start: {without} without the headroom, {with_} with it")
+    assert with_ <= 3, with_
+    assert without >= 20, without          # (the situation the headroom exists for is the one this test sets up)
 
 
 def test_streamed_adamw_equals_one_shot():
