@@ -354,6 +354,7 @@ def timed_leg(tr, lit, batch, n_warm: int, n_steps: int, barrier, first_idx: int
     seq = batch if isinstance(batch, (list, tuple)) else [batch]      # (a list: one batch after the other, round robin)
     for i in range(n_warm):
         tr.train_step(lit, seq[i % len(seq)], first_idx + i)
+    tr.settle_pool()                                                  # (fewer than three warm-up steps: the pool headroom now, not inside the timed steps)
     barrier()
     n0 = device_allocs()
     t1 = time.perf_counter()
@@ -435,6 +436,7 @@ def main():
     loss = None
     for i in range(a.warmup):
         loss = tr.train_step(lit, batch, i)
+    tr.settle_pool()                                 # (--warmup < 3: the allocator's pool headroom now, not inside the timed steps)
     barrier()
     allocs0 = device_allocs()
     with PowerSampler(local) as psamp:               # (helper thread; rank 0 reports it)

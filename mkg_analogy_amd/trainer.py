@@ -89,6 +89,12 @@ class Trainer:
             self._pool_headroom()
         return loss.detach()
 
+    def settle_pool(self) -> None:
+        """For a caller that is about to time steps after fewer than three warm-up steps: apply the pool headroom now instead of inside its timed region."""
+        if self._steps_seen < 3:
+            self._pool_headroom()
+            self._steps_seen = 3
+
     @staticmethod
     def _pool_headroom() -> None:
         """Once, after the third step: bring the caching allocator's pool to what two steps in flight need -- 2.25 x the peak of live
