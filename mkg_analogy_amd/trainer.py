@@ -27,6 +27,7 @@ class Trainer:
         self.num_train_batches = 0
         self.global_step = 0
         self._steps_seen = 0
+        self._live_peak = 0                                            # live device bytes at the end of a forward pass (first three steps)
         self.history: List[Dict[str, float]] = []
 
     def _setup(self, lit, train_batches):
@@ -76,6 +77,8 @@ class Trainer:
             eng.grad_ready = None
             eng.grad_ready_async = None
         loss = lit.training_step(dict(batch), batch_idx)
+        if self._steps_seen < 3 and loss.is_cuda:
+            self._live_peak = max(self._live_peak, torch.cuda.memory_allocated())   # everything the backward pass needs is alive here
         loss.backward()
         if last:
             self.sync.finish()
@@ -95,17 +98,16 @@ class Trainer:
             self._pool_headroom()
             self._steps_seen = 3
 
-    @staticmethod
-    def _pool_headroom() -> None:
-        """Once, after the third step: bring the caching allocator's pool to what two steps in flight need -- 2.25 x the peak of live
-        bytes (two steps plus fragmentation; timing-independent), or MART_POOL_HEADROOM (default 10 %) above what is reserved, whichever is larger --
-        with one allocation per stream that is handed straight back.  A block that a side queue touched returns to the pool only when that queue has passed the free (record_stream), so the pool
+    def _pool_headroom(self) -> None:
+        """Once, after the third step: bring the caching allocator's pool to what two steps in flight need -- MART_POOL_FACTOR (default 2.5) x the live
+        bytes at the end of a forward pass (this trainer's own steps; timing-independent) -- with one allocation per stream pool that is handed
+        straight back.  A block that a side queue touched returns to the pool only when that queue has passed the free (record_stream), so the pool
         of a host that runs ahead holds two steps' worth of buffers plus whatever size classes happened to be pending when they were asked for:
         without this it grows by a hipMalloc about once per step for 25 steps (78.3 -> 82.4 GiB at B = 256), and when the first steps ran with the
         host NOT ahead (a cold process: libraries paging in) the whole second step's worth (32 GiB, ~140 allocations) is allocated later, in
-        whatever steps are being timed (tools/alloc_trace.py, profiles/r06_alloc_trace.txt).  With the slab cached those requests are carved from it."""
-        frac = float(os.environ.get("MART_POOL_HEADROOM", "0.10"))
-        if frac <= 0 or not torch.cuda.is_available():
+        whatever steps are being timed (tools/alloc_trace.py, profiles/r06_alloc_trace.txt).  With the slabs cached those requests are carved from
+        them.  Nothing happens when the pool is already that large (a process that has run something bigger before).  MART_POOL_HEADROOM=0: off."""
+        if os.environ.get("MART_POOL_HEADROOM", "1") in ("0", "0.0") or not torch.cuda.is_available() or self._live_peak <= 0:
             return
         # the allocator keeps one pool per stream (a block serves only the stream it was allocated on): the deficit is split over the streams in
         # proportion to what each has reserved so far, and each share is allocated -- and freed -- on its own stream
@@ -117,9 +119,9 @@ class Trainer:
         reserved = sum(by_stream.values())
         if reserved <= 0:
             return
-        deficit = max(2.25 * torch.cuda.max_memory_allocated(), (1.0 + frac) * reserved) - reserved
+        deficit = float(os.environ.get("MART_POOL_FACTOR", "2.5")) * self._live_peak - reserved
         free, _ = torch.cuda.mem_get_info()
-        if deficit > free // 2:
+        if deficit < (64 << 20) or deficit > free // 2:
             return
         for ptr, r in by_stream.items():
             want = int(deficit * r / reserved)

@@ -10,7 +10,7 @@ from mkg_analogy_amd.trainer import Trainer
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dev = torch.device("cuda:0")
-model, lit, cfg = B.build(16, seed=0, device=dev, backbone="mkgformer", entity_head=11292)
+model, lit, cfg = B.build(int(os.environ.get("PATCH", "16")), seed=0, device=dev, backbone="mkgformer", entity_head=11292)
 D.load_seeded_weights(model, lit, seed=0, conditioned=True)
 batch = D.make_batch(256, L, seed=1234, device=dev, pretrain=False, n_labels=11292)
 tr = Trainer(max_epochs=1, max_steps=10 * steps, world_size=1)
@@ -27,4 +27,5 @@ for i in range(steps):
           f"alloc_retries {st['num_alloc_retries']}  segments {st['segment.all.current']}", flush=True)
     prev = st
 torch.cuda.synchronize()
+print(f"live bytes at the end of a forward pass (Trainer._live_peak) {tr._live_peak / 2**30:.2f} GiB; peak of live bytes over the run {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
 print(torch.cuda.memory_summary(abbreviated=True))
